@@ -1,0 +1,44 @@
+/*
+ * oracle/zge_model.h -- TEST INFRASTRUCTURE ONLY (see oracle.h, zstd_enc_model.c).
+ * Parameters and records of the engine encoder's CPU model.
+ */
+#ifndef ZGE_MODEL_H
+#define ZGE_MODEL_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZGE_BLOCK (128 * 1024)
+#define ZGE_MIN_HUF_LITERALS 64
+
+typedef struct {
+    int level;        /* informational; selects the defaults                                   */
+    int checksum;     /* ZSTD_c_checksumFlag (crates/zarc-cli/src/pack.rs:227 always sets it)   */
+    int window_log;   /* frames larger than 2^window_log are not single-segment                */
+    int long_log, short_log, short_bytes;
+    int tile, sub, cap;
+    int min_match, min_rep, rep_search, back_cap, lazy, lazy_delta;
+    int lit_cost, match_cost, rep_cost;
+    int short_window_log; /* reach of the short-hash table (16 when its entries are u16) */
+} zge_params;
+
+typedef struct { uint32_t ll, ml, off, ofv; } zge_seq;
+
+typedef struct {
+    uint64_t seqs, rep_seqs, match_bytes, lit_bytes, lit_section, seq_section;
+    uint32_t blk_raw, blk_rle, blk_comp, lit_raw, lit_rle, lit_huf, seq_mode[4];
+} zge_stats;
+
+size_t zge_bound(size_t n);
+void zge_default_params(zge_params *P, int level);
+int zge_encode_frame(const zge_params *P, const void *src, size_t n, void *dst, size_t cap,
+                     size_t *out_len, zge_stats *st);
+uint32_t zge_ll_code(uint32_t ll);
+uint32_t zge_ml_code(uint32_t ml);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

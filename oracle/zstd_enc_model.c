@@ -1,0 +1,838 @@
+/*
+ * oracle/zstd_enc_model.c -- TEST INFRASTRUCTURE ONLY (see oracle.h).
+ *
+ * Scalar CPU model of the engine's Zstandard *encoder* ("ZGE").  libzstd's exact parse is not part of
+ * the contract at the reference's compress call site (crates/zarc/src/encode/lowlevel_frames.rs:29-31:
+ * any valid frame that round-trips is acceptable, and the pinned libzstd 1.5.5 is not available here),
+ * so the encoder is the engine's own design: a tile-parallel double-hash match finder plus Huffman /
+ * FSE entropy stages laid out for wave64 execution.  This file states that design
+ * as plain sequential C with every tie-break made explicit, so that
+ *   (1) its output is checked for *validity* by oracle_zstd_decode_frame and by real libzstd builds,
+ *   (2) the HIP kernels are checked *bit-exactly* against it on the same inputs.
+ * The frame/ block / section layouts follow RFC 8878 (and crates/ozarc/src/framing.rs:106-405).
+ */
+#include "oracle.h"
+#include "zge_model.h"
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ helpers ------------------ */
+static int hb32(uint32_t v) { int r = 0; while (v >>= 1) r++; return r; } /* floor(log2 v), v>0 */
+static uint64_t rd64(const uint8_t *p) { uint64_t v; memcpy(&v, p, 8); return v; }
+
+typedef struct { uint8_t *p; size_t pos, cap; uint64_t acc; int nb; int overflow; } bitw;
+static void bw_init(bitw *b, uint8_t *p, size_t cap) { b->p = p; b->pos = 0; b->cap = cap; b->acc = 0; b->nb = 0; b->overflow = 0; }
+static void bw_add(bitw *b, uint32_t v, int n)
+{
+    if (n == 0) return;
+    b->acc |= (uint64_t)(v & (n == 32 ? 0xFFFFFFFFu : ((1u << n) - 1))) << b->nb;
+    b->nb += n;
+    while (b->nb >= 8) {
+        if (b->pos < b->cap) b->p[b->pos] = (uint8_t)b->acc; else b->overflow = 1;
+        b->pos++;
+        b->acc >>= 8;
+        b->nb -= 8;
+    }
+}
+/* end mark: a single 1 bit then zero padding to a byte */
+static size_t bw_close(bitw *b)
+{
+    bw_add(b, 1, 1);
+    if (b->nb > 0) {
+        if (b->pos < b->cap) b->p[b->pos] = (uint8_t)b->acc; else b->overflow = 1;
+        b->pos++;
+        b->nb = 0;
+        b->acc = 0;
+    }
+    return b->pos;
+}
+
+/* ------------------------------------------------------------------ code tables -------------- */
+static const uint32_t LL_BASE[36] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18,
+                                     20, 22, 24, 28, 32, 40, 48, 64, 128, 256, 512, 1024, 2048,
+                                     4096, 8192, 16384, 32768, 65536};
+static const uint8_t LL_BITS[36] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1,
+                                    1, 1, 2, 2, 3, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+static const uint32_t ML_BASE[53] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19,
+                                     20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34,
+                                     35, 37, 39, 41, 43, 47, 51, 59, 67, 83, 99, 131, 259, 515,
+                                     1027, 2051, 4099, 8195, 16387, 32771, 65539};
+static const uint8_t ML_BITS[53] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                                    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1,
+                                    2, 2, 3, 3, 4, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+static const int16_t LL_DEFAULT[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2,
+                                       2, 2, 2, 2, 2, 2, 2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1};
+static const int16_t ML_DEFAULT[53] = {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+                                       1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+                                       1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1};
+static const int16_t OF_DEFAULT[29] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1,
+                                       1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1};
+
+uint32_t zge_ll_code(uint32_t ll)
+{
+    if (ll < 16) return ll;
+    if (ll < 64) { /* codes 16..24 */
+        static const uint8_t t[64] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 16, 16, 17, 17, 18, 18,
+                                      19, 19, 20, 20, 20, 20, 21, 21, 21, 21, 22, 22, 22, 22, 22, 22, 22, 22,
+                                      23, 23, 23, 23, 23, 23, 23, 23, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24,
+                                      24, 24, 24, 24, 24, 24};
+        return t[ll];
+    }
+    return (uint32_t)hb32(ll) + 19;
+}
+uint32_t zge_ml_code(uint32_t ml) /* ml >= 3 */
+{
+    uint32_t b = ml - 3;
+    if (b < 32) return b;
+    if (b < 128) {
+        /* base-3 values 32..127 -> codes 32..42 */
+        static const uint8_t lim[11] = {34, 36, 38, 40, 44, 48, 56, 64, 80, 96, 128};
+        uint32_t c = 0;
+        while (b >= lim[c]) c++;
+        return 32 + c;
+    }
+    return (uint32_t)hb32(b) + 36;
+}
+
+/* ------------------------------------------------------------------ FSE (encoder side) ------- */
+typedef struct {
+    uint16_t state_tab[512];     /* cumul-ordered cell -> state value (T + cell position)        */
+    int32_t  delta_nb[64];       /* (maxBitsOut<<16) - minStatePlus                                */
+    int32_t  delta_find[64];
+    int al;
+} fse_ctab;
+
+/* Build the encoding table from normalized counts (norm: -1 = "less than one"). */
+static void fse_build_ctab(fse_ctab *t, const int16_t *norm, int nsym, int al)
+{
+    int T = 1 << al, high = T - 1, s, i, pos = 0, step = (T >> 1) + (T >> 3) + 3, mask = T - 1;
+    uint8_t cellsym[512];
+    int cumul[65], total;
+    for (s = 0; s < nsym; s++)
+        if (norm[s] == -1) cellsym[high--] = (uint8_t)s;
+    for (s = 0; s < nsym; s++) {
+        if (norm[s] <= 0) continue;
+        for (i = 0; i < norm[s]; i++) {
+            cellsym[pos] = (uint8_t)s;
+            do { pos = (pos + step) & mask; } while (pos > high);
+        }
+    }
+    cumul[0] = 0;
+    for (s = 0; s < nsym; s++) cumul[s + 1] = cumul[s] + (norm[s] == -1 ? 1 : norm[s]);
+    {
+        int next[64];
+        for (s = 0; s < nsym; s++) next[s] = cumul[s];
+        for (i = 0; i < T; i++) t->state_tab[next[cellsym[i]]++] = (uint16_t)(T + i);
+    }
+    total = 0;
+    for (s = 0; s < nsym; s++) {
+        int n = norm[s];
+        if (n == 0) { t->delta_nb[s] = ((al + 1) << 16) - T; t->delta_find[s] = 0; continue; }
+        if (n == -1 || n == 1) {
+            t->delta_nb[s] = (al << 16) - T;
+            t->delta_find[s] = total - 1;
+            total += 1;
+        } else {
+            int max_bits_out = al - hb32((uint32_t)(n - 1));
+            int min_state_plus = n << max_bits_out;
+            t->delta_nb[s] = (max_bits_out << 16) - min_state_plus;
+            t->delta_find[s] = total - n;
+            total += n;
+        }
+    }
+    t->al = al;
+}
+static uint32_t fse_init_state(const fse_ctab *t, int s)
+{
+    /* the symbol's lowest state: guarantees the largest bit count on its first transition */
+    int nb = (t->delta_nb[s] + (1 << 15)) >> 16;
+    int value = (nb << 16) - t->delta_nb[s];
+    return t->state_tab[(value >> nb) + t->delta_find[s]];
+}
+static uint32_t fse_encode(const fse_ctab *t, bitw *b, uint32_t state, int s)
+{
+    int nb = (int)((state + (uint32_t)t->delta_nb[s]) >> 16);
+    bw_add(b, state, nb);
+    return t->state_tab[(int)(state >> nb) + t->delta_find[s]];
+}
+static void fse_flush(const fse_ctab *t, bitw *b, uint32_t state) { bw_add(b, state, t->al); }
+
+/* fixed-point log2: returns 256*log2(x) for x>=1 (linear interpolation of the mantissa) */
+static uint32_t log2_fp8(uint32_t x)
+{
+    int h = hb32(x);
+    uint32_t frac = h >= 8 ? (x >> (h - 8)) - 256 : (x << (8 - h)) - 256; /* 0..255 */
+    return (uint32_t)h * 256 + frac;
+}
+
+/* Normalize counts to sum 2^al.  Every present symbol gets >= 1.  Deterministic:
+ * round-to-nearest, then the surplus/deficit is applied to the largest entries. */
+static void fse_normalize(const uint32_t *count, int nsym, uint32_t total, int al, int16_t *norm)
+{
+    int T = 1 << al, sum = 0, s;
+    for (s = 0; s < nsym; s++) {
+        if (count[s] == 0) { norm[s] = 0; continue; }
+        {
+            uint64_t v = ((uint64_t)count[s] * (uint64_t)T + total / 2) / total;
+            if (v < 1) v = 1;
+            norm[s] = (int16_t)v;
+            sum += (int)v;
+        }
+    }
+    while (sum != T) {
+        /* pick the entry with the largest norm (lowest symbol wins ties) */
+        int best = -1;
+        for (s = 0; s < nsym; s++)
+            if (norm[s] > 0 && (best < 0 || norm[s] > norm[best])) best = s;
+        if (sum > T) {
+            int take = sum - T, room = norm[best] - 1;
+            if (take > room) take = room;
+            if (take <= 0) break; /* cannot happen while T >= number of present symbols */
+            norm[best] = (int16_t)(norm[best] - take);
+            sum -= take;
+        } else {
+            norm[best] = (int16_t)(norm[best] + (T - sum));
+            sum = T;
+        }
+    }
+}
+
+/* Write an FSE table description (RFC 8878 4.1.1); returns bytes written. */
+static size_t fse_write_desc(uint8_t *dst, size_t cap, const int16_t *norm, int nsym, int al)
+{
+    bitw b;
+    int remaining = (1 << al) + 1, threshold = 1 << al, nb = al + 1, s = 0;
+    bw_init(&b, dst, cap);
+    bw_add(&b, (uint32_t)(al - 5), 4);
+    while (remaining > 1 && s < nsym) {
+        int count = norm[s++], max = 2 * threshold - 1 - remaining, val = count + 1;
+        remaining -= count < 0 ? -count : count;
+        if (val >= threshold) val += max;          /* large values are shifted up by max   */
+        if (val < max) bw_add(&b, (uint32_t)val, nb - 1);   /* small values use nb-1 bits  */
+        else bw_add(&b, (uint32_t)val, nb);
+        if (count == 0) {
+            /* run of further zero-probability symbols, 2-bit repeat fields */
+            int run = 0;
+            while (s + run < nsym && norm[s + run] == 0) run++;
+            s += run;
+            while (run >= 3) { bw_add(&b, 3, 2); run -= 3; }
+            bw_add(&b, (uint32_t)run, 2);
+        }
+        while (remaining < threshold) { nb--; threshold >>= 1; }
+    }
+    if (b.nb > 0) { /* flush partial byte, no end mark in forward streams */
+        if (b.pos < b.cap) b.p[b.pos] = (uint8_t)b.acc; else b.overflow = 1;
+        b.pos++;
+    }
+    return b.overflow ? 0 : b.pos;
+}
+
+/* ------------------------------------------------------------------ Huffman ------------------- */
+#define HUF_MAXBITS 11
+/* Code lengths for `count[256]`, limited to HUF_MAXBITS.  Returns number of present symbols. */
+static int huf_build_lengths(const uint32_t *count, uint8_t *len)
+{
+    int order[256], n = 0, i, j;
+    uint32_t w[512];
+    int parent[512], depth[512];
+    memset(len, 0, 256);
+    for (i = 0; i < 256; i++) if (count[i]) order[n++] = i;
+    if (n < 2) { if (n == 1) len[order[0]] = 1; return n; }
+    /* sort ascending by (count, symbol): rank-by-counting in the kernel, insertion sort here */
+    for (i = 1; i < n; i++) {
+        int s = order[i];
+        for (j = i; j > 0 && (count[order[j - 1]] > count[s]); j--) order[j] = order[j - 1];
+        order[j] = s;
+    }
+    /* two-queue Huffman: leaves 0..n-1 (sorted), internal nodes n..2n-2 created in order */
+    for (i = 0; i < n; i++) w[i] = count[order[i]];
+    {
+        int leaf = 0, inode = n, next = n;
+        while (next < 2 * n - 1) {
+            int a, b;
+            /* ties: prefer the leaf (keeps the tree shallow) */
+            if (leaf < n && (inode >= next || w[leaf] <= w[inode])) a = leaf++; else a = inode++;
+            if (leaf < n && (inode >= next || w[leaf] <= w[inode])) b = leaf++; else b = inode++;
+            w[next] = w[a] + w[b];
+            parent[a] = next;
+            parent[b] = next;
+            next++;
+        }
+        depth[2 * n - 2] = 0;
+        for (i = 2 * n - 3; i >= 0; i--) depth[i] = depth[parent[i]] + 1;
+    }
+    {
+        /* histogram of leaf depths, clamp to HUF_MAXBITS and repair the Kraft sum */
+        int num[64], k;
+        uint32_t total = 0;
+        memset(num, 0, sizeof num);
+        for (i = 0; i < n; i++) num[depth[i] > 63 ? 63 : depth[i]]++;
+        for (k = HUF_MAXBITS + 1; k < 64; k++) { num[HUF_MAXBITS] += num[k]; num[k] = 0; }
+        for (k = 1; k <= HUF_MAXBITS; k++) total += (uint32_t)num[k] << (HUF_MAXBITS - k);
+        while (total != (1u << HUF_MAXBITS)) {
+            num[HUF_MAXBITS]--;
+            for (k = HUF_MAXBITS - 1; k > 0; k--)
+                if (num[k]) { num[k]--; num[k + 1] += 2; break; }
+            total--;
+        }
+        /* most frequent symbols (end of `order`) get the shortest codes */
+        i = n - 1;
+        for (k = 1; k <= HUF_MAXBITS; k++) {
+            int c;
+            for (c = 0; c < num[k]; c++) len[order[i--]] = (uint8_t)k;
+        }
+    }
+    return n;
+}
+
+typedef struct { uint16_t code[256]; uint8_t len[256]; int max_bits; int nsym_last; } huf_ctab;
+
+/* Canonical code assignment in zstd's weight order (RFC 8878 4.2.1). */
+static void huf_assign_codes(huf_ctab *h)
+{
+    int maxlen = 0, i, w;
+    uint32_t rank_start[16], rank_count[16];
+    h->nsym_last = 0;
+    for (i = 0; i < 256; i++) if (h->len[i]) { if (h->len[i] > maxlen) maxlen = h->len[i]; h->nsym_last = i; }
+    h->max_bits = maxlen;
+    memset(rank_count, 0, sizeof rank_count);
+    for (i = 0; i < 256; i++) if (h->len[i]) rank_count[maxlen + 1 - h->len[i]]++;
+    {
+        uint32_t pos = 0;
+        for (w = 1; w <= maxlen; w++) { rank_start[w] = pos; pos += rank_count[w] << (w - 1); }
+    }
+    for (i = 0; i < 256; i++) {
+        if (!h->len[i]) { h->code[i] = 0; continue; }
+        w = maxlen + 1 - h->len[i];
+        h->code[i] = (uint16_t)(rank_start[w] >> (w - 1));
+        rank_start[w] += 1u << (w - 1);
+    }
+}
+
+/* Huffman tree description.  Returns bytes written (0 = cannot represent). */
+static size_t huf_write_desc(const huf_ctab *h, uint8_t *dst, size_t cap)
+{
+    uint8_t wt[256];
+    int n = h->nsym_last, i; /* explicit weights for symbols 0..n-1; symbol n is implied */
+    for (i = 0; i < n; i++) wt[i] = h->len[i] ? (uint8_t)(h->max_bits + 1 - h->len[i]) : 0;
+    /* FSE-compressed weights */
+    if (n > 1) {
+        uint32_t count[16];
+        int16_t norm[16];
+        int nsym = 0, distinct = 0, al = 6, s;
+        uint32_t maxc = 0;
+        uint8_t tmp[160];
+        size_t hdr;
+        memset(count, 0, sizeof count);
+        for (i = 0; i < n; i++) count[wt[i]]++;
+        for (s = 0; s < 13; s++) if (count[s]) { nsym = s + 1; distinct++; if (count[s] > maxc) maxc = count[s]; }
+        if (distinct > 1 && maxc > 1) {
+            fse_ctab ct;
+            bitw b;
+            uint32_t s1, s2;
+            int ip = n;
+            size_t body;
+            /* accuracy: at most 6, lower for few weights */
+            { int lim = hb32((uint32_t)(n - 1)) - 2; if (lim < al) al = lim; if (al < 5) al = 5; }
+            while ((1 << al) < distinct) al++;
+            fse_normalize(count, nsym, (uint32_t)n, al, norm);
+            hdr = fse_write_desc(tmp, sizeof tmp, norm, nsym, al);
+            if (hdr) {
+                fse_build_ctab(&ct, norm, nsym, al);
+                bw_init(&b, tmp + hdr, sizeof tmp - hdr);
+                if (n & 1) {
+                    s1 = fse_init_state(&ct, wt[--ip]);
+                    s2 = fse_init_state(&ct, wt[--ip]);
+                    s1 = fse_encode(&ct, &b, s1, wt[--ip]);
+                } else {
+                    s2 = fse_init_state(&ct, wt[--ip]);
+                    s1 = fse_init_state(&ct, wt[--ip]);
+                }
+                while (ip > 0) {
+                    s2 = fse_encode(&ct, &b, s2, wt[--ip]);
+                    s1 = fse_encode(&ct, &b, s1, wt[--ip]);
+                }
+                fse_flush(&ct, &b, s2);
+                fse_flush(&ct, &b, s1);
+                body = bw_close(&b);
+                if (!b.overflow && hdr + body < 128 && (n > 128 || hdr + body < (size_t)(n + 1) / 2) && 1 + hdr + body <= cap) {
+                    dst[0] = (uint8_t)(hdr + body);
+                    memcpy(dst + 1, tmp, hdr + body);
+                    return 1 + hdr + body;
+                }
+            }
+        }
+    }
+    if (n > 128) return 0;
+    if ((size_t)(1 + (n + 1) / 2) > cap) return 0;
+    dst[0] = (uint8_t)(127 + n);
+    for (i = 0; i < n; i += 2) dst[1 + i / 2] = (uint8_t)((wt[i] << 4) | (i + 1 < n ? wt[i + 1] : 0));
+    return (size_t)(1 + (n + 1) / 2);
+}
+
+/* one backward Huffman stream over lit[0..n): symbols are written last-to-first */
+static size_t huf_encode_stream(const huf_ctab *h, const uint8_t *lit, size_t n, uint8_t *dst, size_t cap)
+{
+    bitw b;
+    size_t i;
+    bw_init(&b, dst, cap);
+    for (i = n; i > 0; i--) bw_add(&b, h->code[lit[i - 1]], h->len[lit[i - 1]]);
+    bw_close(&b);
+    return b.overflow ? 0 : b.pos;
+}
+
+/* Literals section.  Returns bytes written. */
+static size_t encode_literals(const uint8_t *lit, size_t n, uint8_t *dst, size_t cap, zge_stats *st)
+{
+    uint32_t count[256];
+    size_t i, raw_hdr = n < 32 ? 1 : (n < 4096 ? 2 : 3);
+    int distinct = 0;
+    memset(count, 0, sizeof count);
+    for (i = 0; i < n; i++) count[lit[i]]++;
+    for (i = 0; i < 256; i++) if (count[i]) distinct++;
+    if (n > 0 && distinct == 1 && n >= 2) {            /* RLE literals */
+        if (raw_hdr + 1 > cap) return 0;
+        if (raw_hdr == 1) dst[0] = (uint8_t)(1 | (n << 3));
+        else if (raw_hdr == 2) { dst[0] = (uint8_t)(1 | (1 << 2) | ((n & 15) << 4)); dst[1] = (uint8_t)(n >> 4); }
+        else { dst[0] = (uint8_t)(1 | (3 << 2) | ((n & 15) << 4)); dst[1] = (uint8_t)(n >> 4); dst[2] = (uint8_t)(n >> 12); }
+        dst[raw_hdr] = lit[0];
+        if (st) st->lit_rle++;
+        return raw_hdr + 1;
+    }
+    if (n >= ZGE_MIN_HUF_LITERALS && distinct >= 2) {
+        huf_ctab h;
+        uint8_t desc[160];
+        size_t dlen, est_bits = 0, est;
+        huf_build_lengths(count, h.len);
+        huf_assign_codes(&h);
+        dlen = huf_write_desc(&h, desc, sizeof desc);
+        for (i = 0; i < 256; i++) est_bits += (size_t)count[i] * h.len[i];
+        est = dlen + (est_bits + 7) / 8 + (n >= 256 ? 6 + 4 : 1);
+        if (dlen && est + 3 < n) {
+            int single = n < 256;
+            size_t hdr = single ? 3 : (n < 1024 ? 3 : (n < 16384 ? 4 : 5));
+            uint8_t *body = dst + hdr;
+            size_t bcap = cap > hdr ? cap - hdr : 0, pos, comp;
+            if (bcap < dlen + 6) return 0;
+            memcpy(body, desc, dlen);
+            pos = dlen;
+            if (single) {
+                size_t s = huf_encode_stream(&h, lit, n, body + pos, bcap - pos);
+                if (!s) return 0;
+                pos += s;
+            } else {
+                size_t per = (n + 3) / 4, s[4], jt = pos, k;
+                pos += 6;
+                for (k = 0; k < 4; k++) {
+                    size_t beg = k * per, cnt = k < 3 ? per : n - 3 * per;
+                    s[k] = huf_encode_stream(&h, lit + beg, cnt, body + pos, bcap - pos);
+                    if (!s[k]) return 0;
+                    pos += s[k];
+                }
+                for (k = 0; k < 3; k++) { body[jt + 2 * k] = (uint8_t)s[k]; body[jt + 2 * k + 1] = (uint8_t)(s[k] >> 8); }
+                if (s[0] > 65535 || s[1] > 65535 || s[2] > 65535) return 0;
+            }
+            comp = pos;
+            if (comp + hdr < n + raw_hdr) {
+                /* sizes must fit the chosen header; hdr was chosen from n, comp < n here */
+                uint64_t v;
+                if (hdr == 3) { v = 2u | ((single ? 0u : 1u) << 2) | ((uint64_t)n << 4) | ((uint64_t)comp << 14); }
+                else if (hdr == 4) { v = 2u | (2u << 2) | ((uint64_t)n << 4) | ((uint64_t)comp << 18); }
+                else { v = 2u | (3u << 2) | ((uint64_t)n << 4) | ((uint64_t)comp << 22); }
+                for (i = 0; i < hdr; i++) dst[i] = (uint8_t)(v >> (8 * i));
+                if (st) st->lit_huf++;
+                return hdr + comp;
+            }
+        }
+    }
+    /* raw literals */
+    if (raw_hdr + n > cap) return 0;
+    if (raw_hdr == 1) dst[0] = (uint8_t)(0 | (n << 3));
+    else if (raw_hdr == 2) { dst[0] = (uint8_t)(0 | (1 << 2) | ((n & 15) << 4)); dst[1] = (uint8_t)(n >> 4); }
+    else { dst[0] = (uint8_t)(0 | (3 << 2) | ((n & 15) << 4)); dst[1] = (uint8_t)(n >> 4); dst[2] = (uint8_t)(n >> 12); }
+    memcpy(dst + raw_hdr, lit, n);
+    if (st) st->lit_raw++;
+    return raw_hdr + n;
+}
+
+/* ------------------------------------------------------------------ sequences section -------- */
+/* cost in 1/256 bit of coding `count` with the distribution `norm` of accuracy `al` */
+static uint64_t dist_cost(const uint32_t *count, const int16_t *norm, int nsym, int al)
+{
+    uint64_t c = 0;
+    int s;
+    for (s = 0; s < nsym; s++) {
+        uint32_t n;
+        if (!count[s]) continue;
+        if (norm[s] == 0) return (uint64_t)-1;     /* cannot be coded */
+        n = norm[s] < 0 ? 1u : (uint32_t)norm[s];
+        c += (uint64_t)count[s] * ((uint32_t)al * 256 - log2_fp8(n));
+    }
+    return c;
+}
+
+typedef struct { int mode; int16_t norm[64]; int nsym; int al; uint8_t rle_sym; uint8_t desc[80]; size_t desc_len; } seq_table_choice;
+
+static void choose_table(seq_table_choice *c, const uint32_t *count, int maxsym, uint32_t nseq,
+                         const int16_t *def, int def_n, int def_al, int max_al)
+{
+    int s, distinct = 0, last = 0, al;
+    uint64_t cost_def, cost_dyn;
+    for (s = 0; s <= maxsym; s++) if (count[s]) { distinct++; last = s; }
+    if (distinct == 1) { c->mode = 1; c->rle_sym = (uint8_t)last; c->desc_len = 0; return; }
+    cost_def = last < def_n ? dist_cost(count, def, def_n, def_al) : (uint64_t)-1;
+    /* dynamic table */
+    al = hb32(nseq > 1 ? nseq - 1 : 1) - 2;
+    if (al > max_al) al = max_al;
+    if (al < 5) al = 5;
+    while ((1 << al) < distinct) al++;
+    c->nsym = last + 1;
+    c->al = al;
+    fse_normalize(count, c->nsym, nseq, al, c->norm);
+    c->desc_len = fse_write_desc(c->desc, sizeof c->desc, c->norm, c->nsym, al);
+    cost_dyn = c->desc_len ? dist_cost(count, c->norm, c->nsym, al) + (uint64_t)c->desc_len * 8 * 256 : (uint64_t)-1;
+    if (cost_def <= cost_dyn) {
+        c->mode = 0;
+        c->nsym = def_n;
+        c->al = def_al;
+        memcpy(c->norm, def, sizeof(int16_t) * (size_t)def_n);
+        c->desc_len = 0;
+    } else {
+        c->mode = 2;
+    }
+}
+
+static size_t encode_sequences(const zge_seq *seq, uint32_t nseq, uint8_t *dst, size_t cap, zge_stats *st)
+{
+    size_t pos = 0;
+    uint32_t cl[36], co[32], cm[53], i;
+    seq_table_choice tl, to, tm;
+    fse_ctab ctl, cto, ctm;
+    bitw b;
+    if (cap < 4) return 0;
+    if (nseq < 128) dst[pos++] = (uint8_t)nseq;
+    else if (nseq < 0x7F00) { dst[pos++] = (uint8_t)((nseq >> 8) + 128); dst[pos++] = (uint8_t)nseq; }
+    else { dst[pos++] = 255; dst[pos++] = (uint8_t)(nseq - 0x7F00); dst[pos++] = (uint8_t)((nseq - 0x7F00) >> 8); }
+    if (nseq == 0) return pos;
+    memset(cl, 0, sizeof cl); memset(co, 0, sizeof co); memset(cm, 0, sizeof cm);
+    for (i = 0; i < nseq; i++) {
+        cl[zge_ll_code(seq[i].ll)]++;
+        cm[zge_ml_code(seq[i].ml)]++;
+        co[hb32(seq[i].ofv)]++;
+    }
+    choose_table(&tl, cl, 35, nseq, LL_DEFAULT, 36, 6, 9);
+    choose_table(&to, co, 31, nseq, OF_DEFAULT, 29, 5, 8);
+    choose_table(&tm, cm, 52, nseq, ML_DEFAULT, 53, 6, 9);
+    if (st) { st->seq_mode[tl.mode]++; st->seq_mode[to.mode]++; st->seq_mode[tm.mode]++; }
+    if (pos + 1 + 3 + tl.desc_len + to.desc_len + tm.desc_len > cap) return 0;
+    dst[pos++] = (uint8_t)((tl.mode << 6) | (to.mode << 4) | (tm.mode << 2));
+    if (tl.mode == 1) dst[pos++] = tl.rle_sym; else { memcpy(dst + pos, tl.desc, tl.desc_len); pos += tl.desc_len; }
+    if (to.mode == 1) dst[pos++] = to.rle_sym; else { memcpy(dst + pos, to.desc, to.desc_len); pos += to.desc_len; }
+    if (tm.mode == 1) dst[pos++] = tm.rle_sym; else { memcpy(dst + pos, tm.desc, tm.desc_len); pos += tm.desc_len; }
+    if (tl.mode != 1) fse_build_ctab(&ctl, tl.norm, tl.nsym, tl.al);
+    if (to.mode != 1) fse_build_ctab(&cto, to.norm, to.nsym, to.al);
+    if (tm.mode != 1) fse_build_ctab(&ctm, tm.norm, tm.nsym, tm.al);
+    bw_init(&b, dst + pos, cap - pos);
+    {
+        uint32_t sl = 0, so = 0, sm = 0;
+        uint32_t n = nseq - 1;
+        uint32_t llc = zge_ll_code(seq[n].ll), mlc = zge_ml_code(seq[n].ml), ofc = (uint32_t)hb32(seq[n].ofv);
+        if (tm.mode != 1) sm = fse_init_state(&ctm, (int)mlc);
+        if (to.mode != 1) so = fse_init_state(&cto, (int)ofc);
+        if (tl.mode != 1) sl = fse_init_state(&ctl, (int)llc);
+        bw_add(&b, seq[n].ll - LL_BASE[llc], LL_BITS[llc]);
+        bw_add(&b, seq[n].ml - ML_BASE[mlc], ML_BITS[mlc]);
+        bw_add(&b, seq[n].ofv - (1u << ofc), (int)ofc);
+        while (n > 0) {
+            n--;
+            llc = zge_ll_code(seq[n].ll); mlc = zge_ml_code(seq[n].ml); ofc = (uint32_t)hb32(seq[n].ofv);
+            if (to.mode != 1) so = fse_encode(&cto, &b, so, (int)ofc);
+            if (tm.mode != 1) sm = fse_encode(&ctm, &b, sm, (int)mlc);
+            if (tl.mode != 1) sl = fse_encode(&ctl, &b, sl, (int)llc);
+            bw_add(&b, seq[n].ll - LL_BASE[llc], LL_BITS[llc]);
+            bw_add(&b, seq[n].ml - ML_BASE[mlc], ML_BITS[mlc]);
+            bw_add(&b, seq[n].ofv - (1u << ofc), (int)ofc);
+        }
+        if (tm.mode != 1) fse_flush(&ctm, &b, sm);
+        if (to.mode != 1) fse_flush(&cto, &b, so);
+        if (tl.mode != 1) fse_flush(&ctl, &b, sl);
+    }
+    bw_close(&b);
+    if (b.overflow) return 0;
+    return pos + b.pos;
+}
+
+/* ------------------------------------------------------------------ match finder ------------- */
+static uint32_t hash_long(uint64_t v, int bits) { return (uint32_t)((v * 0xCF1BBCDCB7A56463ULL) >> (64 - bits)); }
+static uint32_t hash_short(uint64_t v, int bits, int nbytes)
+{
+    return (uint32_t)(((v << (64 - 8 * nbytes)) * 0x9E3779B185EBCA87ULL) >> (64 - bits));
+}
+
+/* common prefix length of src[p..] and src[q..], q < p, at most `limit` bytes */
+static uint32_t match_len(const uint8_t *src, size_t p, size_t q, uint32_t limit)
+{
+    uint32_t n = 0;
+    while (n + 8 <= limit) {
+        uint64_t x = rd64(src + p + n) ^ rd64(src + q + n);
+        if (x) return n + (uint32_t)(__builtin_ctzll(x) >> 3);
+        n += 8;
+    }
+    while (n < limit && src[p + n] == src[q + n]) n++;
+    return n;
+}
+
+typedef struct { uint32_t len, off; uint8_t back, is_rep; int32_t score; } cand;
+
+static int32_t score_of(const zge_params *P, uint32_t len, uint32_t off, int is_rep)
+{
+    if (is_rep) return (int32_t)(P->lit_cost * len) - P->rep_cost;
+    return (int32_t)(P->lit_cost * len) - P->match_cost - hb32(off);
+}
+
+typedef struct {
+    const zge_params *P;
+    const uint8_t *src;
+    size_t n;
+    uint32_t *tl, *ts;       /* long / short tables: value = position+1, 0 = empty */
+    uint32_t rep[3];         /* live repeat-offset history (encoder side)            */
+    size_t window;
+    cand *M;                 /* per-tile candidates                                   */
+    zge_stats *st;
+} mf_ctx;
+
+/* emit one sequence: resolves the offset against the live repcode history */
+static void emit_seq(mf_ctx *c, zge_seq *out, uint32_t ll, uint32_t ml, uint32_t off)
+{
+    uint32_t *r = c->rep, ofv;
+    if (ll > 0) {
+        if (off == r[0]) ofv = 1;
+        else if (off == r[1]) { ofv = 2; r[1] = r[0]; r[0] = off; }
+        else if (off == r[2]) { ofv = 3; r[2] = r[1]; r[1] = r[0]; r[0] = off; }
+        else { ofv = off + 3; r[2] = r[1]; r[1] = r[0]; r[0] = off; }
+    } else {
+        if (off == r[1]) { ofv = 1; r[1] = r[0]; r[0] = off; }
+        else if (off == r[2]) { ofv = 2; r[2] = r[1]; r[1] = r[0]; r[0] = off; }
+        else if (r[0] > 1 && off == r[0] - 1) { ofv = 3; r[2] = r[1]; r[1] = r[0]; r[0] = off; }
+        else { ofv = off + 3; r[2] = r[1]; r[1] = r[0]; r[0] = off; }
+    }
+    out->ll = ll; out->ml = ml; out->off = off; out->ofv = ofv;
+    if (c->st) { if (ofv <= 3) c->st->rep_seqs++; c->st->seqs++; c->st->match_bytes += ml; }
+}
+
+/* Process one block [bs, be): fills seq[], lit[]; returns nseq, *nlit. */
+static uint32_t matchfind_block(mf_ctx *c, size_t bs, size_t be, zge_seq *seq, uint8_t *lit, size_t *nlit)
+{
+    const zge_params *P = c->P;
+    const uint8_t *src = c->src;
+    size_t anchor = bs, pos = bs, tile, lp = 0;
+    uint32_t nseq = 0;
+    /* positions with fewer than 8 readable bytes are never hashed */
+    size_t hash_end = c->n >= 8 ? c->n - 7 : 0; /* p < hash_end is hashable */
+    for (tile = bs; tile < be; tile += (size_t)P->tile) {
+        size_t tend = tile + (size_t)P->tile < be ? tile + (size_t)P->tile : be, p, sub;
+        uint32_t rep0 = c->rep[0], rep1 = c->rep[1];
+        if (pos >= tend) continue; /* whole tile already covered by a match: skip it */
+        /* stage A: ordered lookup + insert, in sub-tiles (lookups of a sub-tile see inserts of earlier ones) */
+        for (sub = tile; sub < tend; sub += (size_t)P->sub) {
+            size_t send = sub + (size_t)P->sub < tend ? sub + (size_t)P->sub : tend;
+            for (p = sub; p < send; p++) {
+                cand *m = &c->M[p - tile];
+                m->len = 0; m->off = 0; m->back = 0; m->is_rep = 0; m->score = -1000000;
+                if (p < hash_end) {
+                    uint64_t v = rd64(src + p);
+                    m->off = c->tl[hash_long(v, P->long_log)];            /* stash candidates */
+                    m->len = c->ts[hash_short(v, P->short_log, P->short_bytes)];
+                }
+            }
+            for (p = sub; p < send && p < hash_end; p++) {
+                uint64_t v = rd64(src + p);
+                c->tl[hash_long(v, P->long_log)] = (uint32_t)p + 1;       /* ascending: max wins */
+                c->ts[hash_short(v, P->short_log, P->short_bytes)] = (uint32_t)p + 1;
+            }
+        }
+        /* stage B: evaluate candidates (independent per position) */
+        for (p = tile; p < tend; p++) {
+            cand *m = &c->M[p - tile];
+            uint32_t cl = m->off, cs = m->len, limit = (uint32_t)(be - p), cap = limit < (uint32_t)P->cap ? limit : (uint32_t)P->cap;
+            uint32_t best_len = 0, best_off = 0; int best_rep = 0; int32_t best_score = -1000000;
+            uint32_t k, cands[2];
+            m->len = 0; m->off = 0;
+            cands[0] = cl; cands[1] = cs;
+            for (k = 0; k < 2; k++) {
+                uint32_t q1 = cands[k], off, len; int32_t sc;
+                if (!q1) continue;
+                off = (uint32_t)p - (q1 - 1);
+                if (off == 0 || off > c->window) continue;
+                if (k == 1 && (cands[0] == cands[1] || off > ((uint32_t)1 << P->short_window_log))) continue;
+                len = match_len(src, p, p - off, cap);
+                if (len < (uint32_t)P->min_match) continue;
+                sc = score_of(P, len, off, 0);
+                if (sc > best_score) { best_score = sc; best_len = len; best_off = off; best_rep = 0; }
+            }
+            if (P->rep_search) {
+                uint32_t reps[2]; reps[0] = rep0; reps[1] = rep1;
+                for (k = 0; k < (uint32_t)P->rep_search; k++) {
+                    uint32_t off = reps[k], len; int32_t sc;
+                    if (off == 0 || off > p || off > c->window) continue;
+                    len = match_len(src, p, p - off, cap);
+                    if (len < (uint32_t)P->min_rep) continue;
+                    sc = score_of(P, len, off, 1);
+                    if (sc > best_score) { best_score = sc; best_len = len; best_off = off; best_rep = 1; }
+                }
+            }
+            if (best_len && best_score > 0) {
+                uint32_t back = 0;
+                m->len = best_len; m->off = best_off; m->is_rep = (uint8_t)best_rep; m->score = best_score;
+                /* backward extension potential (at most back_cap bytes) */
+                while (back < (uint32_t)P->back_cap && p - back > bs && p - back > best_off &&
+                       src[p - back - 1] == src[p - back - 1 - best_off]) back++;
+                m->back = (uint8_t)back;
+            }
+        }
+        /* stage C: serial selection over the tile, in chunks of 64 positions */
+        {
+            size_t chunk;
+            for (chunk = tile; chunk < tend; chunk += 64) {
+                size_t cend = chunk + 64 < tend ? chunk + 64 : tend;
+                p = pos > chunk ? pos : chunk;
+                while (p < cend) {
+                    cand *m = &c->M[p - tile];
+                    uint32_t len, off, back, ll;
+                    size_t q;
+                    if (m->len == 0) { p++; continue; }
+                    /* lazy: a better match starting one byte later inside the same chunk wins */
+                    if (P->lazy && p + 1 < cend) {
+                        cand *m2 = &c->M[p + 1 - tile];
+                        if (m2->len && m2->score > m->score + P->lazy_delta) { p++; continue; }
+                    }
+                    len = m->len; off = m->off; q = p;
+                    if (len == (uint32_t)P->cap) { /* forward extension of a capped match */
+                        uint32_t limit = (uint32_t)(be - q);
+                        len = match_len(src, q, q - off, limit);
+                    }
+                    back = m->back;
+                    if (back > q - anchor) back = (uint32_t)(q - anchor);
+                    q -= back; len += back;
+                    ll = (uint32_t)(q - anchor);
+                    memcpy(lit + lp, src + anchor, ll);
+                    lp += ll;
+                    emit_seq(c, &seq[nseq++], ll, len, off);
+                    anchor = q + len;
+                    p = anchor;
+                }
+                if (p > pos) pos = p;
+            }
+        }
+    }
+    /* trailing literals of the block */
+    memcpy(lit + lp, src + anchor, be - anchor);
+    lp += be - anchor;
+    *nlit = lp;
+    return nseq;
+}
+
+/* ------------------------------------------------------------------ frame --------------------- */
+size_t zge_bound(size_t n)
+{
+    size_t blocks = (n + ZGE_BLOCK - 1) / ZGE_BLOCK;
+    if (blocks == 0) blocks = 1;
+    return n + 3 * blocks + 18;
+}
+
+void zge_default_params(zge_params *P, int level)
+{
+    memset(P, 0, sizeof *P);
+    P->level = level;
+    P->checksum = 1;
+    P->long_log = 14; P->short_log = 14; P->short_bytes = 5;
+    P->tile = 1024; P->sub = 64; P->cap = 32;
+    P->min_match = 5; P->min_rep = 3; P->rep_search = 2;
+    P->back_cap = 8; P->lazy = 1; P->lazy_delta = 5;
+    P->lit_cost = 5; P->match_cost = 12; P->rep_cost = 9;
+    P->window_log = 21; P->short_window_log = 30;
+}
+
+int zge_encode_frame(const zge_params *P, const void *src_, size_t n, void *dst_, size_t cap,
+                     size_t *out_len, zge_stats *st)
+{
+    const uint8_t *src = (const uint8_t *)src_;
+    uint8_t *dst = (uint8_t *)dst_;
+    size_t pos = 0, bs;
+    mf_ctx c;
+    zge_seq *seq;
+    uint8_t *lit, *blk;
+    int wlog, single;
+    if (cap < zge_bound(n)) return -1;
+    if (st) memset(st, 0, sizeof *st);
+    /* frame header */
+    dst[pos++] = 0x28; dst[pos++] = 0xB5; dst[pos++] = 0x2F; dst[pos++] = 0xFD;
+    wlog = P->window_log;
+    single = n <= ((size_t)1 << wlog);
+    {
+        int fcs_flag = n < 256 ? 0 : (n < 65536 + 256 ? 1 : (n <= 0xFFFFFFFFu ? 2 : 3));
+        int i, fcs_bytes = fcs_flag == 0 ? (single ? 1 : 0) : (1 << fcs_flag);
+        uint64_t v = fcs_flag == 1 ? n - 256 : n;
+        if (!single && fcs_flag == 0) { fcs_flag = 1; fcs_bytes = 2; v = n - 256; } /* unreachable: !single => n > 2^wlog */
+        dst[pos++] = (uint8_t)((fcs_flag << 6) | (single << 5) | ((P->checksum ? 1 : 0) << 2));
+        if (!single) dst[pos++] = (uint8_t)((wlog - 10) << 3);
+        for (i = 0; i < fcs_bytes; i++) dst[pos++] = (uint8_t)(v >> (8 * i));
+    }
+    c.P = P; c.src = src; c.n = n; c.st = st;
+    c.window = single ? (n ? n : 1) : ((size_t)1 << wlog);
+    c.rep[0] = 1; c.rep[1] = 4; c.rep[2] = 8;
+    c.tl = (uint32_t *)calloc((size_t)1 << P->long_log, 4);
+    c.ts = (uint32_t *)calloc((size_t)1 << P->short_log, 4);
+    c.M = (cand *)calloc((size_t)P->tile, sizeof(cand));
+    seq = (zge_seq *)malloc(sizeof(zge_seq) * (ZGE_BLOCK / 3 + 8));
+    lit = (uint8_t *)malloc(ZGE_BLOCK + 64);
+    blk = (uint8_t *)malloc(ZGE_BLOCK + 1024);
+    if (n == 0) { dst[pos++] = 1; dst[pos++] = 0; dst[pos++] = 0; }
+    for (bs = 0; bs < n; bs += ZGE_BLOCK) {
+        size_t be = bs + ZGE_BLOCK < n ? bs + ZGE_BLOCK : n, blen = be - bs, nlit = 0, i;
+        int last = be == n, all_same = 1;
+        uint32_t hdr;
+        for (i = 1; i < blen; i++) if (src[bs + i] != src[bs]) { all_same = 0; break; }
+        if (all_same && blen >= 2) {
+            /* RLE block.  The match finder still has to see the block so later blocks can reference it:
+             * the engine inserts nothing for RLE blocks (cheap and deterministic). */
+            hdr = (uint32_t)last | (1u << 1) | ((uint32_t)blen << 3);
+            dst[pos++] = (uint8_t)hdr; dst[pos++] = (uint8_t)(hdr >> 8); dst[pos++] = (uint8_t)(hdr >> 16);
+            dst[pos++] = src[bs];
+            if (st) st->blk_rle++;
+            continue;
+        }
+        {
+            uint32_t rep_save[3];
+            uint32_t nseq;
+            size_t lsz, ssz = 0, csz = 0;
+            memcpy(rep_save, c.rep, sizeof rep_save);
+            nseq = matchfind_block(&c, bs, be, seq, lit, &nlit);
+            lsz = encode_literals(lit, nlit, blk, ZGE_BLOCK + 1024, st);
+            if (lsz) ssz = encode_sequences(seq, nseq, blk + lsz, ZGE_BLOCK + 1024 - lsz, st);
+            csz = lsz && ssz ? lsz + ssz : 0;
+            if (csz && csz < blen) {
+                hdr = (uint32_t)last | (2u << 1) | ((uint32_t)csz << 3);
+                dst[pos++] = (uint8_t)hdr; dst[pos++] = (uint8_t)(hdr >> 8); dst[pos++] = (uint8_t)(hdr >> 16);
+                memcpy(dst + pos, blk, csz);
+                pos += csz;
+                if (st) { st->blk_comp++; st->lit_bytes += nlit; st->lit_section += lsz; st->seq_section += ssz; }
+            } else {
+                /* raw block: the decoder's repcode history is not advanced by it */
+                memcpy(c.rep, rep_save, sizeof rep_save);
+                hdr = (uint32_t)last | (0u << 1) | ((uint32_t)blen << 3);
+                dst[pos++] = (uint8_t)hdr; dst[pos++] = (uint8_t)(hdr >> 8); dst[pos++] = (uint8_t)(hdr >> 16);
+                memcpy(dst + pos, src + bs, blen);
+                pos += blen;
+                if (st) st->blk_raw++;
+            }
+        }
+    }
+    if (P->checksum) {
+        uint32_t x = (uint32_t)oracle_xxh64(src, n, 0);
+        dst[pos++] = (uint8_t)x; dst[pos++] = (uint8_t)(x >> 8); dst[pos++] = (uint8_t)(x >> 16); dst[pos++] = (uint8_t)(x >> 24);
+    }
+    free(c.tl); free(c.ts); free(c.M); free(seq); free(lit); free(blk);
+    *out_len = pos;
+    return 0;
+}
