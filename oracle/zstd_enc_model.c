@@ -627,6 +627,11 @@ static uint32_t matchfind_block(mf_ctx *c, size_t bs, size_t be, zge_seq *seq, u
     const uint8_t *src = c->src;
     size_t anchor = bs, pos = bs, tile, lp = 0;
     uint32_t nseq = 0;
+    /* Every block starts with an UNKNOWN repcode history (0 never equals a real offset): whether the
+     * previous block ends up raw/RLE (which leaves the decoder's history untouched) is only known after
+     * entropy coding, and the match finder must not depend on that.  Offsets are sent explicitly until
+     * the history has been re-established inside the block; the cost is at most 3 repcodes per block. */
+    c->rep[0] = c->rep[1] = c->rep[2] = 0;
     /* positions with fewer than 8 readable bytes are never hashed */
     size_t hash_end = c->n >= 8 ? c->n - 7 : 0; /* p < hash_end is hashable */
     for (tile = bs; tile < be; tile += (size_t)P->tile) {
@@ -711,8 +716,13 @@ static uint32_t matchfind_block(mf_ctx *c, size_t bs, size_t be, zge_seq *seq, u
                         uint32_t limit = (uint32_t)(be - q);
                         len = match_len(src, q, q - off, limit);
                     }
+                    /* backward extension is confined to pending literals of the current 64-position chunk
+                     * (literals of earlier chunks have already been emitted) */
                     back = m->back;
-                    if (back > q - anchor) back = (uint32_t)(q - anchor);
+                    {
+                        size_t floor_ = anchor > chunk ? anchor : chunk;
+                        if (back > q - floor_) back = (uint32_t)(q - floor_);
+                    }
                     q -= back; len += back;
                     ll = (uint32_t)(q - anchor);
                     memcpy(lit + lp, src + anchor, ll);
@@ -803,10 +813,8 @@ int zge_encode_frame(const zge_params *P, const void *src_, size_t n, void *dst_
             continue;
         }
         {
-            uint32_t rep_save[3];
             uint32_t nseq;
             size_t lsz, ssz = 0, csz = 0;
-            memcpy(rep_save, c.rep, sizeof rep_save);
             nseq = matchfind_block(&c, bs, be, seq, lit, &nlit);
             lsz = encode_literals(lit, nlit, blk, ZGE_BLOCK + 1024, st);
             if (lsz) ssz = encode_sequences(seq, nseq, blk + lsz, ZGE_BLOCK + 1024 - lsz, st);
@@ -818,8 +826,7 @@ int zge_encode_frame(const zge_params *P, const void *src_, size_t n, void *dst_
                 pos += csz;
                 if (st) { st->blk_comp++; st->lit_bytes += nlit; st->lit_section += lsz; st->seq_section += ssz; }
             } else {
-                /* raw block: the decoder's repcode history is not advanced by it */
-                memcpy(c.rep, rep_save, sizeof rep_save);
+                /* raw block: the decoder's repcode history is not advanced by it (see matchfind_block) */
                 hdr = (uint32_t)last | (0u << 1) | ((uint32_t)blen << 3);
                 dst[pos++] = (uint8_t)hdr; dst[pos++] = (uint8_t)(hdr >> 8); dst[pos++] = (uint8_t)(hdr >> 16);
                 memcpy(dst + pos, src + bs, blen);

@@ -1,0 +1,603 @@
+// zarc_amd/csrc/engine.hip -- host side of the C ABI declared in include/zarc_gpu.h.
+//
+// One handle owns one HIP stream on one device plus grow-only workspaces in HBM.  A batch call uploads
+// the small per-entry descriptors, launches the kernel chain on the stream, times each stage with HIP
+// events recorded on that same stream, and copies back only per-entry results (lengths, digests, status).
+// There is no CPU implementation behind this file: every data-path byte is touched by the gfx950 kernels.
+#include "../../include/zarc_gpu.h"
+#include "zarc_kernels.h"
+#include <algorithm>
+#include <new>
+#include <numeric>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t n)
+    {
+        if (n <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        size_t want = n + n / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { p = nullptr; return e; }
+        cap = want;
+        return hipSuccess;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <typename T> T *as() const { return (T *)p; }
+};
+
+} // namespace
+
+struct zarc_gpu {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    zarc_gpu_params params{};
+    std::string last_error;
+    // descriptors
+    DevBuf d_off, d_len, d_chunk_prefix, d_block_prefix, d_order, d_dst_off, d_dst_len, d_raw_len, d_frame_off, d_frame_len;
+    // hashing
+    DevBuf d_cvs, d_cvs_tmp, d_digests, d_xxh, d_expect;
+    // encoder
+    DevBuf d_blocks, d_seq, d_lit, d_out;
+    // decoder
+    DevBuf d_declit, d_status, d_stored_ck;
+    // staging arenas for the host-pointer entry points
+    DevBuf d_arena_in, d_arena_out;
+    hipEvent_t ev[16] = {};
+    float ms[ZARC_GPU_T_COUNT];
+    size_t scratch_budget = 0; // 0 = derive from free memory
+};
+
+namespace {
+
+#define ZHIP(call)                                                                                  \
+    do {                                                                                            \
+        hipError_t e_ = (call);                                                                     \
+        if (e_ != hipSuccess) {                                                                     \
+            h->last_error = std::string(#call) + ": " + hipGetErrorString(e_);                      \
+            return e_ == hipErrorOutOfMemory ? ZARC_GPU_E_NOMEM : ZARC_GPU_E_DEVICE;                \
+        }                                                                                           \
+    } while (0)
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+ZgeParams derive_params(const zarc_gpu_params &p)
+{
+    ZgeParams z{};
+    int level = p.level == 0 ? 3 : p.level;
+    z.level = level;
+    z.checksum = p.checksum_flag ? 1 : 0;
+    z.window_log = p.window_log ? p.window_log : (level >= 9 ? 22 : 21);
+    if (z.window_log < 10) z.window_log = 10;
+    if (z.window_log > 27) z.window_log = 27;
+    z.long_log = 14; z.short_log = 14; z.short_bytes = 5;
+    z.tile = 1024; z.sub = 64; z.cap = 32;
+    z.min_match = p.min_match >= 4 && p.min_match <= 7 ? p.min_match : 5;
+    z.min_rep = 3; z.rep_search = 2; z.back_cap = 8;
+    z.lazy = level >= 2 ? 1 : 0; z.lazy_delta = 5;
+    z.lit_cost = 5; z.match_cost = 12; z.rep_cost = 9;
+    z.short_window_log = 30;
+    return z;
+}
+
+inline uint64_t chunks_of(uint64_t len) { return len == 0 ? 1 : (len + 1023) / 1024; }
+inline uint64_t blocks_of(uint64_t len) { return len == 0 ? 1 : (len + ZARC_BLOCK - 1) / ZARC_BLOCK; }
+
+struct Timer {
+    zarc_gpu *h;
+    int next = 0;
+    hipError_t mark(int *idx) { *idx = next; return hipEventRecord(h->ev[next++], h->stream); }
+};
+
+int upload_u64(zarc_gpu *h, DevBuf &b, const uint64_t *src, size_t n)
+{
+    ZHIP(b.reserve(std::max<size_t>(n, 1) * 8));
+    if (n) ZHIP(hipMemcpyAsync(b.p, src, n * 8, hipMemcpyHostToDevice, h->stream));
+    return 0;
+}
+int upload_u32(zarc_gpu *h, DevBuf &b, const uint32_t *src, size_t n)
+{
+    ZHIP(b.reserve(std::max<size_t>(n, 1) * 4));
+    if (n) ZHIP(hipMemcpyAsync(b.p, src, n * 4, hipMemcpyHostToDevice, h->stream));
+    return 0;
+}
+
+// BLAKE3 of n entries described by device arrays d_off/d_len (already uploaded); result in h->d_digests
+int run_blake3(zarc_gpu *h, size_t n, const uint8_t *d_base, const uint64_t *off, const uint64_t *len, const uint64_t *d_off, const uint64_t *d_len)
+{
+    (void)off;
+    std::vector<uint64_t> prefix(n + 1);
+    prefix[0] = 0;
+    for (size_t i = 0; i < n; i++) prefix[i + 1] = prefix[i] + chunks_of(len[i]);
+    const uint64_t total = prefix[n];
+    int rc = upload_u64(h, h->d_chunk_prefix, prefix.data(), n + 1);
+    if (rc) return rc;
+    ZHIP(h->d_cvs.reserve(total * 32));
+    ZHIP(h->d_cvs_tmp.reserve(total * 32));
+    ZHIP(h->d_digests.reserve(std::max<size_t>(n, 1) * 32));
+    const uint32_t tpb = 256;
+    const uint64_t grid = (total + tpb - 1) / tpb;
+    hipLaunchKernelGGL(zarc_blake3_chunks, dim3((unsigned)grid), dim3(tpb), 0, h->stream, d_base, d_off, d_len, h->d_chunk_prefix.as<uint64_t>(),
+                       (uint32_t)n, total, h->d_cvs.as<uint32_t>(), h->d_digests.as<uint32_t>());
+    const unsigned tgrid = (unsigned)std::min<size_t>(n, 65535);
+    hipLaunchKernelGGL(zarc_blake3_tree, dim3(tgrid), dim3(256), 0, h->stream, h->d_chunk_prefix.as<uint64_t>(), (uint32_t)n,
+                       h->d_cvs.as<uint32_t>(), h->d_cvs_tmp.as<uint32_t>(), h->d_digests.as<uint32_t>());
+    ZHIP(hipGetLastError());
+    return 0;
+}
+
+int run_xxh64(zarc_gpu *h, size_t n, const uint8_t *d_base, const uint64_t *d_off, const uint64_t *d_len)
+{
+    ZHIP(h->d_xxh.reserve(std::max<size_t>(n, 1) * 8));
+    const uint32_t tpb = 256;
+    const uint64_t threads = (uint64_t)n * 4;
+    hipLaunchKernelGGL(zarc_xxh64, dim3((unsigned)((threads + tpb - 1) / tpb)), dim3(tpb), 0, h->stream, d_base, d_off, d_len, (uint32_t)n,
+                       h->d_xxh.as<uint64_t>());
+    ZHIP(hipGetLastError());
+    return 0;
+}
+
+float elapsed(zarc_gpu *h, int a, int b)
+{
+    float ms = -1.f;
+    if (hipEventElapsedTime(&ms, h->ev[a], h->ev[b]) != hipSuccess) return -1.f;
+    return ms;
+}
+
+int check_common(zarc_gpu *h, size_t n)
+{
+    if (!h) return ZARC_GPU_E_PARAM;
+    if (n > 0x7FFFFFFFu) { h->last_error = "batch too large"; return ZARC_GPU_E_PARAM; }
+    ZHIP(hipSetDevice(h->device));
+    for (int i = 0; i < ZARC_GPU_T_COUNT; i++) h->ms[i] = -1.f;
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+int zarc_gpu_abi_version(void) { return ZARC_GPU_ABI_VERSION; }
+
+int zarc_gpu_create(zarc_gpu_t **out, int device)
+{
+    if (!out) return ZARC_GPU_E_PARAM;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return ZARC_GPU_E_DEVICE;
+    zarc_gpu *h = new (std::nothrow) zarc_gpu();
+    if (!h) return ZARC_GPU_E_NOMEM;
+    h->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) { delete h; return ZARC_GPU_E_DEVICE; }
+    for (auto &e : h->ev)
+        if (hipEventCreate(&e) != hipSuccess) { delete h; return ZARC_GPU_E_DEVICE; }
+    h->params.level = 0;          // CCtx::init(0): default level (crates/zarc/src/encode.rs:62)
+    h->params.checksum_flag = 0;  // libzstd default; the zarc CLI switches it on (pack.rs:227)
+    h->params.content_size_flag = 1;
+    h->params.compress = 1;
+    for (int i = 0; i < ZARC_GPU_T_COUNT; i++) h->ms[i] = -1.f;
+    *out = h;
+    return ZARC_GPU_OK;
+}
+
+void zarc_gpu_destroy(zarc_gpu_t *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    DevBuf *all[] = {&h->d_off, &h->d_len, &h->d_chunk_prefix, &h->d_block_prefix, &h->d_order, &h->d_dst_off, &h->d_dst_len, &h->d_raw_len,
+                     &h->d_frame_off, &h->d_frame_len, &h->d_cvs, &h->d_cvs_tmp, &h->d_digests, &h->d_xxh, &h->d_expect, &h->d_blocks, &h->d_seq,
+                     &h->d_lit, &h->d_out, &h->d_declit, &h->d_status, &h->d_stored_ck, &h->d_arena_in, &h->d_arena_out};
+    for (DevBuf *b : all) b->release();
+    for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int zarc_gpu_set_parameter(zarc_gpu_t *h, int id, int value)
+{
+    if (!h) return ZARC_GPU_E_PARAM;
+    switch (id) {
+    case ZARC_GPU_P_COMPRESSION_LEVEL:
+        if (value < -131072 || value > 22) return ZARC_GPU_E_PARAM; // same bounds as --level (zarc-cli/src/pack.rs:28-33) / libzstd
+        h->params.level = value; return ZARC_GPU_OK;
+    case ZARC_GPU_P_WINDOW_LOG:
+        if (value != 0 && (value < 10 || value > 27)) return ZARC_GPU_E_PARAM;
+        h->params.window_log = value; return ZARC_GPU_OK;
+    case ZARC_GPU_P_HASH_LOG: h->params.hash_log = value; return ZARC_GPU_OK;       // accepted; table sizes are fixed by LDS
+    case ZARC_GPU_P_CHAIN_LOG: h->params.chain_log = value; return ZARC_GPU_OK;     // accepted, ignored
+    case ZARC_GPU_P_SEARCH_LOG: h->params.search_log = value; return ZARC_GPU_OK;   // accepted, ignored
+    case ZARC_GPU_P_MIN_MATCH:
+        if (value != 0 && (value < 3 || value > 7)) return ZARC_GPU_E_PARAM;
+        h->params.min_match = value; return ZARC_GPU_OK;
+    case ZARC_GPU_P_TARGET_LENGTH: h->params.target_length = value; return ZARC_GPU_OK;
+    case ZARC_GPU_P_STRATEGY:
+        if (value < 0 || value > 9) return ZARC_GPU_E_PARAM;
+        h->params.strategy = value; return ZARC_GPU_OK;
+    case ZARC_GPU_P_CONTENT_SIZE_FLAG:
+        if (value != 1) return ZARC_GPU_E_UNSUPPORTED; // frames always carry their content size
+        return ZARC_GPU_OK;
+    case ZARC_GPU_P_CHECKSUM_FLAG: h->params.checksum_flag = value ? 1 : 0; return ZARC_GPU_OK;
+    case ZARC_GPU_P_DICT_ID_FLAG: return ZARC_GPU_OK; // no dictionaries in zarc
+    default:
+        // long-distance matching (160-164), nbWorkers/jobSize/overlapLog (400-402) and the experimental ids
+        if ((id >= 160 && id <= 164) || (id >= 400 && id <= 402) || (id >= 500 && id <= 1020)) return ZARC_GPU_E_UNSUPPORTED;
+        return ZARC_GPU_E_PARAM;
+    }
+}
+
+void zarc_gpu_get_params(const zarc_gpu_t *h, zarc_gpu_params *out) { if (h && out) *out = h->params; }
+void zarc_gpu_enable_compression(zarc_gpu_t *h, int compress) { if (h) h->params.compress = compress ? 1 : 0; }
+
+size_t zarc_gpu_bound(size_t n)
+{
+    size_t blocks = (n + ZARC_BLOCK - 1) / ZARC_BLOCK;
+    if (blocks == 0) blocks = 1;
+    return align_up(n + 3 * blocks + 18, ZARC_GPU_ALIGN);
+}
+
+const char *zarc_gpu_error_name(int code)
+{
+    switch (code) {
+    case ZARC_GPU_OK: return "No error detected";
+    case ZARC_GPU_E_DEVICE: return "HIP device error";
+    case ZARC_GPU_E_NOMEM: return "Allocation error : not enough memory";
+    case ZARC_GPU_E_PARAM: return "Parameter is out of bound";
+    case ZARC_GPU_E_UNSUPPORTED: return "Unsupported parameter";
+    case ZARC_GPU_E_DSTSIZE: return "Destination buffer is too small";
+    default: return "Unspecified error code";
+    }
+}
+const char *zarc_gpu_frame_status_name(int s)
+{
+    switch (s) {
+    case ZARC_GPU_FRAME_OK: return "No error detected";
+    case ZARC_GPU_FRAME_CORRUPT: return "Data corruption detected";
+    case ZARC_GPU_FRAME_CHECKSUM: return "Restored data doesn't match checksum";
+    case ZARC_GPU_FRAME_DIGEST: return "BLAKE3 digest mismatch";
+    case ZARC_GPU_FRAME_DSTSIZE: return "Destination buffer is too small";
+    case ZARC_GPU_FRAME_BAD_MAGIC: return "Unknown frame descriptor";
+    case ZARC_GPU_FRAME_UNSUPPORTED: return "Unsupported frame parameter";
+    case ZARC_GPU_FRAME_SRCSIZE: return "Src size is incorrect";
+    default: return "Unspecified error code";
+    }
+}
+const char *zarc_gpu_last_error(const zarc_gpu_t *h) { return h ? h->last_error.c_str() : "null handle"; }
+float zarc_gpu_last_kernel_ms(const zarc_gpu_t *h, int which) { return (h && which >= 0 && which < ZARC_GPU_T_COUNT) ? h->ms[which] : -1.f; }
+
+// ---------------------------------------------------------------------------------------------------
+int zarc_gpu_blake3_batch_device(zarc_gpu_t *h, size_t n, const void *d_base, const uint64_t *off, const uint64_t *len, uint8_t *digest)
+{
+    int rc = check_common(h, n);
+    if (rc) return rc;
+    if (n == 0) return ZARC_GPU_OK;
+    if (!d_base || !off || !len || !digest) return ZARC_GPU_E_PARAM;
+    for (size_t i = 0; i < n; i++) if (off[i] % ZARC_GPU_ALIGN) { h->last_error = "entry offset not 16-byte aligned"; return ZARC_GPU_E_PARAM; }
+    if ((rc = upload_u64(h, h->d_off, off, n))) return rc;
+    if ((rc = upload_u64(h, h->d_len, len, n))) return rc;
+    Timer t{h};
+    int a, b;
+    ZHIP(t.mark(&a));
+    if ((rc = run_blake3(h, n, (const uint8_t *)d_base, off, len, h->d_off.as<uint64_t>(), h->d_len.as<uint64_t>()))) return rc;
+    ZHIP(t.mark(&b));
+    ZHIP(hipMemcpyAsync(digest, h->d_digests.p, n * 32, hipMemcpyDeviceToHost, h->stream));
+    ZHIP(hipStreamSynchronize(h->stream));
+    h->ms[ZARC_GPU_T_BLAKE3] = h->ms[ZARC_GPU_T_TOTAL] = elapsed(h, a, b);
+    return ZARC_GPU_OK;
+}
+
+int zarc_gpu_xxh64_batch_device(zarc_gpu_t *h, size_t n, const void *d_base, const uint64_t *off, const uint64_t *len, uint64_t *out)
+{
+    int rc = check_common(h, n);
+    if (rc) return rc;
+    if (n == 0) return ZARC_GPU_OK;
+    if (!d_base || !off || !len || !out) return ZARC_GPU_E_PARAM;
+    for (size_t i = 0; i < n; i++) if (off[i] % ZARC_GPU_ALIGN) { h->last_error = "entry offset not 16-byte aligned"; return ZARC_GPU_E_PARAM; }
+    if ((rc = upload_u64(h, h->d_off, off, n))) return rc;
+    if ((rc = upload_u64(h, h->d_len, len, n))) return rc;
+    Timer t{h};
+    int a, b;
+    ZHIP(t.mark(&a));
+    if ((rc = run_xxh64(h, n, (const uint8_t *)d_base, h->d_off.as<uint64_t>(), h->d_len.as<uint64_t>()))) return rc;
+    ZHIP(t.mark(&b));
+    ZHIP(hipMemcpyAsync(out, h->d_xxh.p, n * 8, hipMemcpyDeviceToHost, h->stream));
+    ZHIP(hipStreamSynchronize(h->stream));
+    h->ms[ZARC_GPU_T_XXH64] = h->ms[ZARC_GPU_T_TOTAL] = elapsed(h, a, b);
+    return ZARC_GPU_OK;
+}
+
+int zarc_gpu_pack_batch_device(zarc_gpu_t *h, size_t n, const void *d_src_base, const uint64_t *src_off, const uint64_t *src_len, void *d_dst,
+                               size_t dst_cap, uint64_t *dst_off, uint64_t *dst_len, uint8_t *digest, int *status)
+{
+    int rc = check_common(h, n);
+    if (rc) return rc;
+    if (n == 0) return ZARC_GPU_OK;
+    if (!d_src_base || !src_off || !src_len || !d_dst || !dst_off || !dst_len || !digest) return ZARC_GPU_E_PARAM;
+    if (!h->params.compress) { h->last_error = "store mode (enable_compression(false)) is not implemented on the device path"; return ZARC_GPU_E_UNSUPPORTED; }
+    const ZgeParams P = derive_params(h->params);
+    uint64_t need = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (src_off[i] % ZARC_GPU_ALIGN) { h->last_error = "entry offset not 16-byte aligned"; return ZARC_GPU_E_PARAM; }
+        if (src_len[i] >= 0xFFFFFFF0ull) { h->last_error = "entries of 4 GiB or more are not supported"; return ZARC_GPU_E_UNSUPPORTED; }
+        dst_off[i] = need;
+        need += zarc_gpu_bound((size_t)src_len[i]);
+    }
+    if (need > dst_cap) return ZARC_GPU_E_DSTSIZE;
+    if ((rc = upload_u64(h, h->d_off, src_off, n))) return rc;
+    if ((rc = upload_u64(h, h->d_len, src_len, n))) return rc;
+    if ((rc = upload_u64(h, h->d_dst_off, dst_off, n))) return rc;
+    ZHIP(h->d_dst_len.reserve(n * 8));
+    const uint8_t *base = (const uint8_t *)d_src_base;
+    const uint64_t *d_off = h->d_off.as<uint64_t>(), *d_len = h->d_len.as<uint64_t>();
+    Timer t{h};
+    int e0, e1, e2;
+    ZHIP(t.mark(&e0));
+    if ((rc = run_blake3(h, n, base, src_off, src_len, d_off, d_len))) return rc;
+    ZHIP(t.mark(&e1));
+    if ((rc = run_xxh64(h, n, base, d_off, d_len))) return rc;
+    ZHIP(t.mark(&e2));
+
+    // ---- encoder: frames sorted by size (largest first), processed in sub-batches that fit the scratch budget ----
+    std::vector<uint32_t> order(n);
+    std::iota(order.begin(), order.end(), 0u);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return src_len[a] > src_len[b]; });
+    const size_t per_block = (size_t)ZARC_MAX_SEQ * 8 + (ZARC_BLOCK + 64) + (ZARC_BLOCK + 1024) + sizeof(ZgeBlock);
+    size_t budget = h->scratch_budget;
+    if (!budget) {
+        budget = (size_t)24 << 30;
+    }
+    size_t max_blocks = std::max<size_t>(budget / per_block, 1);
+    float ms_match = 0, ms_ent = 0, ms_asm = 0;
+    size_t start = 0;
+    std::vector<uint64_t> bp;
+    while (start < n) {
+        size_t end = start, nb = 0;
+        while (end < n) {
+            const size_t b = (size_t)blocks_of(src_len[order[end]]);
+            if (end > start && nb + b > max_blocks) break;
+            nb += b;
+            end++;
+        }
+        const size_t m = end - start;
+        bp.assign(m + 1, 0);
+        for (size_t j = 0; j < m; j++) bp[j + 1] = bp[j] + blocks_of(src_len[order[start + j]]);
+        if ((rc = upload_u64(h, h->d_block_prefix, bp.data(), m + 1))) return rc;
+        if ((rc = upload_u32(h, h->d_order, order.data() + start, m))) return rc;
+        ZHIP(h->d_blocks.reserve(nb * sizeof(ZgeBlock)));
+        ZHIP(h->d_seq.reserve(nb * (size_t)ZARC_MAX_SEQ * 8));
+        ZHIP(h->d_lit.reserve(nb * (size_t)(ZARC_BLOCK + 64)));
+        ZHIP(h->d_out.reserve(nb * (size_t)(ZARC_BLOCK + 1024)));
+        int a, b, c, d;
+        ZHIP(t.mark(&a));
+        hipLaunchKernelGGL(zarc_zge_match, dim3((unsigned)m), dim3(512), 0, h->stream, P, base, d_off, d_len, h->d_order.as<uint32_t>(), (uint32_t)m,
+                           h->d_block_prefix.as<uint64_t>(), h->d_blocks.as<ZgeBlock>(), h->d_seq.as<uint64_t>(), h->d_lit.as<uint8_t>());
+        ZHIP(hipGetLastError());
+        ZHIP(t.mark(&b));
+        hipLaunchKernelGGL(zarc_zge_entropy, dim3((unsigned)nb), dim3(64), 0, h->stream, (uint32_t)nb, h->d_blocks.as<ZgeBlock>(),
+                           h->d_seq.as<uint64_t>(), h->d_lit.as<uint8_t>(), h->d_out.as<uint8_t>());
+        ZHIP(hipGetLastError());
+        ZHIP(t.mark(&c));
+        hipLaunchKernelGGL(zarc_zge_assemble, dim3((unsigned)m), dim3(256), 0, h->stream, P, base, d_off, d_len, h->d_order.as<uint32_t>(), (uint32_t)m,
+                           h->d_block_prefix.as<uint64_t>(), h->d_blocks.as<ZgeBlock>(), h->d_out.as<uint8_t>(), h->d_xxh.as<uint64_t>(),
+                           (uint8_t *)d_dst, h->d_dst_off.as<uint64_t>(), h->d_dst_len.as<uint64_t>());
+        ZHIP(hipGetLastError());
+        ZHIP(t.mark(&d));
+        ZHIP(hipStreamSynchronize(h->stream)); // the scratch is reused by the next sub-batch; also bounds the event pool
+        ms_match += elapsed(h, a, b);
+        ms_ent += elapsed(h, b, c);
+        ms_asm += elapsed(h, c, d);
+        t.next = 3;
+        start = end;
+    }
+    ZHIP(hipMemcpyAsync(dst_len, h->d_dst_len.p, n * 8, hipMemcpyDeviceToHost, h->stream));
+    ZHIP(hipMemcpyAsync(digest, h->d_digests.p, n * 32, hipMemcpyDeviceToHost, h->stream));
+    ZHIP(hipStreamSynchronize(h->stream));
+    if (status) for (size_t i = 0; i < n; i++) status[i] = ZARC_GPU_FRAME_OK;
+    h->ms[ZARC_GPU_T_BLAKE3] = elapsed(h, e0, e1);
+    h->ms[ZARC_GPU_T_XXH64] = elapsed(h, e1, e2);
+    h->ms[ZARC_GPU_T_MATCH] = ms_match;
+    h->ms[ZARC_GPU_T_ENTROPY] = ms_ent;
+    h->ms[ZARC_GPU_T_ASSEMBLE] = ms_asm;
+    h->ms[ZARC_GPU_T_TOTAL] = h->ms[ZARC_GPU_T_BLAKE3] + h->ms[ZARC_GPU_T_XXH64] + ms_match + ms_ent + ms_asm;
+    return ZARC_GPU_OK;
+}
+
+int zarc_gpu_unpack_batch_device(zarc_gpu_t *h, size_t n, const void *d_frames_base, const uint64_t *frame_off, const uint64_t *frame_len,
+                                 void *d_dst_base, const uint64_t *dst_off, const uint64_t *raw_len, const uint8_t *expect, uint8_t *digest,
+                                 int *status)
+{
+    int rc = check_common(h, n);
+    if (rc) return rc;
+    if (n == 0) return ZARC_GPU_OK;
+    if (!d_frames_base || !frame_off || !frame_len || !d_dst_base || !dst_off || !raw_len || !digest || !status) return ZARC_GPU_E_PARAM;
+    for (size_t i = 0; i < n; i++) {
+        if (dst_off[i] % ZARC_GPU_ALIGN) { h->last_error = "output offset not 16-byte aligned"; return ZARC_GPU_E_PARAM; }
+        if (frame_len[i] >= 0xFFFFFFF0ull || raw_len[i] >= 0xFFFFFFF0ull) { h->last_error = "frames of 4 GiB or more are not supported"; return ZARC_GPU_E_UNSUPPORTED; }
+    }
+    if ((rc = upload_u64(h, h->d_frame_off, frame_off, n))) return rc;
+    if ((rc = upload_u64(h, h->d_frame_len, frame_len, n))) return rc;
+    if ((rc = upload_u64(h, h->d_dst_off, dst_off, n))) return rc;
+    if ((rc = upload_u64(h, h->d_raw_len, raw_len, n))) return rc;
+    std::vector<uint32_t> order(n);
+    std::iota(order.begin(), order.end(), 0u);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return raw_len[a] > raw_len[b]; });
+    if ((rc = upload_u32(h, h->d_order, order.data(), n))) return rc;
+    ZHIP(h->d_declit.reserve(n * (size_t)(ZARC_BLOCK + 64)));
+    ZHIP(h->d_status.reserve(n * 4));
+    ZHIP(h->d_stored_ck.reserve(n * 8));
+    if (expect) {
+        ZHIP(h->d_expect.reserve(n * 32));
+        ZHIP(hipMemcpyAsync(h->d_expect.p, expect, n * 32, hipMemcpyHostToDevice, h->stream));
+    }
+    Timer t{h};
+    int e0, e1, e2, e3;
+    ZHIP(t.mark(&e0));
+    hipLaunchKernelGGL(zarc_zstd_decode, dim3((unsigned)n), dim3(64), 0, h->stream, (const uint8_t *)d_frames_base, h->d_frame_off.as<uint64_t>(),
+                       h->d_frame_len.as<uint64_t>(), (uint8_t *)d_dst_base, h->d_dst_off.as<uint64_t>(), h->d_raw_len.as<uint64_t>(),
+                       h->d_order.as<uint32_t>(), (uint32_t)n, h->d_declit.as<uint8_t>(), h->d_status.as<int32_t>(), h->d_stored_ck.as<uint32_t>());
+    ZHIP(hipGetLastError());
+    ZHIP(t.mark(&e1));
+    // verification passes over the decoded bytes (K2 + XXH64 inside libzstd in the reference)
+    if ((rc = run_xxh64(h, n, (const uint8_t *)d_dst_base, h->d_dst_off.as<uint64_t>(), h->d_raw_len.as<uint64_t>()))) return rc;
+    ZHIP(t.mark(&e2));
+    if ((rc = run_blake3(h, n, (const uint8_t *)d_dst_base, dst_off, raw_len, h->d_dst_off.as<uint64_t>(), h->d_raw_len.as<uint64_t>()))) return rc;
+    ZHIP(t.mark(&e3));
+    hipLaunchKernelGGL(zarc_unpack_verdict, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, (uint32_t)n, h->d_xxh.as<uint64_t>(),
+                       h->d_stored_ck.as<uint32_t>(), h->d_digests.as<uint32_t>(), expect ? h->d_expect.as<uint32_t>() : (const uint32_t *)nullptr,
+                       h->d_status.as<int32_t>());
+    ZHIP(hipGetLastError());
+    ZHIP(hipMemcpyAsync(status, h->d_status.p, n * 4, hipMemcpyDeviceToHost, h->stream));
+    ZHIP(hipMemcpyAsync(digest, h->d_digests.p, n * 32, hipMemcpyDeviceToHost, h->stream));
+    ZHIP(hipStreamSynchronize(h->stream));
+    h->ms[ZARC_GPU_T_DECODE] = elapsed(h, e0, e1);
+    h->ms[ZARC_GPU_T_XXH64] = elapsed(h, e1, e2);
+    h->ms[ZARC_GPU_T_BLAKE3] = elapsed(h, e2, e3);
+    h->ms[ZARC_GPU_T_TOTAL] = elapsed(h, e0, e3);
+    return ZARC_GPU_OK;
+}
+
+// ---- host-memory entry points: stage through engine-owned arenas -----------------------------------
+static int stage_in(zarc_gpu *h, size_t n, const void *const *src, const size_t *len, std::vector<uint64_t> &off, std::vector<uint64_t> &l64)
+{
+    off.resize(n);
+    l64.resize(n);
+    uint64_t total = 0;
+    for (size_t i = 0; i < n; i++) {
+        off[i] = total;
+        l64[i] = len[i];
+        total += align_up(len[i], ZARC_GPU_ALIGN);
+    }
+    ZHIP(h->d_arena_in.reserve(total + ZARC_GPU_PAD + 256));
+    for (size_t i = 0; i < n; i++)
+        if (len[i]) {
+            if (!src[i]) return ZARC_GPU_E_PARAM;
+            ZHIP(hipMemcpyAsync(h->d_arena_in.as<uint8_t>() + off[i], src[i], len[i], hipMemcpyHostToDevice, h->stream));
+        }
+    return 0;
+}
+
+int zarc_gpu_blake3_batch(zarc_gpu_t *h, size_t n, const void *const *src, const size_t *len, uint8_t (*digest)[ZARC_GPU_DIGEST_LEN])
+{
+    int rc = check_common(h, n);
+    if (rc) return rc;
+    if (n == 0) return ZARC_GPU_OK;
+    if (!src || !len || !digest) return ZARC_GPU_E_PARAM;
+    std::vector<uint64_t> off, l64;
+    if ((rc = stage_in(h, n, src, len, off, l64))) return rc;
+    return zarc_gpu_blake3_batch_device(h, n, h->d_arena_in.p, off.data(), l64.data(), (uint8_t *)digest);
+}
+
+int zarc_gpu_pack_batch(zarc_gpu_t *h, size_t n, const void *const *src, const size_t *src_len, void *dst, size_t dst_cap, size_t *dst_off,
+                        size_t *dst_len, uint8_t (*digest)[ZARC_GPU_DIGEST_LEN], int *status)
+{
+    int rc = check_common(h, n);
+    if (rc) return rc;
+    if (n == 0) return ZARC_GPU_OK;
+    if (!src || !src_len || !dst || !dst_off || !dst_len || !digest) return ZARC_GPU_E_PARAM;
+    std::vector<uint64_t> off, l64, doff(n), dlen(n);
+    if ((rc = stage_in(h, n, src, src_len, off, l64))) return rc;
+    uint64_t need = 0;
+    for (size_t i = 0; i < n; i++) need += zarc_gpu_bound(src_len[i]);
+    if (need > dst_cap) return ZARC_GPU_E_DSTSIZE;
+    ZHIP(h->d_arena_out.reserve(need + ZARC_GPU_PAD));
+    rc = zarc_gpu_pack_batch_device(h, n, h->d_arena_in.p, off.data(), l64.data(), h->d_arena_out.p, need, doff.data(), dlen.data(),
+                                    (uint8_t *)digest, status);
+    if (rc) return rc;
+    const float keep[ZARC_GPU_T_COUNT] = {h->ms[0], h->ms[1], h->ms[2], h->ms[3], h->ms[4], h->ms[5], h->ms[6]};
+    for (size_t i = 0; i < n; i++) {
+        dst_off[i] = (size_t)doff[i];
+        dst_len[i] = (size_t)dlen[i];
+        ZHIP(hipMemcpyAsync((uint8_t *)dst + doff[i], h->d_arena_out.as<uint8_t>() + doff[i], dlen[i], hipMemcpyDeviceToHost, h->stream));
+    }
+    ZHIP(hipStreamSynchronize(h->stream));
+    for (int i = 0; i < ZARC_GPU_T_COUNT; i++) h->ms[i] = keep[i];
+    return ZARC_GPU_OK;
+}
+
+int zarc_gpu_unpack_batch(zarc_gpu_t *h, size_t n, const void *const *frame, const size_t *frame_len, const size_t *raw_len, void *const *dst,
+                          const uint8_t (*expect)[ZARC_GPU_DIGEST_LEN], uint8_t (*digest)[ZARC_GPU_DIGEST_LEN], int *status)
+{
+    int rc = check_common(h, n);
+    if (rc) return rc;
+    if (n == 0) return ZARC_GPU_OK;
+    if (!frame || !frame_len || !raw_len || !dst || !digest || !status) return ZARC_GPU_E_PARAM;
+    std::vector<uint64_t> foff(n), flen(n), doff(n), rlen(n);
+    uint64_t ftotal = 0, dtotal = 0;
+    for (size_t i = 0; i < n; i++) {
+        foff[i] = ftotal; flen[i] = frame_len[i]; ftotal += align_up(frame_len[i], ZARC_GPU_ALIGN);
+        doff[i] = dtotal; rlen[i] = raw_len[i]; dtotal += align_up(raw_len[i], ZARC_GPU_ALIGN);
+    }
+    ZHIP(h->d_arena_in.reserve(ftotal + ZARC_GPU_PAD + 256));
+    ZHIP(h->d_arena_out.reserve(dtotal + ZARC_GPU_PAD + 256));
+    for (size_t i = 0; i < n; i++)
+        if (frame_len[i]) {
+            if (!frame[i]) return ZARC_GPU_E_PARAM;
+            ZHIP(hipMemcpyAsync(h->d_arena_in.as<uint8_t>() + foff[i], frame[i], frame_len[i], hipMemcpyHostToDevice, h->stream));
+        }
+    rc = zarc_gpu_unpack_batch_device(h, n, h->d_arena_in.p, foff.data(), flen.data(), h->d_arena_out.p, doff.data(), rlen.data(),
+                                      (const uint8_t *)expect, (uint8_t *)digest, status);
+    if (rc) return rc;
+    const float keep[ZARC_GPU_T_COUNT] = {h->ms[0], h->ms[1], h->ms[2], h->ms[3], h->ms[4], h->ms[5], h->ms[6]};
+    for (size_t i = 0; i < n; i++) {
+        // like the reference, bytes are delivered unless the frame itself failed to decode
+        const bool decoded = status[i] == ZARC_GPU_FRAME_OK || status[i] == ZARC_GPU_FRAME_DIGEST || status[i] == ZARC_GPU_FRAME_CHECKSUM;
+        if (decoded && raw_len[i]) {
+            if (!dst[i]) return ZARC_GPU_E_PARAM;
+            ZHIP(hipMemcpyAsync(dst[i], h->d_arena_out.as<uint8_t>() + doff[i], raw_len[i], hipMemcpyDeviceToHost, h->stream));
+        }
+    }
+    ZHIP(hipStreamSynchronize(h->stream));
+    for (int i = 0; i < ZARC_GPU_T_COUNT; i++) h->ms[i] = keep[i];
+    return ZARC_GPU_OK;
+}
+
+// ---- bench / test utilities ---------------------------------------------------------------------------
+int zarc_gpu_corpus_fill_device(zarc_gpu_t *h, size_t n, void *d_base, const uint64_t *off, const uint64_t *len, uint64_t first_index, int kind)
+{
+    int rc = check_common(h, n);
+    if (rc) return rc;
+    if (n == 0) return ZARC_GPU_OK;
+    if (!d_base || !off || !len) return ZARC_GPU_E_PARAM;
+    if ((rc = upload_u64(h, h->d_off, off, n))) return rc;
+    if ((rc = upload_u64(h, h->d_len, len, n))) return rc;
+    hipLaunchKernelGGL(zarc_corpus_fill, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, h->stream, (uint8_t *)d_base, h->d_off.as<uint64_t>(),
+                       h->d_len.as<uint64_t>(), (uint32_t)n, first_index, kind);
+    ZHIP(hipGetLastError());
+    ZHIP(hipStreamSynchronize(h->stream));
+    return ZARC_GPU_OK;
+}
+int zarc_gpu_device_malloc(zarc_gpu_t *h, void **d_ptr, size_t bytes)
+{
+    if (!h || !d_ptr) return ZARC_GPU_E_PARAM;
+    ZHIP(hipSetDevice(h->device));
+    ZHIP(hipMalloc(d_ptr, bytes ? bytes : 1));
+    return ZARC_GPU_OK;
+}
+int zarc_gpu_device_free(zarc_gpu_t *h, void *d_ptr)
+{
+    if (!h) return ZARC_GPU_E_PARAM;
+    ZHIP(hipSetDevice(h->device));
+    ZHIP(hipFree(d_ptr));
+    return ZARC_GPU_OK;
+}
+int zarc_gpu_memcpy_h2d(zarc_gpu_t *h, void *d_dst, const void *src, size_t bytes)
+{
+    if (!h) return ZARC_GPU_E_PARAM;
+    ZHIP(hipSetDevice(h->device));
+    ZHIP(hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice));
+    return ZARC_GPU_OK;
+}
+int zarc_gpu_memcpy_d2h(zarc_gpu_t *h, void *dst, const void *d_src, size_t bytes)
+{
+    if (!h) return ZARC_GPU_E_PARAM;
+    ZHIP(hipSetDevice(h->device));
+    ZHIP(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
+    return ZARC_GPU_OK;
+}
+
+} // extern "C"

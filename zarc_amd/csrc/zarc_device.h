@@ -1,0 +1,114 @@
+// zarc_amd/csrc/zarc_device.h -- device-side primitives shared by the gfx950 kernels.
+//
+// wave64 throughout (CDNA4): ballots are 64-bit, shuffles span 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace zd {
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+__device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
+
+// Make LDS / global writes of this wave's lanes visible to the other lanes of the same wave.
+// Hardware executes a wave's memory instructions in order, so only the compiler has to be fenced;
+// the test emulator runs lanes one after another and needs a real rendezvous here.
+__device__ __forceinline__ void wave_sync()
+{
+#ifdef ZARC_HIPEMU
+    hipemu_wave_sync();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
+
+// Same for global-memory hand-offs between lanes of one wave (store -> fence -> load by another lane):
+// the release/acquire pair at workgroup scope waits for the stores (s_waitcnt vmcnt(0)); all waves of
+// a workgroup share the CU's vector L1, so no cache maintenance is involved.
+__device__ __forceinline__ void wave_sync_global()
+{
+#ifdef ZARC_HIPEMU
+    hipemu_wave_sync();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#endif
+}
+
+// value of the first active lane, as a wave-uniform (scalar) value
+__device__ __forceinline__ uint32_t uniform(uint32_t v)
+{
+#ifdef ZARC_HIPEMU
+    return hipemu_readfirstlane(v);
+#else
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+#endif
+}
+
+__device__ __forceinline__ uint64_t ballot(bool p) { return (uint64_t)__ballot(p ? 1 : 0); }
+__device__ __forceinline__ uint32_t shfl(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, 64); }
+__device__ __forceinline__ uint32_t shfl_up(uint32_t v, unsigned d) { return (uint32_t)__shfl_up((int)v, d, 64); }
+__device__ __forceinline__ uint32_t shfl_down(uint32_t v, unsigned d) { return (uint32_t)__shfl_down((int)v, d, 64); }
+__device__ __forceinline__ uint32_t shfl_xor(uint32_t v, int m) { return (uint32_t)__shfl_xor((int)v, m, 64); }
+
+__device__ __forceinline__ uint32_t rotr32(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+__device__ __forceinline__ uint64_t rotl64(uint64_t x, int n) { return (x << n) | (x >> (64 - n)); }
+__device__ __forceinline__ int hb32(uint32_t v) { return 31 - __clz((int)v); }          // floor(log2 v), v > 0
+__device__ __forceinline__ int ctz64(uint64_t v) { return __ffsll((long long)v) - 1; }  // v != 0
+__device__ __forceinline__ int ctz32(uint32_t v) { return __ffs((int)v) - 1; }          // v != 0
+
+// inclusive prefix sum over the wave
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v)
+{
+    int l = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = shfl_up(v, (unsigned)d);
+        if (l >= d) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += shfl_xor(v, d);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max(uint32_t v)
+{
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { uint32_t t = shfl_xor(v, d); v = t > v ? t : v; }
+    return v;
+}
+
+// little-endian loads from byte pointers with no alignment requirement.  Built from aligned dword
+// loads so they are legal for LDS and global memory alike; they may touch up to 3 bytes before and
+// 7 bytes after the addressed range, which every engine buffer pads for (ZARC_GPU_PAD).
+__device__ __forceinline__ uint32_t load_u32(const uint8_t *p)
+{
+    uintptr_t a = (uintptr_t)p;
+    const uint32_t *w = (const uint32_t *)(a & ~(uintptr_t)3);
+    unsigned sh = (unsigned)(a & 3) * 8;
+    uint32_t lo = w[0];
+    if (sh == 0) return lo;
+    return (lo >> sh) | (w[1] << (32 - sh));
+}
+__device__ __forceinline__ uint64_t load_u64(const uint8_t *p)
+{
+    uintptr_t a = (uintptr_t)p;
+    const uint32_t *w = (const uint32_t *)(a & ~(uintptr_t)3);
+    unsigned sh = (unsigned)(a & 3) * 8;
+    uint32_t w0 = w[0], w1 = w[1];
+    if (sh == 0) return (uint64_t)w0 | ((uint64_t)w1 << 32);
+    uint32_t w2 = w[2];
+    uint32_t lo = (w0 >> sh) | (w1 << (32 - sh));
+    uint32_t hi = (w1 >> sh) | (w2 << (32 - sh));
+    return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+
+} // namespace zd

@@ -1,0 +1,58 @@
+// zarc_amd/csrc/zarc_kernels.h -- kernel entry points and the records they exchange through HBM.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// per-frame status values; numerically identical to ZARC_GPU_FRAME_* in include/zarc_gpu.h
+enum {
+    ZARC_FRAME_OK = 0, ZARC_FRAME_CORRUPT = 1, ZARC_FRAME_CHECKSUM = 2, ZARC_FRAME_DIGEST = 3,
+    ZARC_FRAME_DSTSIZE = 4, ZARC_FRAME_BAD_MAGIC = 5, ZARC_FRAME_UNSUPPORTED = 6, ZARC_FRAME_SRCSIZE = 7
+};
+
+constexpr uint32_t ZARC_BLOCK = 128 * 1024;          // Zstandard Block_Maximum_Size
+constexpr uint32_t ZARC_MAX_SEQ = ZARC_BLOCK / 3 + 8; // sequences per block (every match >= 3 bytes)
+
+// ---- encoder tuning (mirrors oracle/zge_model.h zge_params; plain ints so the struct can be passed by value)
+struct ZgeParams {
+    int level, checksum, window_log, long_log, short_log, short_bytes, tile, sub, cap, min_match, min_rep, rep_search,
+        back_cap, lazy, lazy_delta, lit_cost, match_cost, rep_cost, short_window_log;
+};
+
+// Per-block record written by the match finder and completed by the entropy coder.
+struct ZgeBlock {
+    uint32_t frame;      // entry index
+    uint32_t index;      // block index inside the frame
+    uint32_t src_len;    // uncompressed bytes in this block
+    uint32_t nseq, nlit; // match finder output
+    uint32_t type;       // 0 raw, 1 rle, 2 compressed (set by the entropy coder; rle by the match finder)
+    uint32_t out_len;    // bytes of block content (without the 3-byte header)
+    uint32_t pad;
+};
+// one sequence: ofv (28 bits) | ll << 28 (18 bits) | ml << 46 (18 bits)
+__host__ __device__ inline uint64_t zge_pack_seq(uint32_t ll, uint32_t ml, uint32_t ofv) { return (uint64_t)ofv | ((uint64_t)ll << 28) | ((uint64_t)ml << 46); }
+__host__ __device__ inline uint32_t zge_seq_ofv(uint64_t s) { return (uint32_t)(s & 0xFFFFFFFu); }
+__host__ __device__ inline uint32_t zge_seq_ll(uint64_t s) { return (uint32_t)((s >> 28) & 0x3FFFFu); }
+__host__ __device__ inline uint32_t zge_seq_ml(uint64_t s) { return (uint32_t)((s >> 46) & 0x3FFFFu); }
+
+// ---- kernels -----------------------------------------------------------------------------------
+__global__ void zarc_blake3_chunks(const uint8_t *base, const uint64_t *off, const uint64_t *len, const uint64_t *chunk_prefix,
+                                   uint32_t n_entries, uint64_t total_chunks, uint32_t *cvs, uint32_t *digests);
+__global__ void zarc_blake3_tree(const uint64_t *chunk_prefix, uint32_t n_entries, uint32_t *cvs, uint32_t *tmp, uint32_t *digests);
+__global__ void zarc_xxh64(const uint8_t *base, const uint64_t *off, const uint64_t *len, uint32_t n_entries, uint64_t *out);
+__global__ void zarc_zstd_decode(const uint8_t *frames_base, const uint64_t *frame_off, const uint64_t *frame_len, uint8_t *dst_base,
+                                 const uint64_t *dst_off, const uint64_t *raw_len, const uint32_t *order, uint32_t n_frames,
+                                 uint8_t *lit_scratch, int32_t *status, uint32_t *stored_checksum);
+// status[i]: keeps decode errors; else CHECKSUM if the stored XXH64 differs; else DIGEST if expect differs
+__global__ void zarc_unpack_verdict(uint32_t n, const uint64_t *xxh, const uint32_t *stored_checksum, const uint32_t *digests,
+                                    const uint32_t *expect /* may be null */, int32_t *status);
+__global__ void zarc_corpus_fill(uint8_t *base, const uint64_t *off, const uint64_t *len, uint32_t n, uint64_t first_index, int kind);
+
+// encoder
+__global__ void zarc_zge_match(ZgeParams P, const uint8_t *src_base, const uint64_t *src_off, const uint64_t *src_len,
+                               const uint32_t *order, uint32_t n_frames, const uint64_t *block_prefix, ZgeBlock *blocks,
+                               uint64_t *seq_scratch, uint8_t *lit_scratch);
+__global__ void zarc_zge_entropy(uint32_t n_blocks, ZgeBlock *blocks, const uint64_t *seq_scratch, const uint8_t *lit_scratch,
+                                 uint8_t *out_scratch);
+__global__ void zarc_zge_assemble(ZgeParams P, const uint8_t *src_base, const uint64_t *src_off, const uint64_t *src_len,
+                                  const uint32_t *order, uint32_t n_frames, const uint64_t *block_prefix, const ZgeBlock *blocks, const uint8_t *out_scratch,
+                                  const uint64_t *xxh, uint8_t *dst_base, const uint64_t *dst_off, uint64_t *dst_len);

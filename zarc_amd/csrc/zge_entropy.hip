@@ -1,0 +1,659 @@
+// zarc_amd/csrc/zge_entropy.hip -- encoder stage 2: Huffman literals + FSE sequences -> block bytes (gfx950).
+//
+// Part of the replacement for `CCtx::compress2` at crates/zarc/src/encode/lowlevel_frames.rs:29-31.
+// One wave per 128 KiB block (blocks are independent here: no Treeless / Repeat modes are emitted and
+// the repcode history restarts per block), so tens of thousands of waves are in flight and the serial
+// pieces (tree construction, table normalisation, FSE state chains) are latency-hidden by occupancy:
+//   - byte histograms with LDS atomics, symbol ranking by counting (256 symbols, 4 per lane)
+//   - Huffman code lengths (two-queue merge, limited to 11 bits), canonical codes, weight description
+//     (direct or FSE-compressed) on lane 0
+//   - literal streams: 64 symbols per step, wave prefix-sum of code lengths, codes OR-ed into an LDS
+//     staging window (ds_or), whole bytes flushed to HBM
+//   - sequences: code histograms in parallel; the three FSE state chains run on lanes 0..2 for 64
+//     sequences at a time, then all 64 lanes pack their sequence's bit fields the same way
+// Bit-identical to oracle/zstd_enc_model.c (encode_literals / encode_sequences).
+#include "zarc_device.h"
+#include "zarc_kernels.h"
+
+namespace {
+
+constexpr int HUF_MAXBITS = 11;
+constexpr uint32_t MIN_HUF_LITERALS = 64;
+
+__constant__ const uint32_t E_LL_BASE[36] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18,
+                                             20, 22, 24, 28, 32, 40, 48, 64, 128, 256, 512, 1024, 2048,
+                                             4096, 8192, 16384, 32768, 65536};
+__constant__ const uint8_t E_LL_BITS[36] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1,
+                                            1, 1, 2, 2, 3, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+__constant__ const uint32_t E_ML_BASE[53] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19,
+                                             20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34,
+                                             35, 37, 39, 41, 43, 47, 51, 59, 67, 83, 99, 131, 259, 515,
+                                             1027, 2051, 4099, 8195, 16387, 32771, 65539};
+__constant__ const uint8_t E_ML_BITS[53] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                                            0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1,
+                                            2, 2, 3, 3, 4, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+__constant__ const int16_t E_LL_DEFAULT[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2,
+                                               2, 2, 2, 2, 2, 2, 2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1};
+__constant__ const int16_t E_ML_DEFAULT[53] = {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+                                               1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+                                               1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1};
+__constant__ const int16_t E_OF_DEFAULT[29] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1,
+                                               1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1};
+__constant__ const uint8_t E_LL_CODE_16_63[48] = {16, 16, 17, 17, 18, 18, 19, 19, 20, 20, 20, 20, 21, 21, 21, 21,
+                                                  22, 22, 22, 22, 22, 22, 22, 22, 23, 23, 23, 23, 23, 23, 23, 23,
+                                                  24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24};
+__constant__ const uint8_t E_ML_LIM[11] = {34, 36, 38, 40, 44, 48, 56, 64, 80, 96, 128};
+
+__device__ __forceinline__ uint32_t ll_code(uint32_t ll)
+{
+    if (ll < 16) return ll;
+    if (ll < 64) return E_LL_CODE_16_63[ll - 16];
+    return (uint32_t)zd::hb32(ll) + 19;
+}
+__device__ __forceinline__ uint32_t ml_code(uint32_t ml)
+{
+    const uint32_t b = ml - 3;
+    if (b < 32) return b;
+    if (b < 128) { uint32_t c = 0; while (b >= E_ML_LIM[c]) c++; return 32 + c; }
+    return (uint32_t)zd::hb32(b) + 36;
+}
+
+// ---- lane-serial bit writer into a byte buffer (LDS or global) ----
+struct BitW {
+    uint8_t *p; uint32_t pos, cap; uint64_t acc; int nb; bool overflow;
+    __device__ void init(uint8_t *ptr, uint32_t c) { p = ptr; pos = 0; cap = c; acc = 0; nb = 0; overflow = false; }
+    __device__ void add(uint32_t v, int n)
+    {
+        if (n == 0) return;
+        acc |= (uint64_t)(v & (n == 32 ? 0xFFFFFFFFu : ((1u << n) - 1))) << nb;
+        nb += n;
+        while (nb >= 8) {
+            if (pos < cap) p[pos] = (uint8_t)acc; else overflow = true;
+            pos++; acc >>= 8; nb -= 8;
+        }
+    }
+    __device__ void flush_partial() { if (nb > 0) { if (pos < cap) p[pos] = (uint8_t)acc; else overflow = true; pos++; nb = 0; acc = 0; } }
+    __device__ uint32_t close() { add(1, 1); flush_partial(); return pos; }
+};
+
+struct FseCtab { uint16_t *state_tab; int32_t *dnb; int32_t *dfs; int al; };
+
+struct EntLds {
+    uint32_t count[256];
+    uint32_t code[256]; // code | len << 16
+    uint32_t w[512];
+    uint16_t parent[512];
+    uint16_t order[256];
+    uint8_t depth[512];
+    uint8_t cellsym[512];
+    uint8_t len8[256], wt[256];
+    uint16_t st_ll[512], st_ml[512], st_of[256], st_w[64];
+    int32_t dnb_ll[36], dfs_ll[36], dnb_ml[53], dfs_ml[53], dnb_of[32], dfs_of[32], dnb_w[16], dfs_w[16];
+    uint32_t cl[36], co[32], cm[53], cw[16];
+    int16_t norm[3][64];
+    int16_t wnorm[16];
+    uint8_t desc[3][80];
+    uint8_t tmp[192], hdesc[192];
+    uint32_t stage[224];
+    uint32_t chain[3][64]; // value | nb << 16 for LL / OF / ML transitions of the current 64 sequences
+    uint8_t symc[3][64];   // LL / OF / ML codes of the current 64 sequences
+    int32_t ctrl[32];
+};
+enum { X_TMP = 0, X_DLEN = 1, X_MODE_L = 2, X_MODE_O = 3, X_MODE_M = 4, X_AL_L = 5, X_AL_O = 6, X_AL_M = 7, X_DL_L = 8, X_DL_O = 9,
+       X_DL_M = 10, X_RLE_L = 11, X_RLE_O = 12, X_RLE_M = 13, X_NSYM_L = 14, X_NSYM_O = 15, X_NSYM_M = 16, X_MAXBITS = 17, X_NSYM_LAST = 18 };
+
+// ---- FSE helpers (lane-serial; same arithmetic as the model) ----
+__device__ void fse_build_ctab(FseCtab &t, const int16_t *norm, int nsym, int al, uint8_t *cellsym)
+{
+    const int T = 1 << al, step = (T >> 1) + (T >> 3) + 3, mask = T - 1;
+    int high = T - 1, pos = 0;
+    for (int s = 0; s < nsym; s++) if (norm[s] == -1) cellsym[high--] = (uint8_t)s;
+    for (int s = 0; s < nsym; s++) {
+        for (int i = 0; i < norm[s]; i++) {
+            cellsym[pos] = (uint8_t)s;
+            do { pos = (pos + step) & mask; } while (pos > high);
+        }
+    }
+    // cumulative starts; dfs[] doubles as the running "next" index, then gets its final value
+    int total = 0;
+    for (int s = 0; s < nsym; s++) { t.dfs[s] = total; total += norm[s] == -1 ? 1 : norm[s]; }
+    for (int i = 0; i < T; i++) { const int s = cellsym[i]; t.state_tab[t.dfs[s]++] = (uint16_t)(T + i); }
+    total = 0;
+    for (int s = 0; s < nsym; s++) {
+        const int n = norm[s];
+        if (n == 0) { t.dnb[s] = ((al + 1) << 16) - T; t.dfs[s] = 0; continue; }
+        if (n == -1 || n == 1) { t.dnb[s] = (al << 16) - T; t.dfs[s] = total - 1; total += 1; }
+        else {
+            const int max_bits_out = al - zd::hb32((uint32_t)(n - 1));
+            const int min_state_plus = n << max_bits_out;
+            t.dnb[s] = (max_bits_out << 16) - min_state_plus;
+            t.dfs[s] = total - n;
+            total += n;
+        }
+    }
+    t.al = al;
+}
+__device__ __forceinline__ uint32_t fse_init_state(const FseCtab &t, int s)
+{
+    const int nb = (t.dnb[s] + (1 << 15)) >> 16;
+    const int value = (nb << 16) - t.dnb[s];
+    return t.state_tab[(value >> nb) + t.dfs[s]];
+}
+// returns the new state; *bits = value | nb << 16
+__device__ __forceinline__ uint32_t fse_step(const FseCtab &t, uint32_t state, int s, uint32_t *bits)
+{
+    const int nb = (int)((state + (uint32_t)t.dnb[s]) >> 16);
+    *bits = (state & ((1u << nb) - 1)) | ((uint32_t)nb << 16);
+    return t.state_tab[(int)(state >> nb) + t.dfs[s]];
+}
+__device__ uint32_t log2_fp8(uint32_t x)
+{
+    const int h = zd::hb32(x);
+    const uint32_t frac = h >= 8 ? (x >> (h - 8)) - 256 : (x << (8 - h)) - 256;
+    return (uint32_t)h * 256 + frac;
+}
+__device__ void fse_normalize(const uint32_t *count, int nsym, uint32_t total, int al, int16_t *norm)
+{
+    const int T = 1 << al;
+    int sum = 0;
+    for (int s = 0; s < nsym; s++) {
+        if (count[s] == 0) { norm[s] = 0; continue; }
+        uint64_t v = ((uint64_t)count[s] * (uint64_t)T + total / 2) / total;
+        if (v < 1) v = 1;
+        norm[s] = (int16_t)v;
+        sum += (int)v;
+    }
+    while (sum != T) {
+        int best = -1;
+        for (int s = 0; s < nsym; s++) if (norm[s] > 0 && (best < 0 || norm[s] > norm[best])) best = s;
+        if (sum > T) {
+            int take = sum - T;
+            const int room = norm[best] - 1;
+            if (take > room) take = room;
+            if (take <= 0) break;
+            norm[best] = (int16_t)(norm[best] - take);
+            sum -= take;
+        } else {
+            norm[best] = (int16_t)(norm[best] + (T - sum));
+            sum = T;
+        }
+    }
+}
+__device__ uint32_t fse_write_desc(uint8_t *dst, uint32_t cap, const int16_t *norm, int nsym, int al)
+{
+    BitW b;
+    b.init(dst, cap);
+    int remaining = (1 << al) + 1, threshold = 1 << al, nb = al + 1, s = 0;
+    b.add((uint32_t)(al - 5), 4);
+    while (remaining > 1 && s < nsym) {
+        const int count = norm[s++], max = 2 * threshold - 1 - remaining;
+        int val = count + 1;
+        remaining -= count < 0 ? -count : count;
+        if (val >= threshold) val += max;
+        if (val < max) b.add((uint32_t)val, nb - 1); else b.add((uint32_t)val, nb);
+        if (count == 0) {
+            int run = 0;
+            while (s + run < nsym && norm[s + run] == 0) run++;
+            s += run;
+            while (run >= 3) { b.add(3, 2); run -= 3; }
+            b.add((uint32_t)run, 2);
+        }
+        while (remaining < threshold) { nb--; threshold >>= 1; }
+    }
+    b.flush_partial();
+    return b.overflow ? 0 : b.pos;
+}
+__device__ uint64_t dist_cost(const uint32_t *count, const int16_t *norm, int nsym, int al)
+{
+    uint64_t c = 0;
+    for (int s = 0; s < nsym; s++) {
+        if (!count[s]) continue;
+        if (norm[s] == 0) return ~0ull;
+        const uint32_t n = norm[s] < 0 ? 1u : (uint32_t)norm[s];
+        c += (uint64_t)count[s] * ((uint32_t)al * 256 - log2_fp8(n));
+    }
+    return c;
+}
+// lane 0: pick predefined / RLE / dynamic table; results go to ctrl[] slots starting at `slot` offsets
+__device__ void choose_table(EntLds &L, int which, const uint32_t *count, int maxsym, uint32_t nseq, const int16_t *def, int def_n,
+                             int def_al, int max_al)
+{
+    int distinct = 0, last = 0;
+    for (int s = 0; s <= maxsym; s++) if (count[s]) { distinct++; last = s; }
+    int16_t *norm = L.norm[which];
+    if (distinct == 1) { L.ctrl[X_MODE_L + which] = 1; L.ctrl[X_RLE_L + which] = last; L.ctrl[X_DL_L + which] = 0; return; }
+    uint64_t cost_def = ~0ull;
+    if (last < def_n) {
+        // the predefined distribution lives in constant memory; stage it in norm[] to reuse dist_cost
+        for (int s = 0; s < def_n; s++) norm[s] = def[s];
+        cost_def = dist_cost(count, norm, def_n, def_al);
+    }
+    int al = zd::hb32(nseq > 1 ? nseq - 1 : 1) - 2;
+    if (al > max_al) al = max_al;
+    if (al < 5) al = 5;
+    while ((1 << al) < distinct) al++;
+    const int nsym = last + 1;
+    fse_normalize(count, nsym, nseq, al, norm);
+    const uint32_t dl = fse_write_desc(L.desc[which], 80, norm, nsym, al);
+    const uint64_t cost_dyn = dl ? dist_cost(count, norm, nsym, al) + (uint64_t)dl * 8 * 256 : ~0ull;
+    if (cost_def <= cost_dyn) {
+        for (int s = 0; s < def_n; s++) norm[s] = def[s];
+        L.ctrl[X_MODE_L + which] = 0; L.ctrl[X_NSYM_L + which] = def_n; L.ctrl[X_AL_L + which] = def_al; L.ctrl[X_DL_L + which] = 0;
+    } else {
+        L.ctrl[X_MODE_L + which] = 2; L.ctrl[X_NSYM_L + which] = nsym; L.ctrl[X_AL_L + which] = al; L.ctrl[X_DL_L + which] = (int)dl;
+    }
+}
+
+// ---- Huffman construction (lane 0 for the serial parts) ----
+// L.count -> L.len8 (code lengths).  Uniform; returns number of present symbols.
+__device__ int huf_build_lengths(EntLds &L, int lane)
+{
+    // rank by counting: order ascending by (count, symbol)
+    uint32_t present = 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int s = r * 64 + lane;
+        const uint32_t c = L.count[s];
+        L.len8[s] = 0;
+        if (c) {
+            uint32_t rank = 0;
+            for (int t = 0; t < 256; t++) {
+                const uint32_t ct = L.count[t];
+                rank += (ct != 0 && (ct < c || (ct == c && t < s))) ? 1u : 0u;
+            }
+            L.order[rank] = (uint16_t)s;
+        }
+        present += (uint32_t)__popcll(zd::ballot(c != 0));
+    }
+    zd::wave_sync();
+    const int n = (int)present;
+    if (n < 2) { if (n == 1 && lane == 0) L.len8[L.order[0]] = 1; zd::wave_sync(); return n; }
+    if (lane == 0) {
+        for (int i = 0; i < n; i++) L.w[i] = L.count[L.order[i]];
+        int leaf = 0, inode = n, next = n;
+        while (next < 2 * n - 1) {
+            int a, b;
+            if (leaf < n && (inode >= next || L.w[leaf] <= L.w[inode])) a = leaf++; else a = inode++;
+            if (leaf < n && (inode >= next || L.w[leaf] <= L.w[inode])) b = leaf++; else b = inode++;
+            L.w[next] = L.w[a] + L.w[b];
+            L.parent[a] = (uint16_t)next;
+            L.parent[b] = (uint16_t)next;
+            next++;
+        }
+        L.depth[2 * n - 2] = 0;
+        for (int i = 2 * n - 3; i >= 0; i--) { const int d = L.depth[L.parent[i]] + 1; L.depth[i] = (uint8_t)(d > 63 ? 63 : d); }
+        int num[64];
+        for (int k = 0; k < 64; k++) num[k] = 0;
+        for (int i = 0; i < n; i++) num[L.depth[i]]++;
+        for (int k = HUF_MAXBITS + 1; k < 64; k++) { num[HUF_MAXBITS] += num[k]; num[k] = 0; }
+        uint32_t total = 0;
+        for (int k = 1; k <= HUF_MAXBITS; k++) total += (uint32_t)num[k] << (HUF_MAXBITS - k);
+        while (total != (1u << HUF_MAXBITS)) {
+            num[HUF_MAXBITS]--;
+            for (int k = HUF_MAXBITS - 1; k > 0; k--) if (num[k]) { num[k]--; num[k + 1] += 2; break; }
+            total--;
+        }
+        int i = n - 1;
+        for (int k = 1; k <= HUF_MAXBITS; k++) for (int c = 0; c < num[k]; c++) L.len8[L.order[i--]] = (uint8_t)k;
+    }
+    zd::wave_sync();
+    return n;
+}
+
+// lane 0: canonical codes in zstd weight order; fills L.code, ctrl[X_MAXBITS], ctrl[X_NSYM_LAST]
+__device__ void huf_assign_codes(EntLds &L)
+{
+    int maxlen = 0, last = 0;
+    for (int i = 0; i < 256; i++) if (L.len8[i]) { if (L.len8[i] > maxlen) maxlen = L.len8[i]; last = i; }
+    uint32_t rank_start[16], rank_count[16];
+    for (int w = 0; w < 16; w++) rank_count[w] = 0;
+    for (int i = 0; i < 256; i++) if (L.len8[i]) rank_count[maxlen + 1 - L.len8[i]]++;
+    uint32_t pos = 0;
+    for (int w = 1; w <= maxlen; w++) { rank_start[w] = pos; pos += rank_count[w] << (w - 1); }
+    for (int i = 0; i < 256; i++) {
+        if (!L.len8[i]) { L.code[i] = 0; continue; }
+        const int w = maxlen + 1 - L.len8[i];
+        L.code[i] = (rank_start[w] >> (w - 1)) | ((uint32_t)L.len8[i] << 16);
+        rank_start[w] += 1u << (w - 1);
+    }
+    L.ctrl[X_MAXBITS] = maxlen;
+    L.ctrl[X_NSYM_LAST] = last;
+}
+
+// lane 0: Huffman tree description into L.hdesc; returns its length (0 = not representable)
+__device__ uint32_t huf_write_desc(EntLds &L)
+{
+    const int n = L.ctrl[X_NSYM_LAST], max_bits = L.ctrl[X_MAXBITS];
+    for (int i = 0; i < n; i++) L.wt[i] = L.len8[i] ? (uint8_t)(max_bits + 1 - L.len8[i]) : 0;
+    if (n > 1) {
+        for (int s = 0; s < 16; s++) L.cw[s] = 0;
+        for (int i = 0; i < n; i++) L.cw[L.wt[i]]++;
+        int nsym = 0, distinct = 0, al = 6;
+        uint32_t maxc = 0;
+        for (int s = 0; s < 13; s++) if (L.cw[s]) { nsym = s + 1; distinct++; if (L.cw[s] > maxc) maxc = L.cw[s]; }
+        if (distinct > 1 && maxc > 1) {
+            { int lim = zd::hb32((uint32_t)(n - 1)) - 2; if (lim < al) al = lim; if (al < 5) al = 5; }
+            while ((1 << al) < distinct) al++;
+            fse_normalize(L.cw, nsym, (uint32_t)n, al, L.wnorm);
+            const uint32_t hdr = fse_write_desc(L.tmp, 192, L.wnorm, nsym, al);
+            if (hdr) {
+                FseCtab ct = {L.st_w, L.dnb_w, L.dfs_w, 0};
+                fse_build_ctab(ct, L.wnorm, nsym, al, L.cellsym);
+                BitW b;
+                b.init(L.tmp + hdr, 192 - hdr);
+                uint32_t s1, s2, bits;
+                int ip = n;
+                if (n & 1) {
+                    s1 = fse_init_state(ct, L.wt[--ip]);
+                    s2 = fse_init_state(ct, L.wt[--ip]);
+                    s1 = fse_step(ct, s1, L.wt[--ip], &bits); b.add(bits & 0xFFFF, (int)(bits >> 16));
+                } else {
+                    s2 = fse_init_state(ct, L.wt[--ip]);
+                    s1 = fse_init_state(ct, L.wt[--ip]);
+                }
+                while (ip > 0) {
+                    s2 = fse_step(ct, s2, L.wt[--ip], &bits); b.add(bits & 0xFFFF, (int)(bits >> 16));
+                    s1 = fse_step(ct, s1, L.wt[--ip], &bits); b.add(bits & 0xFFFF, (int)(bits >> 16));
+                }
+                b.add(s2, al);
+                b.add(s1, al);
+                const uint32_t body = b.close();
+                if (!b.overflow && hdr + body < 128 && (n > 128 || hdr + body < (uint32_t)(n + 1) / 2)) {
+                    L.hdesc[0] = (uint8_t)(hdr + body);
+                    for (uint32_t i = 0; i < hdr + body; i++) L.hdesc[1 + i] = L.tmp[i];
+                    return 1 + hdr + body;
+                }
+            }
+        }
+    }
+    if (n > 128) return 0;
+    L.hdesc[0] = (uint8_t)(127 + n);
+    for (int i = 0; i < n; i += 2) L.hdesc[1 + i / 2] = (uint8_t)((L.wt[i] << 4) | (i + 1 < n ? L.wt[i + 1] : 0));
+    return (uint32_t)(1 + (n + 1) / 2);
+}
+
+// Wave-parallel bit packer: fields are OR-ed into an LDS staging window and whole bytes are flushed to `dst`.
+struct WavePacker {
+    uint32_t *stage; // LDS, >= 224 words
+    uint8_t *dst;
+    uint32_t pos;    // bytes flushed so far
+    uint32_t carry;  // pending bits (0..7) kept in stage[0]'s low byte
+    uint32_t cap;    // bytes available at dst
+    bool overflow;
+    __device__ void begin(uint32_t *st, uint8_t *d, uint32_t c, int lane)
+    {
+        stage = st; dst = d; pos = 0; carry = 0; cap = c; overflow = false;
+        for (int i = lane; i < 224; i += 64) stage[i] = 0;
+        zd::wave_sync();
+    }
+    // every lane contributes (lo,hi) = up to 96 bits, `nbits` of them, in lane order
+    __device__ void put(uint64_t lo, uint32_t hi, uint32_t nbits, int lane)
+    {
+        const uint32_t incl = zd::wave_scan_incl(nbits);
+        const uint32_t total = zd::uniform(zd::shfl(incl, 63));
+        const uint32_t at = carry + incl - nbits;
+        if (nbits) {
+            const uint32_t w = at >> 5, sh = at & 31;
+            // 96-bit value shifted left by sh (<32) -> up to four 32-bit words
+            const uint32_t v0 = (uint32_t)lo, v1 = (uint32_t)(lo >> 32), v2 = hi;
+            const uint32_t o0 = v0 << sh;
+            const uint32_t o1 = sh ? (v1 << sh) | (v0 >> (32 - sh)) : v1;
+            const uint32_t o2 = sh ? (v2 << sh) | (v1 >> (32 - sh)) : v2;
+            const uint32_t o3 = sh ? (v2 >> (32 - sh)) : 0u;
+            if (o0) atomicOr(&stage[w], o0);
+            if (o1) atomicOr(&stage[w + 1], o1);
+            if (o2) atomicOr(&stage[w + 2], o2);
+            if (o3) atomicOr(&stage[w + 3], o3);
+        }
+        zd::wave_sync();
+        const uint32_t bits = carry + total, full = bits >> 3;
+        const uint8_t *sb = (const uint8_t *)stage;
+        if (pos + full + 1 > cap) overflow = true; // keep one byte for the final partial byte
+        if (!overflow) for (uint32_t i = (uint32_t)lane; i < full; i += 64) dst[pos + i] = sb[i];
+        const uint32_t keep = (bits & 7) ? (uint32_t)sb[full] : 0u;
+        zd::wave_sync();
+        const uint32_t words = (bits + 31) / 32 + 1;
+        for (uint32_t i = (uint32_t)lane; i < words; i += 64) stage[i] = i == 0 ? keep : 0u;
+        zd::wave_sync();
+        pos += full;
+        carry = bits & 7;
+    }
+    // end mark + final partial byte; returns total bytes
+    __device__ uint32_t finish(int lane)
+    {
+        put(1, 0, lane == 0 ? 1u : 0u, lane);
+        if (carry) {
+            if (lane == 0 && !overflow) dst[pos] = (uint8_t)stage[0];
+            pos += 1;
+            carry = 0;
+        }
+        return pos;
+    }
+};
+
+} // namespace
+
+__global__ void __launch_bounds__(64) zarc_zge_entropy(uint32_t n_blocks, ZgeBlock *__restrict__ blocks, const uint64_t *__restrict__ seq_scratch,
+                                                       const uint8_t *__restrict__ lit_scratch, uint8_t *__restrict__ out_scratch)
+{
+    __shared__ EntLds L;
+    const int lane = zd::lane_id();
+    const uint32_t bi = blockIdx.x;
+    if (bi >= n_blocks) return;
+    ZgeBlock *rec = blocks + bi;
+    if (rec->type == 1) return; // RLE block: nothing to code
+    const uint32_t nlit = rec->nlit, nseq = rec->nseq, src_len = rec->src_len;
+    const uint64_t *seq = seq_scratch + (uint64_t)bi * ZARC_MAX_SEQ;
+    const uint8_t *lit = lit_scratch + (uint64_t)bi * (ZARC_BLOCK + 64);
+    uint8_t *out = out_scratch + (uint64_t)bi * (ZARC_BLOCK + 1024);
+    const uint32_t out_cap = ZARC_BLOCK + 1024;
+    bool fail = false;
+
+    // ================= literals section =================
+    uint32_t lsz = 0;
+    {
+        const uint32_t n = nlit;
+        const uint32_t raw_hdr = n < 32 ? 1u : (n < 4096 ? 2u : 3u);
+        for (int i = lane; i < 256; i += 64) L.count[i] = 0;
+        zd::wave_sync();
+        for (uint32_t i = (uint32_t)lane; i < n; i += 64) atomicAdd(&L.count[lit[i]], 1u);
+        zd::wave_sync();
+        uint32_t distinct = 0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) distinct += (uint32_t)__popcll(zd::ballot(L.count[r * 64 + lane] != 0));
+        int kind = 0; // 0 raw, 1 rle, 2 huffman
+        if (n >= 2 && distinct == 1) kind = 1;
+        else if (n >= MIN_HUF_LITERALS && distinct >= 2) {
+            huf_build_lengths(L, lane);
+            if (lane == 0) {
+                huf_assign_codes(L);
+                const uint32_t dlen = huf_write_desc(L);
+                uint64_t est_bits = 0;
+                for (int i = 0; i < 256; i++) est_bits += (uint64_t)L.count[i] * L.len8[i];
+                const uint64_t est = dlen + (est_bits + 7) / 8 + (n >= 256 ? 10 : 1);
+                L.ctrl[X_DLEN] = (dlen && est + 3 < n) ? (int)dlen : 0;
+            }
+            zd::wave_sync();
+            const uint32_t dlen = (uint32_t)L.ctrl[X_DLEN];
+            zd::wave_sync();
+            if (dlen) {
+                const bool single = n < 256;
+                const uint32_t hdr = single ? 3u : (n < 1024 ? 3u : (n < 16384 ? 4u : 5u));
+                uint8_t *body = out + hdr;
+                for (uint32_t i = (uint32_t)lane; i < dlen; i += 64) body[i] = L.hdesc[i];
+                uint32_t pos = dlen, ssz[4] = {0, 0, 0, 0};
+                const uint32_t nstreams = single ? 1u : 4u, per = single ? n : (n + 3) / 4, jt = pos;
+                if (!single) pos += 6;
+                WavePacker pk;
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) {
+                    if (k >= nstreams) break;
+                    const uint32_t beg = k * per, cnt = single ? n : (k < 3 ? per : n - 3 * per);
+                    pk.begin(L.stage, body + pos, out_cap - hdr - pos, lane);
+                    for (uint32_t j0 = 0; j0 < cnt; j0 += 64) {
+                        const uint32_t j = j0 + (uint32_t)lane;
+                        uint32_t cv = 0, cl_ = 0;
+                        if (j < cnt) { const uint32_t e = L.code[lit[beg + cnt - 1 - j]]; cv = e & 0xFFFF; cl_ = e >> 16; }
+                        pk.put(cv, 0, cl_, lane);
+                    }
+                    ssz[k] = pk.finish(lane);
+                    if (pk.overflow) fail = true;
+                    pos += ssz[k];
+                }
+                if (!single) {
+                    if (lane == 0) for (int k = 0; k < 3; k++) { body[jt + 2 * k] = (uint8_t)ssz[k]; body[jt + 2 * k + 1] = (uint8_t)(ssz[k] >> 8); }
+                    if (ssz[0] > 65535 || ssz[1] > 65535 || ssz[2] > 65535) fail = true;
+                }
+                const uint32_t comp = pos;
+                if (!fail && comp + hdr < n + raw_hdr) {
+                    uint64_t v;
+                    if (hdr == 3) v = 2u | ((single ? 0u : 1u) << 2) | ((uint64_t)n << 4) | ((uint64_t)comp << 14);
+                    else if (hdr == 4) v = 2u | (2u << 2) | ((uint64_t)n << 4) | ((uint64_t)comp << 18);
+                    else v = 2u | (3u << 2) | ((uint64_t)n << 4) | ((uint64_t)comp << 22);
+                    if (lane == 0) for (uint32_t i = 0; i < hdr; i++) out[i] = (uint8_t)(v >> (8 * i));
+                    lsz = hdr + comp;
+                    kind = 2;
+                }
+            }
+        }
+        if (kind == 1) {
+            if (lane == 0) {
+                if (raw_hdr == 1) out[0] = (uint8_t)(1 | (n << 3));
+                else if (raw_hdr == 2) { out[0] = (uint8_t)(1 | (1 << 2) | ((n & 15) << 4)); out[1] = (uint8_t)(n >> 4); }
+                else { out[0] = (uint8_t)(1 | (3 << 2) | ((n & 15) << 4)); out[1] = (uint8_t)(n >> 4); out[2] = (uint8_t)(n >> 12); }
+                out[raw_hdr] = lit[0];
+            }
+            lsz = raw_hdr + 1;
+        } else if (kind == 0) {
+            if (lane == 0) {
+                if (raw_hdr == 1) out[0] = (uint8_t)(0 | (n << 3));
+                else if (raw_hdr == 2) { out[0] = (uint8_t)(0 | (1 << 2) | ((n & 15) << 4)); out[1] = (uint8_t)(n >> 4); }
+                else { out[0] = (uint8_t)(0 | (3 << 2) | ((n & 15) << 4)); out[1] = (uint8_t)(n >> 4); out[2] = (uint8_t)(n >> 12); }
+            }
+            for (uint32_t i = (uint32_t)lane; i < n; i += 64) out[raw_hdr + i] = lit[i];
+            lsz = raw_hdr + n;
+        }
+    }
+    zd::wave_sync_global();
+
+    // ================= sequences section =================
+    uint32_t ssz = 0;
+    if (!fail) {
+        uint8_t *so = out + lsz;
+        const uint32_t scap = out_cap - lsz;
+        uint32_t pos = 0;
+        if (lane == 0) {
+            if (nseq < 128) so[0] = (uint8_t)nseq;
+            else if (nseq < 0x7F00) { so[0] = (uint8_t)((nseq >> 8) + 128); so[1] = (uint8_t)nseq; }
+            else { so[0] = 255; so[1] = (uint8_t)(nseq - 0x7F00); so[2] = (uint8_t)((nseq - 0x7F00) >> 8); }
+        }
+        pos = nseq < 128 ? 1u : (nseq < 0x7F00 ? 2u : 3u);
+        if (nseq == 0) ssz = pos;
+        else {
+            for (int i = lane; i < 36; i += 64) L.cl[i] = 0;
+            for (int i = lane; i < 32; i += 64) L.co[i] = 0;
+            for (int i = lane; i < 53; i += 64) L.cm[i] = 0;
+            zd::wave_sync();
+            for (uint32_t i = (uint32_t)lane; i < nseq; i += 64) {
+                const uint64_t s = seq[i];
+                atomicAdd(&L.cl[ll_code(zge_seq_ll(s))], 1u);
+                atomicAdd(&L.cm[ml_code(zge_seq_ml(s))], 1u);
+                atomicAdd(&L.co[zd::hb32(zge_seq_ofv(s))], 1u);
+            }
+            zd::wave_sync();
+            if (lane == 0) {
+                choose_table(L, 0, L.cl, 35, nseq, E_LL_DEFAULT, 36, 6, 9);
+                choose_table(L, 1, L.co, 31, nseq, E_OF_DEFAULT, 29, 5, 8);
+                choose_table(L, 2, L.cm, 52, nseq, E_ML_DEFAULT, 53, 6, 9);
+                FseCtab tl_ = {L.st_ll, L.dnb_ll, L.dfs_ll, 0}, to_ = {L.st_of, L.dnb_of, L.dfs_of, 0}, tm_ = {L.st_ml, L.dnb_ml, L.dfs_ml, 0};
+                if (L.ctrl[X_MODE_L] != 1) fse_build_ctab(tl_, L.norm[0], L.ctrl[X_NSYM_L], L.ctrl[X_AL_L], L.cellsym);
+                if (L.ctrl[X_MODE_O] != 1) fse_build_ctab(to_, L.norm[1], L.ctrl[X_NSYM_O], L.ctrl[X_AL_O], L.cellsym);
+                if (L.ctrl[X_MODE_M] != 1) fse_build_ctab(tm_, L.norm[2], L.ctrl[X_NSYM_M], L.ctrl[X_AL_M], L.cellsym);
+            }
+            zd::wave_sync();
+            const int mode_l = L.ctrl[X_MODE_L], mode_o = L.ctrl[X_MODE_O], mode_m = L.ctrl[X_MODE_M];
+            const uint32_t dl_l = (uint32_t)L.ctrl[X_DL_L], dl_o = (uint32_t)L.ctrl[X_DL_O], dl_m = (uint32_t)L.ctrl[X_DL_M];
+            const int al_l = L.ctrl[X_AL_L], al_o = L.ctrl[X_AL_O], al_m = L.ctrl[X_AL_M];
+            if (pos + 4 + dl_l + dl_o + dl_m > scap) fail = true;
+            if (!fail) {
+                if (lane == 0) {
+                    so[pos] = (uint8_t)((mode_l << 6) | (mode_o << 4) | (mode_m << 2));
+                    uint32_t q = pos + 1;
+                    if (mode_l == 1) so[q++] = (uint8_t)L.ctrl[X_RLE_L]; else for (uint32_t i = 0; i < dl_l; i++) so[q++] = L.desc[0][i];
+                    if (mode_o == 1) so[q++] = (uint8_t)L.ctrl[X_RLE_O]; else for (uint32_t i = 0; i < dl_o; i++) so[q++] = L.desc[1][i];
+                    if (mode_m == 1) so[q++] = (uint8_t)L.ctrl[X_RLE_M]; else for (uint32_t i = 0; i < dl_m; i++) so[q++] = L.desc[2][i];
+                }
+                pos += 1 + (mode_l == 1 ? 1u : dl_l) + (mode_o == 1 ? 1u : dl_o) + (mode_m == 1 ? 1u : dl_m);
+                // FSE state chains: lane 0 = LL, lane 1 = OF, lane 2 = ML; 64 sequences per round, last -> first
+                FseCtab ct;
+                int my_mode = 1;
+                if (lane == 0) { ct = FseCtab{L.st_ll, L.dnb_ll, L.dfs_ll, al_l}; my_mode = mode_l; }
+                else if (lane == 1) { ct = FseCtab{L.st_of, L.dnb_of, L.dfs_of, al_o}; my_mode = mode_o; }
+                else { ct = FseCtab{L.st_ml, L.dnb_ml, L.dfs_ml, al_m}; my_mode = lane == 2 ? mode_m : 1; }
+                uint32_t state = 0;
+                WavePacker pk;
+                pk.begin(L.stage, so + pos, scap - pos, lane);
+                for (uint32_t done = 0; done < nseq; done += 64) {
+                    const uint32_t cnt = nseq - done < 64 ? nseq - done : 64;
+                    // element e of this round is sequence index (nseq-1-done-e); lane e loads and classifies it
+                    uint32_t ll = 0, ml = 3, ofv = 1, llc = 0, mlc = 0, ofc = 0;
+                    if ((uint32_t)lane < cnt) {
+                        const uint64_t s = seq[nseq - 1 - done - (uint32_t)lane];
+                        ll = zge_seq_ll(s); ml = zge_seq_ml(s); ofv = zge_seq_ofv(s);
+                        llc = ll_code(ll); mlc = ml_code(ml); ofc = (uint32_t)zd::hb32(ofv);
+                        L.symc[0][lane] = (uint8_t)llc; L.symc[1][lane] = (uint8_t)ofc; L.symc[2][lane] = (uint8_t)mlc;
+                    }
+                    zd::wave_sync();
+                    if (lane < 3) {
+                        for (uint32_t e = 0; e < cnt; e++) {
+                            const int sym = L.symc[lane][e];
+                            uint32_t bits = 0;
+                            if (my_mode != 1) {
+                                if (done + e == 0) state = fse_init_state(ct, sym);
+                                else state = fse_step(ct, state, sym, &bits);
+                            }
+                            L.chain[lane][e] = bits;
+                        }
+                    }
+                    zd::wave_sync();
+                    uint64_t lo = 0;
+                    uint32_t hi = 0, nb = 0;
+                    if ((uint32_t)lane < cnt) {
+                        const uint32_t bo = L.chain[1][lane], bm = L.chain[2][lane], bl = L.chain[0][lane];
+                        // order: OF state bits, ML state bits, LL state bits, LL extra, ML extra, OF extra
+                        uint64_t acc = bo & 0xFFFF; uint32_t sh = bo >> 16;
+                        acc |= (uint64_t)(bm & 0xFFFF) << sh; sh += bm >> 16;
+                        acc |= (uint64_t)(bl & 0xFFFF) << sh; sh += bl >> 16;                     // <= 27 bits
+                        acc |= (uint64_t)(ll - E_LL_BASE[llc]) << sh; sh += E_LL_BITS[llc];      // <= 43
+                        acc |= (uint64_t)(ml - E_ML_BASE[mlc]) << sh; sh += E_ML_BITS[mlc];      // <= 59
+                        const uint64_t ofx = (uint64_t)(ofv - (1u << ofc));
+                        lo = acc | (ofx << sh);
+                        hi = sh == 0 ? 0u : (uint32_t)(ofx >> (64 - sh));
+                        nb = sh + ofc;
+                    }
+                    pk.put(lo, hi, nb, lane);
+                    zd::wave_sync();
+                }
+                // flush ML, OF, LL states (in that order)
+                {
+                    const uint32_t st_l = zd::shfl(state, 0), st_o = zd::shfl(state, 1), st_m = zd::shfl(state, 2);
+                    uint64_t lo = 0; uint32_t nb = 0;
+                    if (lane == 0) {
+                        if (mode_m != 1) { lo |= (uint64_t)(st_m & ((1u << al_m) - 1)) << nb; nb += (uint32_t)al_m; }
+                        if (mode_o != 1) { lo |= (uint64_t)(st_o & ((1u << al_o) - 1)) << nb; nb += (uint32_t)al_o; }
+                        if (mode_l != 1) { lo |= (uint64_t)(st_l & ((1u << al_l) - 1)) << nb; nb += (uint32_t)al_l; }
+                    }
+                    pk.put(lo, 0, nb, lane);
+                }
+                const uint32_t bytes = pk.finish(lane);
+                if (pk.overflow || pos + bytes > scap) fail = true;
+                ssz = pos + bytes;
+            }
+        }
+    }
+    const uint32_t csz = fail ? 0u : lsz + ssz;
+    if (lane == 0) {
+        if (csz && csz < src_len) { rec->type = 2; rec->out_len = csz; }
+        else { rec->type = 0; rec->out_len = src_len; }
+    }
+}

@@ -1,0 +1,626 @@
+// zarc_amd/csrc/zstd_decode.hip -- batched Zstandard frame decoder for gfx950 (RFC 8878).
+//
+// Replaces libzstd's ZSTD_decompressStream as driven by the reference at
+//   crates/zarc/src/decode/zstd_iterator.rs:88-153 (decompress_step) / :24-36 (one fresh DCtx per frame).
+// Frames are independent (no dictionary, no cross-frame window), so the unit of parallelism is the frame:
+// ONE WAVE PER FRAME, thousands of frames in flight.  Inside a frame the format is a chain of serial
+// dependencies (backward bitstreams, FSE states, repeat offsets, LZ window), so:
+//   - table construction and bitstream decoding run on one lane (or four lanes for the four Huffman
+//     streams) -- latency is hidden by the other resident waves, not by lanes of this wave;
+//   - every byte move (raw/RLE blocks, literal runs, match copies) is wave-cooperative, 64 lanes wide;
+//   - decode tables live in LDS (about 9.5 KiB per wave: 2048x2 B Huffman + 512/512/256 x 4 B FSE), which
+//     also makes Treeless literals and Repeat-mode tables free: the previous block's tables simply stay.
+// Literals of Huffman-coded blocks are regenerated into a per-frame scratch area in HBM; raw literals
+// are used in place from the compressed stream.
+// Algorithmic traffic per frame: C bytes read + N bytes written (+ literals scratch round trip).
+#include "zarc_device.h"
+#include "zarc_kernels.h"
+
+namespace {
+
+constexpr int BLOCK_MAX = 128 * 1024;
+constexpr int SEQ_BATCH = 32;
+
+__constant__ const uint32_t D_LL_BASE[36] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18,
+                                             20, 22, 24, 28, 32, 40, 48, 64, 128, 256, 512, 1024, 2048,
+                                             4096, 8192, 16384, 32768, 65536};
+__constant__ const uint8_t D_LL_BITS[36] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1,
+                                            1, 1, 2, 2, 3, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+__constant__ const uint32_t D_ML_BASE[53] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19,
+                                             20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34,
+                                             35, 37, 39, 41, 43, 47, 51, 59, 67, 83, 99, 131, 259, 515,
+                                             1027, 2051, 4099, 8195, 16387, 32771, 65539};
+__constant__ const uint8_t D_ML_BITS[53] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                                            0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1,
+                                            2, 2, 3, 3, 4, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+__constant__ const int8_t D_LL_DEFAULT[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2,
+                                              2, 2, 2, 2, 2, 2, 2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1};
+__constant__ const int8_t D_ML_DEFAULT[53] = {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+                                              1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+                                              1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1};
+__constant__ const int8_t D_OF_DEFAULT[29] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1,
+                                              1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1};
+
+// ---- backward bit reader (one lane) -----------------------------------------------------------
+struct BackBits {
+    const uint8_t *p;
+    int32_t bitpos; // unread bits below the cursor; negative = read past the beginning
+    uint64_t c;     // container: the next k bits are (c << used) >> (64 - k)
+    int32_t used;
+    __device__ __forceinline__ void refill()
+    {
+        int32_t top_byte = (bitpos + 7) >> 3;
+        if (top_byte >= 8) c = zd::load_u64(p + top_byte - 8);
+        else if (top_byte > 0) c = zd::load_u64(p) << (8 * (8 - top_byte));
+        else c = 0;
+        used = 8 * top_byte - bitpos;
+    }
+    // returns false if the stream is malformed (empty or last byte zero)
+    __device__ __forceinline__ bool init(const uint8_t *ptr, uint32_t len)
+    {
+        p = ptr;
+        if (len == 0) return false;
+        uint32_t last = ptr[len - 1];
+        if (last == 0) return false;
+        bitpos = (int32_t)(len - 1) * 8 + zd::hb32(last);
+        refill();
+        return true;
+    }
+    __device__ __forceinline__ uint32_t peek(int k) // 1 <= k <= 32
+    {
+        if (used + k > 64) refill();
+        return (uint32_t)((c << used) >> (64 - k));
+    }
+    __device__ __forceinline__ void skip(int k) { used += k; bitpos -= k; }
+    __device__ __forceinline__ uint32_t read(int k) // 0 <= k <= 32
+    {
+        if (k == 0) return 0;
+        uint32_t v = peek(k);
+        skip(k);
+        return v;
+    }
+};
+
+// ---- forward bit reader (one lane), for FSE table descriptions -----------------------------------
+struct FwdBits {
+    const uint8_t *p;
+    uint32_t bitpos;
+    __device__ __forceinline__ uint32_t peek(int k) { return (zd::load_u32(p + (bitpos >> 3)) >> (bitpos & 7)) & ((1u << k) - 1); }
+};
+
+// FSE decode cell: sym | nbits << 8 | base << 16
+__device__ __forceinline__ uint32_t cell_sym(uint32_t c) { return c & 0xFF; }
+__device__ __forceinline__ uint32_t cell_nbits(uint32_t c) { return (c >> 8) & 0xFF; }
+__device__ __forceinline__ uint32_t cell_base(uint32_t c) { return c >> 16; }
+
+// Build an FSE decode table from normalized counts (lane-serial).  Returns false on bad distributions.
+__device__ bool fse_build_dtable(uint32_t *tab, const int16_t *norm, int nsym, int al, uint16_t *next /*>=nsym*/)
+{
+    const int T = 1 << al;
+    int high = T - 1;
+    for (int s = 0; s < nsym; s++) {
+        if (norm[s] == -1) { tab[high--] = (uint32_t)s; next[s] = 1; }
+        else next[s] = (uint16_t)norm[s];
+    }
+    const int step = (T >> 1) + (T >> 3) + 3, mask = T - 1;
+    int pos = 0;
+    for (int s = 0; s < nsym; s++) {
+        for (int i = 0; i < norm[s]; i++) {
+            tab[pos] = (uint32_t)s;
+            do { pos = (pos + step) & mask; } while (pos > high);
+        }
+    }
+    if (pos != 0) return false;
+    for (int i = 0; i < T; i++) {
+        uint32_t s = tab[i];
+        uint32_t x = next[s]++;
+        uint32_t nb = (uint32_t)(al - zd::hb32(x));
+        uint32_t base = (x << nb) - (uint32_t)T;
+        tab[i] = s | (nb << 8) | (base << 16);
+    }
+    return true;
+}
+
+// Parse an FSE table description (lane-serial).  Returns bytes consumed, or -1.
+__device__ int fse_read_desc(const uint8_t *src, uint32_t len, int max_al, int max_sym, int16_t *norm, int *nsym_out, int *al_out)
+{
+    if (len == 0) return -1;
+    FwdBits b = {src, 0};
+    int al = (int)b.peek(4) + 5;
+    b.bitpos += 4;
+    if (al > max_al) return -1;
+    int remaining = (1 << al) + 1, threshold = 1 << al, nb = al + 1, sym = 0;
+    for (int i = 0; i <= max_sym; i++) norm[i] = 0;
+    const uint32_t limit_bits = len * 8;
+    while (remaining > 1 && sym <= max_sym) {
+        if (b.bitpos + (uint32_t)nb > limit_bits + 7) return -1; // a valid description never needs this
+        int max = 2 * threshold - 1 - remaining;
+        int low = (int)b.peek(nb - 1), val;
+        if (low < max) { val = low; b.bitpos += (uint32_t)(nb - 1); }
+        else {
+            val = (int)b.peek(nb);
+            if (val >= threshold) val -= max;
+            b.bitpos += (uint32_t)nb;
+        }
+        int count = val - 1;
+        remaining -= count < 0 ? -count : count;
+        norm[sym++] = (int16_t)count;
+        if (count == 0) {
+            for (;;) {
+                if (b.bitpos + 2 > limit_bits) return -1;
+                int rep = (int)b.peek(2);
+                b.bitpos += 2;
+                sym += rep;
+                if (rep != 3) break;
+            }
+            if (sym > max_sym + 1) return -1;
+        }
+        while (remaining < threshold) { nb--; threshold >>= 1; }
+    }
+    if (remaining != 1 || sym > max_sym + 1 || b.bitpos > limit_bits) return -1;
+    *nsym_out = sym;
+    *al_out = al;
+    return (int)((b.bitpos + 7) >> 3);
+}
+
+struct Lds {
+    uint16_t huf[2048];   // sym | nbits << 8
+    uint32_t ll[512], ml[512], of[256];
+    uint8_t weights[256];
+    int16_t norm[64];
+    uint16_t next[64];
+    uint32_t wtab[64];    // FSE table for Huffman weights (accuracy <= 6)
+    uint32_t seq[SEQ_BATCH * 3];
+    int32_t ctrl[16];
+};
+enum { C_ERR = 0, C_HUF_BITS = 1, C_HUF_VALID = 2, C_LL_AL = 3, C_OF_AL = 4, C_ML_AL = 5, C_LL_OK = 6, C_OF_OK = 7, C_ML_OK = 8,
+       C_TMP0 = 9, C_TMP1 = 10, C_TMP2 = 11 };
+
+// wave-cooperative byte copy; src and dst never overlap forward within one call
+__device__ __forceinline__ void wave_copy(uint8_t *dst, const uint8_t *src, uint32_t n, int lane)
+{
+    for (uint32_t i = (uint32_t)lane; i < n; i += 64) dst[i] = src[i];
+}
+
+// Huffman tree description -> weights in LDS, returns bytes consumed (or -1); lane-serial part on lane 0.
+__device__ int huf_read_weights(Lds &L, const uint8_t *src, uint32_t len, int lane, int *nweights)
+{
+    if (len < 1) return -1;
+    const uint32_t hb = src[0];
+    int consumed, n;
+    if (hb >= 128) {
+        n = (int)hb - 127;
+        consumed = 1 + (n + 1) / 2;
+        if ((uint32_t)consumed > len) return -1;
+        for (int i = lane; i < n; i += 64) {
+            uint8_t byte = src[1 + i / 2];
+            L.weights[i] = (i & 1) ? (byte & 15) : (byte >> 4);
+        }
+        zd::wave_sync();
+    } else {
+        if (hb == 0 || 1 + hb > len) return -1;
+        if (lane == 0) {
+            int nsym = 0, al = 0, cnt = -1;
+            int used = fse_read_desc(src + 1, hb, 6, 63, L.norm, &nsym, &al); // weights are <= 11; 63 bounds L.norm
+            BackBits b;
+            if (used > 0 && (uint32_t)used < hb && fse_build_dtable(L.wtab, L.norm, nsym, al, L.next) &&
+                b.init(src + 1 + used, hb - (uint32_t)used)) {
+                uint32_t s1 = b.read(al), s2 = b.read(al);
+                if (b.bitpos >= 0) {
+                    cnt = 0;
+                    for (;;) {
+                        if (cnt > 253) { cnt = -1; break; }
+                        L.weights[cnt++] = (uint8_t)cell_sym(L.wtab[s1]);
+                        s1 = cell_base(L.wtab[s1]) + b.read((int)cell_nbits(L.wtab[s1]));
+                        if (b.bitpos < 0) { L.weights[cnt++] = (uint8_t)cell_sym(L.wtab[s2]); break; }
+                        if (cnt > 253) { cnt = -1; break; }
+                        L.weights[cnt++] = (uint8_t)cell_sym(L.wtab[s2]);
+                        s2 = cell_base(L.wtab[s2]) + b.read((int)cell_nbits(L.wtab[s2]));
+                        if (b.bitpos < 0) { L.weights[cnt++] = (uint8_t)cell_sym(L.wtab[s1]); break; }
+                    }
+                }
+            }
+            L.ctrl[C_TMP0] = cnt;
+        }
+        zd::wave_sync();
+        n = L.ctrl[C_TMP0];
+        zd::wave_sync();
+        if (n < 1) return -1;
+        consumed = 1 + (int)hb;
+    }
+    *nweights = n;
+    return consumed;
+}
+
+// weights[0..n) in LDS -> decode table.  Uniform; returns false on an invalid tree.
+__device__ bool huf_build_table(Lds &L, int n, int lane)
+{
+    // sum of 2^(w-1)
+    uint32_t part = 0;
+    bool bad = false;
+    for (int i = lane; i < n; i += 64) {
+        uint32_t w = L.weights[i];
+        if (w > 11) bad = true;
+        else if (w) part += 1u << (w - 1);
+    }
+    const uint32_t sum = zd::wave_sum(part);
+    if (zd::ballot(bad) != 0 || sum == 0) return false;
+    const int max_bits = zd::hb32(sum) + 1;
+    if (max_bits > 11) return false;
+    const uint32_t left = (1u << max_bits) - sum;
+    if (left & (left - 1)) return false;
+    const uint32_t last_w = (uint32_t)zd::hb32(left) + 1;
+    if (lane == 0) L.weights[n] = (uint8_t)last_w;
+    zd::wave_sync();
+    const int nsym = n + 1;
+    // rank_start[w] for w = 1..max_bits, computed redundantly by every lane from ballots
+    uint32_t run[12];
+#pragma unroll
+    for (int w = 0; w < 12; w++) run[w] = 0;
+    uint32_t my_start[4] = {0, 0, 0, 0}, my_w[4] = {0, 0, 0, 0};
+    // pass 1: counts per weight
+    uint32_t cnt[12];
+#pragma unroll
+    for (int w = 0; w < 12; w++) cnt[w] = 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int s = r * 64 + lane;
+        const uint32_t w = s < nsym ? L.weights[s] : 0u;
+        my_w[r] = w;
+#pragma unroll
+        for (int ww = 1; ww < 12; ww++) cnt[ww] += (uint32_t)__popcll(zd::ballot(w == (uint32_t)ww));
+    }
+    uint32_t start[12], pos = 0;
+#pragma unroll
+    for (int ww = 1; ww < 12; ww++) { start[ww] = pos; pos += cnt[ww] << (ww - 1); }
+    if (pos != (1u << max_bits)) return false;
+    // pass 2: each symbol's slot = start[w] + (symbols of the same weight before it) << (w-1)
+    const uint64_t lt = (1ull << lane) - 1;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const uint32_t w = my_w[r];
+#pragma unroll
+        for (int ww = 1; ww < 12; ww++) {
+            const uint64_t m = zd::ballot(w == (uint32_t)ww);
+            if (w == (uint32_t)ww) my_start[r] = start[ww] + ((run[ww] + (uint32_t)__popcll(m & lt)) << (ww - 1));
+            run[ww] += (uint32_t)__popcll(m);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const uint32_t w = my_w[r];
+        if (w) {
+            const uint32_t lenr = 1u << (w - 1);
+            const uint16_t e = (uint16_t)((uint32_t)(r * 64 + lane) | ((uint32_t)(max_bits + 1 - (int)w) << 8));
+            for (uint32_t k = 0; k < lenr; k++) L.huf[my_start[r] + k] = e;
+        }
+    }
+    if (lane == 0) { L.ctrl[C_HUF_BITS] = max_bits; L.ctrl[C_HUF_VALID] = 1; }
+    zd::wave_sync();
+    return true;
+}
+
+// One Huffman stream on the calling lane.  Returns false on corruption.
+__device__ bool huf_decode_stream(const Lds &L, int max_bits, const uint8_t *src, uint32_t len, uint8_t *out, uint32_t nout)
+{
+    BackBits b;
+    if (!b.init(src, len)) return false;
+    for (uint32_t i = 0; i < nout; i++) {
+        const uint32_t e = L.huf[b.peek(max_bits)];
+        b.skip((int)(e >> 8));
+        out[i] = (uint8_t)e;
+    }
+    return b.bitpos == 0;
+}
+
+// (Re)build one sequence table according to its mode.  Uniform entry; the work runs on lane 0.
+// Returns bytes consumed from src, or -1.
+__device__ int seq_table(Lds &L, uint32_t *tab, int ctrl_al, int ctrl_ok, int mode, const uint8_t *src, uint32_t len,
+                         const int8_t *def, int def_n, int def_al, int max_al, int max_sym, int lane)
+{
+    if (lane == 0) {
+        int res = -1;
+        if (mode == 0) {
+            for (int i = 0; i < def_n; i++) L.norm[i] = def[i];
+            if (fse_build_dtable(tab, L.norm, def_n, def_al, L.next)) { L.ctrl[ctrl_al] = def_al; L.ctrl[ctrl_ok] = 1; res = 0; }
+        } else if (mode == 1) {
+            if (len >= 1 && src[0] <= max_sym) { tab[0] = src[0]; L.ctrl[ctrl_al] = 0; L.ctrl[ctrl_ok] = 1; res = 1; }
+        } else if (mode == 2) {
+            int nsym = 0, al = 0;
+            int used = fse_read_desc(src, len, max_al, max_sym, L.norm, &nsym, &al);
+            if (used > 0 && fse_build_dtable(tab, L.norm, nsym, al, L.next)) { L.ctrl[ctrl_al] = al; L.ctrl[ctrl_ok] = 1; res = used; }
+        } else {
+            res = L.ctrl[ctrl_ok] ? 0 : -1;
+        }
+        L.ctrl[C_TMP0] = res;
+    }
+    zd::wave_sync();
+    const int r = L.ctrl[C_TMP0];
+    zd::wave_sync();
+    return r;
+}
+
+} // namespace
+
+// One wave (64-thread workgroup) per frame.  order[] lists frame indices, largest first.
+__global__ void __launch_bounds__(64) zarc_zstd_decode(const uint8_t *__restrict__ frames_base, const uint64_t *__restrict__ frame_off,
+                                                       const uint64_t *__restrict__ frame_len, uint8_t *__restrict__ dst_base,
+                                                       const uint64_t *__restrict__ dst_off, const uint64_t *__restrict__ raw_len,
+                                                       const uint32_t *__restrict__ order, uint32_t n_frames,
+                                                       uint8_t *__restrict__ lit_scratch, int32_t *__restrict__ status,
+                                                       uint32_t *__restrict__ stored_checksum /* 2 words/frame: has, value */)
+{
+    __shared__ Lds L;
+    const int lane = zd::lane_id();
+    const uint32_t f = order[blockIdx.x];
+    const uint8_t *src = frames_base + frame_off[f];
+    const uint32_t slen = (uint32_t)frame_len[f];
+    uint8_t *out = dst_base + dst_off[f];
+    const uint64_t cap = raw_len[f];
+    uint8_t *lit_buf = lit_scratch + (uint64_t)blockIdx.x * (BLOCK_MAX + 64);
+    int err = ZARC_FRAME_OK;
+
+    if (lane == 0) {
+        for (int i = 0; i < 16; i++) L.ctrl[i] = 0;
+    }
+    zd::wave_sync();
+
+    // ---- frame header (every lane computes the same values) ----
+    uint32_t pos = 0;
+    uint32_t has_ck = 0;
+    uint64_t window = 0, fcs = 0; // window is parsed for completeness; offsets are only checked against the output position
+    bool have_fcs = false;
+    if (slen < 6) err = ZARC_FRAME_SRCSIZE;
+    else if (!(src[0] == 0x28 && src[1] == 0xB5 && src[2] == 0x2F && src[3] == 0xFD)) err = ZARC_FRAME_BAD_MAGIC;
+    else {
+        const uint32_t desc = src[4];
+        const uint32_t fcs_flag = desc >> 6, ss = (desc >> 5) & 1, did_flag = desc & 3;
+        has_ck = (desc >> 2) & 1;
+        pos = 5;
+        if (desc & 8) err = ZARC_FRAME_CORRUPT;
+        const uint32_t did_bytes = did_flag == 3 ? 4u : did_flag;
+        const uint32_t fcs_bytes = fcs_flag == 0 ? ss : (1u << fcs_flag);
+        if (!err && pos + (ss ? 0u : 1u) + did_bytes + fcs_bytes > slen) err = ZARC_FRAME_SRCSIZE;
+        if (!err) {
+            if (!ss) {
+                const uint32_t wd = src[pos++];
+                window = 1ull << (10 + (wd >> 3));
+                window += (window >> 3) * (wd & 7);
+            }
+            uint32_t did = 0;
+            for (uint32_t i = 0; i < did_bytes; i++) did |= (uint32_t)src[pos + i] << (8 * i);
+            pos += did_bytes;
+            if (did != 0) err = ZARC_FRAME_UNSUPPORTED;
+            for (uint32_t i = 0; i < fcs_bytes; i++) fcs |= (uint64_t)src[pos + i] << (8 * i);
+            if (fcs_bytes == 2) fcs += 256;
+            pos += fcs_bytes;
+            have_fcs = fcs_bytes != 0;
+            if (ss) window = fcs;
+            if (have_fcs && fcs != cap) err = ZARC_FRAME_SRCSIZE;
+        }
+    }
+    err = (int)zd::uniform((uint32_t)err);
+
+    uint64_t opos = 0;          // bytes produced
+    uint32_t rep0 = 1, rep1 = 4, rep2 = 8;
+    bool last = false;
+    while (!err && !last) {
+        if (pos + 3 > slen) { err = ZARC_FRAME_SRCSIZE; break; }
+        const uint32_t bh = zd::uniform((uint32_t)src[pos] | ((uint32_t)src[pos + 1] << 8) | ((uint32_t)src[pos + 2] << 16));
+        pos += 3;
+        last = bh & 1;
+        const uint32_t btype = (bh >> 1) & 3, bsize = bh >> 3;
+        if (btype == 3 || bsize > BLOCK_MAX) { err = ZARC_FRAME_CORRUPT; break; }
+        if (btype == 0) { // raw
+            if (pos + bsize > slen) { err = ZARC_FRAME_SRCSIZE; break; }
+            if (opos + bsize > cap) { err = ZARC_FRAME_DSTSIZE; break; }
+            wave_copy(out + opos, src + pos, bsize, lane);
+            opos += bsize;
+            pos += bsize;
+            zd::wave_sync_global(); // later blocks may copy from these bytes
+            continue;
+        }
+        if (btype == 1) { // RLE
+            if (pos + 1 > slen) { err = ZARC_FRAME_SRCSIZE; break; }
+            if (opos + bsize > cap) { err = ZARC_FRAME_DSTSIZE; break; }
+            const uint8_t v = src[pos];
+            for (uint32_t i = (uint32_t)lane; i < bsize; i += 64) out[opos + i] = v;
+            opos += bsize;
+            pos += 1;
+            zd::wave_sync_global();
+            continue;
+        }
+        // ---- compressed block ----
+        if (pos + bsize > slen) { err = ZARC_FRAME_SRCSIZE; break; }
+        const uint8_t *bp = src + pos;
+        const uint32_t blen = bsize;
+        pos += bsize;
+        if (blen < 2) { err = ZARC_FRAME_CORRUPT; break; }
+        // literals section
+        const uint32_t b0 = bp[0];
+        const uint32_t ltype = b0 & 3, sf = (b0 >> 2) & 3;
+        const uint8_t *lit = lit_buf; // where the literal bytes live
+        uint32_t lit_len = 0, lused = 0;
+        bool lit_rle = false;
+        uint8_t lit_rle_byte = 0;
+        if (ltype < 2) {
+            uint32_t hdr;
+            if (sf == 0 || sf == 2) { lit_len = b0 >> 3; hdr = 1; }
+            else if (sf == 1) { lit_len = (b0 >> 4) | ((uint32_t)bp[1] << 4); hdr = 2; }
+            else { if (blen < 3) { err = ZARC_FRAME_CORRUPT; break; } lit_len = (b0 >> 4) | ((uint32_t)bp[1] << 4) | ((uint32_t)bp[2] << 12); hdr = 3; }
+            if (lit_len > BLOCK_MAX) { err = ZARC_FRAME_CORRUPT; break; }
+            if (ltype == 0) {
+                if (hdr + lit_len > blen) { err = ZARC_FRAME_CORRUPT; break; }
+                lit = bp + hdr; // used in place
+                lused = hdr + lit_len;
+            } else {
+                if (hdr + 1 > blen) { err = ZARC_FRAME_CORRUPT; break; }
+                lit_rle = true;
+                lit_rle_byte = bp[hdr];
+                lused = hdr + 1;
+            }
+        } else {
+            uint32_t hdr, comp, streams;
+            if (blen < 5 && !(sf <= 1 && blen >= 3)) { err = ZARC_FRAME_CORRUPT; break; }
+            if (sf <= 1) {
+                const uint32_t v = b0 | ((uint32_t)bp[1] << 8) | ((uint32_t)bp[2] << 16);
+                lit_len = (v >> 4) & 0x3FF; comp = (v >> 14) & 0x3FF; hdr = 3; streams = sf == 0 ? 1 : 4;
+            } else if (sf == 2) {
+                const uint32_t v = b0 | ((uint32_t)bp[1] << 8) | ((uint32_t)bp[2] << 16) | ((uint32_t)bp[3] << 24);
+                lit_len = (v >> 4) & 0x3FFF; comp = (v >> 18) & 0x3FFF; hdr = 4; streams = 4;
+            } else {
+                const uint64_t v = (uint64_t)b0 | ((uint64_t)bp[1] << 8) | ((uint64_t)bp[2] << 16) | ((uint64_t)bp[3] << 24) | ((uint64_t)bp[4] << 32);
+                lit_len = (uint32_t)(v >> 4) & 0x3FFFF; comp = (uint32_t)(v >> 22) & 0x3FFFF; hdr = 5; streams = 4;
+            }
+            if (lit_len > BLOCK_MAX || hdr + comp > blen) { err = ZARC_FRAME_CORRUPT; break; }
+            const uint8_t *hp = bp + hdr;
+            uint32_t rem = comp;
+            if (ltype == 2) {
+                int nw = 0;
+                const int used = huf_read_weights(L, hp, rem, lane, &nw);
+                if (used < 0 || !huf_build_table(L, nw, lane)) { err = ZARC_FRAME_CORRUPT; break; }
+                hp += used;
+                rem -= (uint32_t)used;
+            } else if (!L.ctrl[C_HUF_VALID]) { err = ZARC_FRAME_CORRUPT; break; }
+            const int max_bits = L.ctrl[C_HUF_BITS];
+            bool ok = true;
+            if (streams == 1) {
+                if (lane == 0) ok = huf_decode_stream(L, max_bits, hp, rem, lit_buf, lit_len);
+            } else {
+                if (rem < 6) { err = ZARC_FRAME_CORRUPT; break; }
+                const uint32_t s1 = hp[0] | ((uint32_t)hp[1] << 8), s2 = hp[2] | ((uint32_t)hp[3] << 8), s3 = hp[4] | ((uint32_t)hp[5] << 8);
+                const uint32_t per = (lit_len + 3) / 4;
+                if (6 + s1 + s2 + s3 > rem || per * 3 > lit_len) { err = ZARC_FRAME_CORRUPT; break; }
+                const uint32_t s4 = rem - 6 - s1 - s2 - s3;
+                if (lane < 4) {
+                    const uint32_t so = lane == 0 ? 0 : (lane == 1 ? s1 : (lane == 2 ? s1 + s2 : s1 + s2 + s3));
+                    const uint32_t sl = lane == 0 ? s1 : (lane == 1 ? s2 : (lane == 2 ? s3 : s4));
+                    const uint32_t cntl = lane < 3 ? per : lit_len - 3 * per;
+                    ok = huf_decode_stream(L, max_bits, hp + 6 + so, sl, lit_buf + (uint32_t)lane * per, cntl);
+                }
+            }
+            if (zd::ballot(!ok) != 0) { err = ZARC_FRAME_CORRUPT; break; }
+            zd::wave_sync_global(); // literal bytes written by lanes 0..3 are read by every lane below
+            lused = hdr + comp;
+        }
+        // sequences section
+        const uint8_t *sp = bp + lused;
+        uint32_t srem = blen - lused;
+        if (srem < 1) { err = ZARC_FRAME_CORRUPT; break; }
+        uint32_t nseq;
+        if (sp[0] < 128) { nseq = sp[0]; sp += 1; srem -= 1; }
+        else if (sp[0] < 255) { if (srem < 2) { err = ZARC_FRAME_CORRUPT; break; } nseq = ((uint32_t)(sp[0] - 128) << 8) + sp[1]; sp += 2; srem -= 2; }
+        else { if (srem < 3) { err = ZARC_FRAME_CORRUPT; break; } nseq = (uint32_t)sp[1] + ((uint32_t)sp[2] << 8) + 0x7F00; sp += 3; srem -= 3; }
+        nseq = zd::uniform(nseq);
+        const uint64_t block_start = opos;
+        uint32_t lp = 0; // literals consumed
+        if (nseq > 0) {
+            if (srem < 1) { err = ZARC_FRAME_CORRUPT; break; }
+            const uint32_t modes = sp[0];
+            sp++; srem--;
+            if (modes & 3) { err = ZARC_FRAME_CORRUPT; break; }
+            int r = seq_table(L, L.ll, C_LL_AL, C_LL_OK, (int)(modes >> 6), sp, srem, D_LL_DEFAULT, 36, 6, 9, 35, lane);
+            if (r < 0) { err = ZARC_FRAME_CORRUPT; break; }
+            sp += r; srem -= (uint32_t)r;
+            r = seq_table(L, L.of, C_OF_AL, C_OF_OK, (int)((modes >> 4) & 3), sp, srem, D_OF_DEFAULT, 29, 5, 8, 31, lane);
+            if (r < 0) { err = ZARC_FRAME_CORRUPT; break; }
+            sp += r; srem -= (uint32_t)r;
+            r = seq_table(L, L.ml, C_ML_AL, C_ML_OK, (int)((modes >> 2) & 3), sp, srem, D_ML_DEFAULT, 53, 6, 9, 52, lane);
+            if (r < 0) { err = ZARC_FRAME_CORRUPT; break; }
+            sp += r; srem -= (uint32_t)r;
+            const int al_l = L.ctrl[C_LL_AL], al_o = L.ctrl[C_OF_AL], al_m = L.ctrl[C_ML_AL];
+            // lane 0 owns the bitstream and the FSE states
+            BackBits b;
+            uint32_t sl = 0, so = 0, sm = 0;
+            bool okb = true;
+            if (lane == 0) {
+                okb = b.init(sp, srem);
+                if (okb) { sl = b.read(al_l); so = b.read(al_o); sm = b.read(al_m); okb = b.bitpos >= 0; }
+            }
+            if (zd::ballot(!okb) != 0) { err = ZARC_FRAME_CORRUPT; break; }
+            uint64_t fenced = opos; // output bytes below this are known visible to every lane
+            for (uint32_t base = 0; base < nseq && !err; base += SEQ_BATCH) {
+                const uint32_t cnt = nseq - base < SEQ_BATCH ? nseq - base : SEQ_BATCH;
+                if (lane == 0) {
+                    for (uint32_t i = 0; i < cnt; i++) {
+                        const uint32_t cl = L.ll[sl], co = L.of[so], cm = L.ml[sm];
+                        const uint32_t ofc = cell_sym(co), mlc = cell_sym(cm), llc = cell_sym(cl);
+                        if (ofc > 31 || mlc > 52 || llc > 35) { okb = false; break; }
+                        const uint32_t ofv = (1u << ofc) + b.read((int)ofc);
+                        const uint32_t ml = D_ML_BASE[mlc] + b.read(D_ML_BITS[mlc]);
+                        const uint32_t ll = D_LL_BASE[llc] + b.read(D_LL_BITS[llc]);
+                        uint32_t offset;
+                        if (ofv > 3) { offset = ofv - 3; rep2 = rep1; rep1 = rep0; rep0 = offset; }
+                        else {
+                            const uint32_t idx = ofv - 1 + (ll == 0 ? 1u : 0u);
+                            if (idx == 0) offset = rep0;
+                            else {
+                                offset = idx == 3 ? rep0 - 1 : (idx == 1 ? rep1 : rep2);
+                                if (offset == 0) { okb = false; break; }
+                                if (idx > 1) rep2 = rep1;
+                                rep1 = rep0;
+                                rep0 = offset;
+                            }
+                        }
+                        L.seq[i * 3] = ll; L.seq[i * 3 + 1] = ml; L.seq[i * 3 + 2] = offset;
+                        if (base + i + 1 < nseq) {
+                            sl = cell_base(cl) + b.read((int)cell_nbits(cl));
+                            sm = cell_base(cm) + b.read((int)cell_nbits(cm));
+                            so = cell_base(co) + b.read((int)cell_nbits(co));
+                        }
+                        if (b.bitpos < 0) { okb = false; break; }
+                    }
+                }
+                zd::wave_sync();
+                if (zd::ballot(!okb) != 0) { err = ZARC_FRAME_CORRUPT; break; }
+                for (uint32_t i = 0; i < cnt; i++) {
+                    const uint32_t ll = L.seq[i * 3], ml = L.seq[i * 3 + 1], offset = L.seq[i * 3 + 2];
+                    if (lp + ll > lit_len) { err = ZARC_FRAME_CORRUPT; break; }
+                    if (opos + ll + ml > cap) { err = ZARC_FRAME_DSTSIZE; break; }
+                    if (lit_rle) { for (uint32_t k = (uint32_t)lane; k < ll; k += 64) out[opos + k] = lit_rle_byte; }
+                    else wave_copy(out + opos, lit + lp, ll, lane);
+                    lp += ll;
+                    opos += ll;
+                    if (offset > opos) { err = ZARC_FRAME_CORRUPT; break; }
+                    const uint64_t mstart = opos - offset;
+                    const uint64_t send = mstart + ml < opos ? mstart + ml : opos;
+                    if (send > fenced) { zd::wave_sync_global(); fenced = opos; }
+                    // all reads come from below the match start: byte i <- source[i mod offset]
+                    for (uint32_t k = (uint32_t)lane; k < ml; k += 64) {
+                        uint32_t j = k;
+                        if (j >= offset) j = j % offset;
+                        out[opos + k] = out[mstart + j];
+                    }
+                    opos += ml;
+                }
+                zd::wave_sync(); // L.seq is rewritten by lane 0 in the next batch
+            }
+            if (err) break;
+            bool endok = true;
+            if (lane == 0) endok = b.bitpos == 0;
+            if (zd::ballot(!endok) != 0) { err = ZARC_FRAME_CORRUPT; break; }
+        } else if (srem != 0) { err = ZARC_FRAME_CORRUPT; break; }
+        // trailing literals
+        {
+            const uint32_t tail = lit_len - lp;
+            if (opos + tail > cap) { err = ZARC_FRAME_DSTSIZE; break; }
+            if (lit_rle) { for (uint32_t k = (uint32_t)lane; k < tail; k += 64) out[opos + k] = lit_rle_byte; }
+            else wave_copy(out + opos, lit + lp, tail, lane);
+            opos += tail;
+        }
+        if (opos - block_start > BLOCK_MAX) { err = ZARC_FRAME_CORRUPT; break; }
+        zd::wave_sync_global(); // the next block may reference anything written so far; lit_buf is reused
+    }
+    if (!err && opos != cap) err = ZARC_FRAME_SRCSIZE;
+    uint32_t ck = 0;
+    if (!err && has_ck) {
+        if (pos + 4 > slen) err = ZARC_FRAME_SRCSIZE;
+        else { ck = (uint32_t)src[pos] | ((uint32_t)src[pos + 1] << 8) | ((uint32_t)src[pos + 2] << 16) | ((uint32_t)src[pos + 3] << 24); pos += 4; }
+    }
+    if (!err && pos != slen) err = ZARC_FRAME_SRCSIZE;
+    if (lane == 0) {
+        status[f] = err;
+        stored_checksum[2 * f] = has_ck;
+        stored_checksum[2 * f + 1] = ck;
+    }
+}
