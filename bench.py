@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the content engine (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+metric  : uncompressed GiB/s of `zarc pack` at zstd level 3 (BLAKE3 + frame encode + XXH64), inputs resident in
+          HBM; the same line carries the unpack rate, the compression ratio and the ratio vs libzstd -3.
+workload: BASELINE.json configs[1]/[2] -- 10 000 x 1 MiB synthetic entries per GPU (kinds text / records / lz /
+          random round-robin); `--entries` scales it down for quick runs.
+step    : one pack pass over the whole batch (timed region 1), and one unpack pass over its output (region 2).
+scaling : weak -- every rank packs its own `entries` entries (corpus indices rank*entries ...), no collective
+          on the data path; only the timing barrier / max-over-ranks uses torch.distributed (RCCL).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GIB = float(1 << 30)
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def shard_indices(rank, entries):
+    """Weak scaling: rank r owns corpus entries [r*entries, (r+1)*entries)."""
+    return rank * entries
+
+
+def aggregate(local_seconds, local_units, dist=None, device=None):
+    """Max time over ranks, sum of units over ranks (value = units / max time)."""
+    if dist is None:
+        return local_seconds, local_units
+    import torch
+    t = torch.tensor([local_seconds], dtype=torch.float64, device=device)
+    u = torch.tensor([float(local_units)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(u, op=dist.ReduceOp.SUM)
+    return float(t.item()), float(u.item())
+
+
+def cpu_baseline(entries_sample, size, first_index):
+    """The reference's CPU path on this box's host cores, bounded sample: libzstd (dlopen) ZSTD_compress2 with
+    checksumFlag=1 at level 3 after session reset (content_frame.rs:37-41, pack.rs:227) + BLAKE3 (oracle port;
+    the blake3 crate's SIMD is faster).  Single thread, like the reference."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "support"))
+    import harness
+    corpus, oracle = harness.Corpus(), harness.Oracle()
+    zs = harness.libzstds()
+    z = next((x for x in zs if x.version.startswith("1.5")), None) or (zs[0] if zs else None)
+    raws = [corpus.entry(first_index + i, size, -1) for i in range(entries_sample)]
+    t0 = time.perf_counter()
+    comp = 0
+    frames = []
+    for r in raws:
+        oracle.blake3(r)
+        f = z.compress(r, 3, 1) if z else oracle.zge_encode(r)
+        frames.append(f)
+        comp += len(f)
+    t_pack = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for r, f in zip(raws, frames):
+        if z:
+            out, _ = z.decompress(f, len(r))
+        else:
+            _, out, _ = oracle.zstd_decode(f, len(r))
+        oracle.blake3(out)
+    t_unpack = time.perf_counter() - t0
+    total = float(entries_sample * size)
+    return {"value": total / t_pack / GIB, "unit": "GiB/s", "cores": 1, "kind": "port",
+            "unpack_value": total / t_unpack / GIB,
+            "sample": "%d x %d B entries (corpus %d..), libzstd %s via dlopen + oracle BLAKE3, 1 thread"
+                      % (entries_sample, size, first_index, z.version if z else "absent->oracle model"),
+            "ratio": total / comp}, comp
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--entries", type=int, default=10000, help="entries per GPU (BASELINE configs[1]: 10000)")
+    ap.add_argument("--size", type=int, default=1 << 20, help="bytes per entry (BASELINE configs[1]: 1 MiB)")
+    ap.add_argument("--cpu-sample", type=int, default=48, help="entries timed on the host for cpu_baseline (rank 0, N=1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        torch.cuda.set_device(local_rank)
+        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist = dist_mod
+    device = torch.device("cuda", local_rank)
+
+    from zarc_amd import Engine, _lib
+    eng = Engine(local_rank)
+    eng.set_parameter(_lib.P_COMPRESSION_LEVEL, 3)
+    eng.set_parameter(_lib.P_CHECKSUM_FLAG, 1)  # crates/zarc-cli/src/pack.rs:227
+
+    n, size = args.entries, args.size
+    stride = (size + 15) // 16 * 16
+    off = np.arange(n, dtype=np.uint64) * np.uint64(stride)
+    lens = np.full(n, size, dtype=np.uint64)
+    cap = int(eng.bound(size)) * n
+    d_src = eng.malloc(n * stride + _lib.PAD)
+    d_dst = eng.malloc(cap + _lib.PAD)
+    d_out = eng.malloc(n * stride + _lib.PAD)
+    first = shard_indices(rank, n)
+    eng.corpus_fill(d_src, off, lens, first_index=first, kind=-1)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    # ---------------- pack ----------------
+    for _ in range(args.warmup):
+        doff, dlen, dig, st = eng.pack_device(d_src, off, lens, d_dst, cap)
+    barrier()
+    t0 = time.perf_counter()
+    k_ms = np.zeros(_lib.T_TOTAL + 1)
+    for _ in range(args.steps):
+        doff, dlen, dig, st = eng.pack_device(d_src, off, lens, d_dst, cap)   # synchronous at the ABI
+        k_ms += np.array([eng.kernel_ms(i) for i in range(_lib.T_TOTAL + 1)])
+    barrier()
+    t_pack = time.perf_counter() - t0
+    assert (st == 0).all()
+    k_ms /= max(args.steps, 1)
+    raw_bytes = float(lens.sum())
+    comp_bytes = float(dlen.sum())
+
+    # ---------------- unpack ----------------
+    for _ in range(args.warmup):
+        dig2, st2 = eng.unpack_device(d_dst, doff, dlen, d_out, off, lens, expect=dig)
+    barrier()
+    t0 = time.perf_counter()
+    u_ms = np.zeros(_lib.T_TOTAL + 1)
+    for _ in range(args.steps):
+        dig2, st2 = eng.unpack_device(d_dst, doff, dlen, d_out, off, lens, expect=dig)
+        u_ms += np.array([eng.kernel_ms(i) for i in range(_lib.T_TOTAL + 1)])
+    barrier()
+    t_unpack = time.perf_counter() - t0
+    u_ms /= max(args.steps, 1)
+    ok = bool((st2 == 0).all() and (dig2 == dig).all())      # bit-exact round trip: same BLAKE3 on both sides
+
+    tp, units = aggregate(t_pack, raw_bytes * args.steps, dist, device)
+    tu, _ = aggregate(t_unpack, raw_bytes * args.steps, dist, device)
+    pack_gibs = units / tp / GIB
+    unpack_gibs = units / tu / GIB
+
+    if rank == 0:
+        # roofline of the dominant kernel of the headline (pack) path: the match finder.  Algorithmic bytes per
+        # frame = N + C + 32; duration from HIP events on the engine's stream.
+        names = {_lib.T_BLAKE3: "blake3", _lib.T_XXH64: "xxh64", _lib.T_MATCH: "zge_match", _lib.T_ENTROPY: "zge_entropy",
+                 _lib.T_ASSEMBLE: "zge_assemble"}
+        dom = max(names, key=lambda i: k_ms[i])
+        alg_bytes = raw_bytes + comp_bytes + 32.0 * n
+        achieved = alg_bytes / (k_ms[dom] * 1e-3) / 1e9 if k_ms[dom] > 0 else 0.0
+        line = {
+            "metric": "uncompressed GiB/s (pack) at zstd -3", "value": round(pack_gibs, 3), "unit": "GiB/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(tp / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "zarc pack %d x %d B synthetic entries per GPU, zstd level 3, checksum on "
+                                   "(BASELINE configs[1]%s)" % (n, size, "" if (n, size) == (10000, 1 << 20) else ", scaled"),
+                       "entries_per_gpu": n, "entry_bytes": size, "kinds": "text/records/lz/random round-robin", "parallelism": "frames sharded by index, no collective"},
+            "unpack_gibs": round(unpack_gibs, 3), "unpack_ms_per_step": round(tu / args.steps * 1e3, 3),
+            "roundtrip_bit_exact": ok,
+            "ratio": round(raw_bytes / comp_bytes, 4),
+            "kernel_ms": {names[i]: round(float(k_ms[i]), 3) for i in names},
+            "unpack_kernel_ms": {"zstd_decode": round(float(u_ms[_lib.T_DECODE]), 3), "xxh64": round(float(u_ms[_lib.T_XXH64]), 3),
+                                 "blake3": round(float(u_ms[_lib.T_BLAKE3]), 3)},
+            "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(float(k_ms[dom]), 3)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            sample = min(args.cpu_sample, n)
+            cb, ref_comp = cpu_baseline(sample, size, first)
+            ours = float(dlen[:sample].sum())
+            line["cpu_baseline"] = cb
+            line["ratio_vs_reference"] = round(ref_comp / ours, 4)   # >= 0.95 required (within 5 % of libzstd -3)
+        print(json.dumps(line))
+    for p in (d_src, d_dst, d_out):
+        eng.free(p)
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+    if not ok:
+        sys.exit(1)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,146 @@
+"""Shared parity checks: the HIP path (through the C ABI) against the oracle.  Used twice: on the CPU build of
+the same kernel sources under the HIP emulator (small inputs) and on a real MI355X (-m gpu)."""
+import hashlib
+import os
+
+import numpy as np
+
+import make_golden
+from zarc_amd import _lib
+
+
+def hash_cases(corpus, big):
+    c = [b"", b"a", b"abc", bytes(i % 251 for i in range(1023)), bytes(i % 251 for i in range(1024)),
+         bytes(i % 251 for i in range(1025)), bytes(i % 251 for i in range(2049)), bytes(i % 251 for i in range(31744)),
+         corpus.entry(0, 65536, 0), corpus.entry(3, 70001, 3), corpus.entry(1, 131072 + 17, 1)]
+    if big:
+        c += [corpus.entry(2, 1 << 20, 2), corpus.entry(5, (1 << 20) + 1, 1), corpus.entry(7, 5 * (1 << 20) + 333, 3)]
+    return c
+
+
+def check_blake3(engine, oracle, corpus, big):
+    ents = hash_cases(corpus, big)
+    got = engine.blake3(ents)
+    for e, d in zip(ents, got):
+        assert d == oracle.blake3(e), len(e)
+
+
+def check_xxh64_device(engine, oracle, corpus, big):
+    ents = hash_cases(corpus, big)
+    off, pos = [], 0
+    for e in ents:
+        off.append(pos)
+        pos += (len(e) + 15) // 16 * 16
+    d = engine.malloc(pos + _lib.PAD)
+    try:
+        for e, o in zip(ents, off):
+            if e:
+                engine.h2d(d + o, e)
+        got = engine.xxh64_device(d, off, [len(e) for e in ents])
+        for e, g in zip(ents, got):
+            assert int(g) == oracle.xxh64(e), len(e)
+    finally:
+        engine.free(d)
+
+
+def encode_cases(corpus, big):
+    import random
+    rnd = random.Random(11)
+    c = {"empty": b"", "one": b"a", "abc": b"abc" * 9, "zeros": bytes(300000), "rand": corpus.entry(3, 70000, 3),
+         "k0_1000": corpus.entry(0, 1000, 0), "k0_64k": corpus.entry(4, 65536, 0), "k1_64k": corpus.entry(5, 65536, 1),
+         "k2_64k": corpus.entry(6, 65536, 2), "k0_200k": corpus.entry(8, 200000, 0), "k1_131073": corpus.entry(9, 131073, 1),
+         "sparse": bytes(rnd.randrange(256) if i % 7 else 0 for i in range(100000)),
+         "runs": make_golden.recipe_bytes({"kind": "runs", "n": 120000, "seed": 9}, corpus),
+         "few": make_golden.recipe_bytes({"kind": "few", "n": 40000, "seed": 8}, corpus)}
+    if big:
+        for k in range(4):
+            c["k%d_1m" % k] = corpus.entry(40 + k, 1 << 20, k)
+        c["k1_2m5"] = corpus.entry(1, (5 << 20) // 2, 1)   # > 2^21: window-descriptor frame
+        c["k0_4m"] = corpus.entry(12, 4 << 20, 0)
+    return c
+
+
+def check_pack(engine, oracle, corpus, libzstds, big):
+    """Frames are bit-identical to the encoder model, valid for the oracle decoder and for real libzstd."""
+    cases = encode_cases(corpus, big)
+    names = list(cases)
+    res = engine.pack([cases[k] for k in names])
+    for k, (frame, dig) in zip(names, res):
+        raw = cases[k]
+        assert dig == oracle.blake3(raw), k
+        assert frame == oracle.zge_encode(raw), k                      # bit-exact vs the CPU model
+        rc, out, used = oracle.zstd_decode(frame, len(raw))
+        assert rc == 0 and used == len(frame) and out == raw, k       # valid Zstandard
+        for z in libzstds:
+            got, err = z.decompress(frame, len(raw))
+            assert got == raw, (k, z.version, err)
+        assert len(frame) <= engine.bound(len(raw))
+
+
+def check_unpack_golden(engine, oracle, corpus, golden_frames, limit=None):
+    """Frames made by real libzstd builds decode bit-exactly; digest + checksum verified."""
+    d, m = golden_frames
+    frames, raws, cache = [], [], {}
+    sel = m["frames"] if limit is None else [f for f in m["frames"] if f["raw_len"] <= limit]
+    for fr in sel:
+        name = fr["recipe"]
+        if name not in cache:
+            cache[name] = make_golden.recipe_bytes(m["recipes"][name], corpus)
+        frames.append(open(os.path.join(d, fr["file"]), "rb").read())
+        raws.append(cache[name])
+    res = engine.unpack(frames, [len(r) for r in raws], [oracle.blake3(r) for r in raws])
+    for fr, raw, (out, dig, st) in zip(sel, raws, res):
+        assert st == _lib.FRAME_OK, (fr["file"], st)
+        assert out == raw and dig == oracle.blake3(raw), fr["file"]
+        assert hashlib.sha256(out).hexdigest() == fr["raw_sha256"]
+
+
+def check_roundtrip(engine, oracle, corpus, big):
+    cases = encode_cases(corpus, big)
+    names = list(cases)
+    packed = engine.pack([cases[k] for k in names])
+    res = engine.unpack([p[0] for p in packed], [len(cases[k]) for k in names], [p[1] for p in packed])
+    for k, (out, dig, st) in zip(names, res):
+        assert st == _lib.FRAME_OK and out == cases[k], k
+
+
+def check_unpack_errors(engine, oracle, corpus, golden_frames):
+    """Per-frame status without aborting the batch (ok / checksum / digest / corrupt)."""
+    d, m = golden_frames
+    fr = next(f for f in m["frames"] if f["recipe"] == "text300" and f["level"] == 3 and f["checksum"] == 1 and f["libzstd"].startswith("1.5"))
+    good = open(os.path.join(d, fr["file"]), "rb").read()
+    raw = make_golden.recipe_bytes(m["recipes"]["text300"], corpus)
+    bad_ck = bytearray(good); bad_ck[-1] ^= 0x40
+    bad_magic = bytearray(good); bad_magic[0] ^= 1
+    trunc = good[:-7]
+    corrupt = bytearray(good); corrupt[12] ^= 0xFF; corrupt[13] ^= 0xFF
+    wrong_digest = bytes(32)
+    frames = [good, bytes(bad_ck), bytes(bad_magic), trunc, bytes(corrupt), good, good]
+    expect = [oracle.blake3(raw)] * 5 + [wrong_digest, oracle.blake3(raw)]
+    raw_lens = [len(raw)] * 6 + [len(raw) + 1]
+    res = engine.unpack(frames, raw_lens, expect)
+    st = [r[2] for r in res]
+    assert st[0] == _lib.FRAME_OK and res[0][0] == raw
+    assert st[1] == _lib.FRAME_CHECKSUM
+    assert st[2] == _lib.FRAME_BAD_MAGIC
+    assert st[3] != _lib.FRAME_OK
+    assert st[4] != _lib.FRAME_OK
+    assert st[5] == _lib.FRAME_DIGEST and res[5][0] == raw       # reported, bytes still delivered (unpack.rs:118-120)
+    assert st[6] == _lib.FRAME_SRCSIZE                            # Frame.uncompressed disagrees with the frame
+    # the oracle agrees on which frames are undecodable
+    for i in (2, 3, 4):
+        assert oracle.zstd_decode(frames[i], len(raw))[0] != 0
+
+
+def check_params(engine):
+    import pytest
+    from zarc_amd import ZarcGpuError
+    engine.set_parameter(_lib.P_COMPRESSION_LEVEL, 3)
+    engine.set_parameter(_lib.P_WINDOW_LOG, 0)
+    with pytest.raises(ZarcGpuError):
+        engine.set_parameter(_lib.P_COMPRESSION_LEVEL, 23)
+    with pytest.raises(ZarcGpuError):
+        engine.set_parameter(400, 4)      # NbWorkers: known to libzstd, unsupported here
+    with pytest.raises(ZarcGpuError):
+        engine.set_parameter(31337, 1)    # unknown id
+    assert engine.params().checksum_flag == 1

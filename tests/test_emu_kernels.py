@@ -1,0 +1,28 @@
+"""CPU: the real kernel sources (zarc_amd/csrc/*.hip) compiled against the HIP emulator and driven through the
+same C ABI, checked against the oracle.  Catches logic errors, divergent barriers and (with the asan target)
+out-of-bounds accesses before any GPU time is spent.  Small inputs: the emulator is slow."""
+import parity_cases as pc
+
+
+def test_emu_blake3(emu_engine, oracle, corpus):
+    pc.check_blake3(emu_engine, oracle, corpus, big=False)
+
+
+def test_emu_xxh64(emu_engine, oracle, corpus):
+    pc.check_xxh64_device(emu_engine, oracle, corpus, big=False)
+
+
+def test_emu_pack_bit_exact_and_valid(emu_engine, oracle, corpus, libzstds):
+    pc.check_pack(emu_engine, oracle, corpus, libzstds, big=False)
+
+
+def test_emu_unpack_libzstd_golden(emu_engine, oracle, corpus, golden_frames):
+    pc.check_unpack_golden(emu_engine, oracle, corpus, golden_frames, limit=140000)
+
+
+def test_emu_unpack_error_statuses(emu_engine, oracle, corpus, golden_frames):
+    pc.check_unpack_errors(emu_engine, oracle, corpus, golden_frames)
+
+
+def test_emu_params(emu_engine):
+    pc.check_params(emu_engine)

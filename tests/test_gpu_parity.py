@@ -1,0 +1,87 @@
+"""GPU (-m gpu): the product library on a real MI355X, through the C ABI, against the oracle."""
+import numpy as np
+import pytest
+
+import parity_cases as pc
+from zarc_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def test_gpu_blake3(engine, oracle, corpus):
+    pc.check_blake3(engine, oracle, corpus, big=True)
+
+
+def test_gpu_xxh64(engine, oracle, corpus):
+    pc.check_xxh64_device(engine, oracle, corpus, big=True)
+
+
+def test_gpu_pack_bit_exact_and_valid(engine, oracle, corpus, libzstds):
+    pc.check_pack(engine, oracle, corpus, libzstds, big=True)
+
+
+def test_gpu_unpack_libzstd_golden(engine, oracle, corpus, golden_frames):
+    pc.check_unpack_golden(engine, oracle, corpus, golden_frames)
+
+
+def test_gpu_unpack_live_libzstd(engine, oracle, corpus, libzstds):
+    if not libzstds:
+        pytest.skip("no libzstd on this box")
+    raws = [corpus.entry(300 + i, (1 << 20) + i * 4099, -1) for i in range(8)]
+    for z in libzstds:
+        for lvl in (1, 3, 9):
+            res = engine.unpack([z.compress(r, lvl, 1) for r in raws], [len(r) for r in raws], [oracle.blake3(r) for r in raws])
+            for r, (out, dig, st) in zip(raws, res):
+                assert st == 0 and out == r
+
+
+def test_gpu_roundtrip(engine, oracle, corpus):
+    pc.check_roundtrip(engine, oracle, corpus, big=True)
+
+
+def test_gpu_unpack_error_statuses(engine, oracle, corpus, golden_frames):
+    pc.check_unpack_errors(engine, oracle, corpus, golden_frames)
+
+
+def test_gpu_params(engine):
+    pc.check_params(engine)
+
+
+def test_gpu_c1_config(engine, oracle, corpus):
+    # BASELINE.json configs[0]: 10 x 64 KiB random -> 10 frames of exactly 65 550 bytes
+    ents = [corpus.entry(i, 65536, 3) for i in range(10)]
+    res = engine.pack(ents)
+    assert [len(f) for f, _ in res] == [65550] * 10
+    assert len({d for _, d in res}) == 10
+
+
+def test_gpu_full_size_properties(engine, oracle, corpus):
+    """BASELINE configs[1]/[2] shape at reduced count (same 1 MiB entries, all four kinds): device-resident pack
+    -> unpack round trip, digests equal on both sides, sample of entries compared byte-for-byte with the host
+    generator, checksum-of-digests equal to the oracle's on a sample."""
+    n, size = 256, 1 << 20
+    off = np.arange(n, dtype=np.uint64) * size
+    lens = np.full(n, size, dtype=np.uint64)
+    cap = sum(engine.bound(size) for _ in range(n))
+    d_src = engine.malloc(n * size + _lib.PAD)
+    d_dst = engine.malloc(cap + _lib.PAD)
+    d_out = engine.malloc(n * size + _lib.PAD)
+    try:
+        engine.corpus_fill(d_src, off, lens, first_index=0, kind=-1)
+        doff, dlen, dig, st = engine.pack_device(d_src, off, lens, d_dst, cap)
+        assert (st == 0).all()
+        for i in (0, 1, 2, 3, 77, 255):
+            raw = corpus.entry(i, size, -1)
+            assert bytes(engine.d2h(d_src + int(off[i]), size)) == raw          # device generator == host generator
+            assert bytes(dig[i]) == oracle.blake3(raw)
+            frame = bytes(engine.d2h(d_dst + int(doff[i]), int(dlen[i])))
+            assert frame == oracle.zge_encode(raw)
+        ratio = float(lens.sum()) / float(dlen.sum())
+        assert ratio > 1.9                                                        # libzstd -3 gives ~2.0 on this mix
+        dig2, st2 = engine.unpack_device(d_dst, doff, dlen, d_out, off, lens, expect=dig)
+        assert (st2 == 0).all() and (dig2 == dig).all()
+        for i in (0, 3, 130):
+            assert bytes(engine.d2h(d_out + int(off[i]), size)) == corpus.entry(i, size, -1)
+    finally:
+        for p in (d_src, d_dst, d_out):
+            engine.free(p)

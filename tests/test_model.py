@@ -1,0 +1,44 @@
+"""CPU: the encoder model (oracle/zstd_enc_model.c) produces valid Zstandard with ratio near libzstd -3."""
+import pytest
+
+
+def _cases(corpus):
+    c = {"empty": b"", "one": b"a", "abc": b"abc" * 9, "zeros": bytes(300000)}
+    for k in range(4):
+        for n in (1000, 65536, 200000):
+            c["k%d_%d" % (k, n)] = corpus.entry(k + 4 * n, n, k)
+    c["k0_1m"] = corpus.entry(0, 1 << 20, 0)
+    c["k1_2m5"] = corpus.entry(1, (5 << 20) // 2, 1)  # > 2^21: not single-segment, window descriptor path
+    return c
+
+
+def test_model_frames_are_valid_zstandard(oracle, corpus, libzstds):
+    for name, raw in _cases(corpus).items():
+        frame = oracle.zge_encode(raw)
+        rc, out, used = oracle.zstd_decode(frame, len(raw))
+        assert rc == 0 and used == len(frame) and out == raw, name
+        for z in libzstds:  # stock zstd decodes it (README.md:52-61 acceptance criterion of the reference)
+            got, err = z.decompress(frame, len(raw))
+            assert got == raw, (name, z.version, err)
+        assert len(frame) <= oracle.lib.zge_bound(len(raw))
+
+
+def test_c1_shape_random_64k(oracle, corpus):
+    # 64 KiB random -> one raw block, exactly 65 550 bytes with checksum
+    raw = corpus.entry(3, 65536, 3)
+    frame = oracle.zge_encode(raw)
+    assert len(frame) == 65550 and frame[:4] == b"\x28\xb5\x2f\xfd" and frame[4] == 0x64
+
+
+def test_model_ratio_within_5_percent_of_libzstd_level3(oracle, corpus, libzstds):
+    z = next((z for z in libzstds if z.version.startswith("1.5")), None) or (libzstds[0] if libzstds else None)
+    if z is None:
+        pytest.skip("no libzstd on this box")
+    ours = ref = 0
+    for i in range(8):  # kinds round-robin like the bench corpus
+        raw = corpus.entry(i, 1 << 20, -1)
+        o_, r_ = len(oracle.zge_encode(raw)), len(z.compress(raw, 3, 1))
+        assert o_ <= r_ * 1.05, (i, o_, r_)
+        ours += o_
+        ref += r_
+    assert ours <= ref * 1.05
