@@ -582,7 +582,7 @@ static uint32_t match_len(const uint8_t *src, size_t p, size_t q, uint32_t limit
     return n;
 }
 
-typedef struct { uint32_t len, off; uint8_t back, is_rep; int32_t score; } cand;
+typedef struct { uint32_t len, off; uint8_t back, is_rep; } cand;
 
 static int32_t score_of(const zge_params *P, uint32_t len, uint32_t off, int is_rep)
 {
@@ -595,55 +595,59 @@ typedef struct {
     const uint8_t *src;
     size_t n;
     uint32_t *tl, *ts;       /* long / short tables: value = position+1, 0 = empty */
-    uint32_t rep[3];         /* live repeat-offset history (encoder side)            */
     size_t window;
-    cand *M;                 /* per-tile candidates                                   */
+    cand *M, *M2;            /* per-tile candidates: own best, then after backward propagation */
+    uint32_t *next;          /* per-tile successor of each position on the parse path */
+    uint8_t *take, *mark;
     zge_stats *st;
 } mf_ctx;
 
-/* emit one sequence: resolves the offset against the live repcode history */
-static void emit_seq(mf_ctx *c, zge_seq *out, uint32_t ll, uint32_t ml, uint32_t off)
+/* Resolve explicit offsets against the repcode history (RFC 8878 3.1.1.5).  The history starts UNKNOWN
+ * (0 never equals a real offset) in every block: whether the previous block ends up raw/RLE -- which leaves the
+ * decoder's history untouched -- is only known after entropy coding, and blocks are coded independently.
+ * The cost is at most 3 repcodes per block.  In the engine this pass runs at the start of the entropy stage. */
+static void resolve_repcodes(zge_seq *seq, uint32_t nseq, zge_stats *st)
 {
-    uint32_t *r = c->rep, ofv;
-    if (ll > 0) {
-        if (off == r[0]) ofv = 1;
-        else if (off == r[1]) { ofv = 2; r[1] = r[0]; r[0] = off; }
-        else if (off == r[2]) { ofv = 3; r[2] = r[1]; r[1] = r[0]; r[0] = off; }
-        else { ofv = off + 3; r[2] = r[1]; r[1] = r[0]; r[0] = off; }
-    } else {
-        if (off == r[1]) { ofv = 1; r[1] = r[0]; r[0] = off; }
-        else if (off == r[2]) { ofv = 2; r[2] = r[1]; r[1] = r[0]; r[0] = off; }
-        else if (r[0] > 1 && off == r[0] - 1) { ofv = 3; r[2] = r[1]; r[1] = r[0]; r[0] = off; }
-        else { ofv = off + 3; r[2] = r[1]; r[1] = r[0]; r[0] = off; }
+    uint32_t r[3] = {0, 0, 0}, i;
+    for (i = 0; i < nseq; i++) {
+        uint32_t off = seq[i].off, ofv;
+        if (seq[i].ll > 0) {
+            if (off == r[0]) ofv = 1;
+            else if (off == r[1]) { ofv = 2; r[1] = r[0]; r[0] = off; }
+            else if (off == r[2]) { ofv = 3; r[2] = r[1]; r[1] = r[0]; r[0] = off; }
+            else { ofv = off + 3; r[2] = r[1]; r[1] = r[0]; r[0] = off; }
+        } else {
+            if (off == r[1]) { ofv = 1; r[1] = r[0]; r[0] = off; }
+            else if (off == r[2]) { ofv = 2; r[2] = r[1]; r[1] = r[0]; r[0] = off; }
+            else if (r[0] > 1 && off == r[0] - 1) { ofv = 3; r[2] = r[1]; r[1] = r[0]; r[0] = off; }
+            else { ofv = off + 3; r[2] = r[1]; r[1] = r[0]; r[0] = off; }
+        }
+        seq[i].ofv = ofv;
+        if (st) { if (ofv <= 3) st->rep_seqs++; st->seqs++; st->match_bytes += seq[i].ml; }
     }
-    out->ll = ll; out->ml = ml; out->off = off; out->ofv = ofv;
-    if (c->st) { if (ofv <= 3) c->st->rep_seqs++; c->st->seqs++; c->st->match_bytes += ml; }
 }
 
-/* Process one block [bs, be): fills seq[], lit[]; returns nseq, *nlit. */
+/* Process one block [bs, be): fills seq[] (ll, ml, off) and lit[]; returns nseq, *nlit.
+ * Every step below is a data-parallel operation over the positions of a 1024-position tile, except the
+ * ordered table update (64 positions at a time) and the tile-to-tile carry of the parse cursor. */
 static uint32_t matchfind_block(mf_ctx *c, size_t bs, size_t be, zge_seq *seq, uint8_t *lit, size_t *nlit)
 {
     const zge_params *P = c->P;
     const uint8_t *src = c->src;
-    size_t anchor = bs, pos = bs, tile, lp = 0;
-    uint32_t nseq = 0;
-    /* Every block starts with an UNKNOWN repcode history (0 never equals a real offset): whether the
-     * previous block ends up raw/RLE (which leaves the decoder's history untouched) is only known after
-     * entropy coding, and the match finder must not depend on that.  Offsets are sent explicitly until
-     * the history has been re-established inside the block; the cost is at most 3 repcodes per block. */
-    c->rep[0] = c->rep[1] = c->rep[2] = 0;
+    size_t pos = bs, tile, lp = 0, prev_lp = 0;
+    uint32_t nseq = 0, erep0 = 0, erep1 = 0, i;
     /* positions with fewer than 8 readable bytes are never hashed */
     size_t hash_end = c->n >= 8 ? c->n - 7 : 0; /* p < hash_end is hashable */
     for (tile = bs; tile < be; tile += (size_t)P->tile) {
         size_t tend = tile + (size_t)P->tile < be ? tile + (size_t)P->tile : be, p, sub;
-        uint32_t rep0 = c->rep[0], rep1 = c->rep[1];
-        if (pos >= tend) continue; /* whole tile already covered by a match: skip it */
-        /* stage A: ordered lookup + insert, in sub-tiles (lookups of a sub-tile see inserts of earlier ones) */
+        uint32_t tcount = (uint32_t)(tend - tile), t;
+        if (pos >= tend) continue; /* whole tile already covered by a match: skip it (nothing is inserted) */
+        /* S2: ordered lookup + insert, 64 positions at a time (lookups of a group see inserts of earlier groups) */
         for (sub = tile; sub < tend; sub += (size_t)P->sub) {
             size_t send = sub + (size_t)P->sub < tend ? sub + (size_t)P->sub : tend;
             for (p = sub; p < send; p++) {
                 cand *m = &c->M[p - tile];
-                m->len = 0; m->off = 0; m->back = 0; m->is_rep = 0; m->score = -1000000;
+                m->len = 0; m->off = 0; m->back = 0; m->is_rep = 0;
                 if (p < hash_end) {
                     uint64_t v = rd64(src + p);
                     m->off = c->tl[hash_long(v, P->long_log)];            /* stash candidates */
@@ -656,89 +660,89 @@ static uint32_t matchfind_block(mf_ctx *c, size_t bs, size_t be, zge_seq *seq, u
                 c->ts[hash_short(v, P->short_log, P->short_bytes)] = (uint32_t)p + 1;
             }
         }
-        /* stage B: evaluate candidates (independent per position) */
+        /* S3: every position scores its own candidates {long, short, guess0, guess1} */
         for (p = tile; p < tend; p++) {
             cand *m = &c->M[p - tile];
-            uint32_t cl = m->off, cs = m->len, limit = (uint32_t)(be - p), cap = limit < (uint32_t)P->cap ? limit : (uint32_t)P->cap;
+            uint32_t limit = (uint32_t)(be - p), cap = limit < (uint32_t)P->cap ? limit : (uint32_t)P->cap;
             uint32_t best_len = 0, best_off = 0; int best_rep = 0; int32_t best_score = -1000000;
-            uint32_t k, cands[2];
+            uint32_t k, offs[4];
+            offs[0] = m->off ? (uint32_t)p - (m->off - 1) : 0;
+            offs[1] = (m->len && m->len != m->off) ? (uint32_t)p - (m->len - 1) : 0;
+            if (offs[1] > ((uint32_t)1 << P->short_window_log)) offs[1] = 0;
+            offs[2] = P->rep_search > 0 ? erep0 : 0;
+            offs[3] = (P->rep_search > 1 && erep1 != erep0) ? erep1 : 0;
             m->len = 0; m->off = 0;
-            cands[0] = cl; cands[1] = cs;
-            for (k = 0; k < 2; k++) {
-                uint32_t q1 = cands[k], off, len; int32_t sc;
-                if (!q1) continue;
-                off = (uint32_t)p - (q1 - 1);
-                if (off == 0 || off > c->window) continue;
-                if (k == 1 && (cands[0] == cands[1] || off > ((uint32_t)1 << P->short_window_log))) continue;
+            for (k = 0; k < 4; k++) {
+                uint32_t off = offs[k], len; int is_rep; int32_t sc;
+                if (off == 0 || off > p || off > c->window) continue;
+                is_rep = off == erep0 || off == erep1;
                 len = match_len(src, p, p - off, cap);
-                if (len < (uint32_t)P->min_match) continue;
-                sc = score_of(P, len, off, 0);
-                if (sc > best_score) { best_score = sc; best_len = len; best_off = off; best_rep = 0; }
-            }
-            if (P->rep_search) {
-                uint32_t reps[2]; reps[0] = rep0; reps[1] = rep1;
-                for (k = 0; k < (uint32_t)P->rep_search; k++) {
-                    uint32_t off = reps[k], len; int32_t sc;
-                    if (off == 0 || off > p || off > c->window) continue;
-                    len = match_len(src, p, p - off, cap);
-                    if (len < (uint32_t)P->min_rep) continue;
-                    sc = score_of(P, len, off, 1);
-                    if (sc > best_score) { best_score = sc; best_len = len; best_off = off; best_rep = 1; }
-                }
+                if (len < (uint32_t)(is_rep ? P->min_rep : P->min_match)) continue;
+                sc = score_of(P, len, off, is_rep);
+                if (sc > best_score) { best_score = sc; best_len = len; best_off = off; best_rep = is_rep; }
             }
             if (best_len && best_score > 0) {
                 uint32_t back = 0;
-                m->len = best_len; m->off = best_off; m->is_rep = (uint8_t)best_rep; m->score = best_score;
-                /* backward extension potential (at most back_cap bytes) */
+                m->len = best_len; m->off = best_off; m->is_rep = (uint8_t)best_rep;
+                /* backward extension potential: equal bytes just before the match and its source */
                 while (back < (uint32_t)P->back_cap && p - back > bs && p - back > best_off &&
                        src[p - back - 1] == src[p - back - 1 - best_off]) back++;
                 m->back = (uint8_t)back;
             }
         }
-        /* stage C: serial selection over the tile, in chunks of 64 positions */
-        {
-            size_t chunk;
-            for (chunk = tile; chunk < tend; chunk += 64) {
-                size_t cend = chunk + 64 < tend ? chunk + 64 : tend;
-                p = pos > chunk ? pos : chunk;
-                while (p < cend) {
-                    cand *m = &c->M[p - tile];
-                    uint32_t len, off, back, ll;
-                    size_t q;
-                    if (m->len == 0) { p++; continue; }
-                    /* lazy: a better match starting one byte later inside the same chunk wins */
-                    if (P->lazy && p + 1 < cend) {
-                        cand *m2 = &c->M[p + 1 - tile];
-                        if (m2->len && m2->score > m->score + P->lazy_delta) { p++; continue; }
-                    }
-                    len = m->len; off = m->off; q = p;
-                    if (len == (uint32_t)P->cap) { /* forward extension of a capped match */
-                        uint32_t limit = (uint32_t)(be - q);
-                        len = match_len(src, q, q - off, limit);
-                    }
-                    /* backward extension is confined to pending literals of the current 64-position chunk
-                     * (literals of earlier chunks have already been emitted) */
-                    back = m->back;
-                    {
-                        size_t floor_ = anchor > chunk ? anchor : chunk;
-                        if (back > q - floor_) back = (uint32_t)(q - floor_);
-                    }
-                    q -= back; len += back;
-                    ll = (uint32_t)(q - anchor);
-                    memcpy(lit + lp, src + anchor, ll);
-                    lp += ll;
-                    emit_seq(c, &seq[nseq++], ll, len, off);
-                    anchor = q + len;
-                    p = anchor;
-                }
-                if (p > pos) pos = p;
+        /* S4: backward propagation -- position t may start the match of t+k, k bytes earlier */
+        for (t = 0; t < tcount; t++) {
+            cand best = c->M[t];
+            int32_t best_score = best.len ? score_of(P, best.len, best.off, best.is_rep) : 0;
+            uint32_t k;
+            for (k = 1; k <= (uint32_t)P->back_cap && t + k < tcount; k++) {
+                const cand *nb = &c->M[t + k];
+                int32_t sc;
+                if (!nb->len || nb->back < k) continue;
+                sc = score_of(P, nb->len + k, nb->off, nb->is_rep);
+                if (sc > best_score) { best_score = sc; best.len = nb->len + k; best.off = nb->off; best.is_rep = nb->is_rep; }
             }
+            best.back = 0;
+            c->M2[t] = best;
+        }
+        /* S5: take flags (one-byte lazy lookahead inside the tile) and successors */
+        for (t = 0; t < tcount; t++) {
+            const cand *m = &c->M2[t];
+            int tk = m->len != 0;
+            if (tk && P->lazy && t + 1 < tcount && c->M2[t + 1].len) {
+                const cand *m2 = &c->M2[t + 1];
+                if (score_of(P, m2->len, m2->off, m2->is_rep) > score_of(P, m->len, m->off, m->is_rep) + P->lazy_delta) tk = 0;
+            }
+            c->take[t] = (uint8_t)tk;
+            c->next[t] = tk ? t + m->len : t + 1;
+            c->mark[t] = 0;
+        }
+        /* S6: the parse path from the entry cursor (pointer doubling in the kernel) */
+        t = (uint32_t)((pos > tile ? pos : tile) - tile);
+        while (t < tcount) { c->mark[t] = 1; t = c->next[t]; }
+        pos = tile + t;
+        /* S7: emission in position order (prefix sums in the kernel) */
+        {
+            uint32_t last0 = 0, last1 = 0, nsel = 0;
+            for (t = 0; t < tcount; t++) {
+                if (!c->mark[t]) continue;
+                if (c->take[t]) {
+                    seq[nseq].ll = (uint32_t)(lp - prev_lp); seq[nseq].ml = c->M2[t].len; seq[nseq].off = c->M2[t].off; seq[nseq].ofv = 0;
+                    prev_lp = lp;
+                    nseq++;
+                    last1 = last0; last0 = c->M2[t].off; nsel++;
+                } else {
+                    lit[lp++] = src[tile + t];
+                }
+            }
+            /* offset guesses for the next tile: offsets of the last two matches selected so far */
+            if (nsel >= 2) { erep0 = last0; erep1 = last1; }
+            else if (nsel == 1) { erep1 = erep0; erep0 = last0; }
         }
     }
-    /* trailing literals of the block */
-    memcpy(lit + lp, src + anchor, be - anchor);
-    lp += be - anchor;
+    (void)i;
     *nlit = lp;
+    resolve_repcodes(seq, nseq, c->st);
     return nseq;
 }
 
@@ -756,7 +760,7 @@ void zge_default_params(zge_params *P, int level)
     P->level = level;
     P->checksum = 1;
     P->long_log = 14; P->short_log = 14; P->short_bytes = 5;
-    P->tile = 1024; P->sub = 64; P->cap = 32;
+    P->tile = 1024; P->sub = 64; P->cap = 256;
     P->min_match = 5; P->min_rep = 3; P->rep_search = 2;
     P->back_cap = 8; P->lazy = 1; P->lazy_delta = 5;
     P->lit_cost = 5; P->match_cost = 12; P->rep_cost = 9;
@@ -790,10 +794,13 @@ int zge_encode_frame(const zge_params *P, const void *src_, size_t n, void *dst_
     }
     c.P = P; c.src = src; c.n = n; c.st = st;
     c.window = single ? (n ? n : 1) : ((size_t)1 << wlog);
-    c.rep[0] = 1; c.rep[1] = 4; c.rep[2] = 8;
     c.tl = (uint32_t *)calloc((size_t)1 << P->long_log, 4);
     c.ts = (uint32_t *)calloc((size_t)1 << P->short_log, 4);
     c.M = (cand *)calloc((size_t)P->tile, sizeof(cand));
+    c.M2 = (cand *)calloc((size_t)P->tile, sizeof(cand));
+    c.next = (uint32_t *)calloc((size_t)P->tile, 4);
+    c.take = (uint8_t *)calloc((size_t)P->tile, 1);
+    c.mark = (uint8_t *)calloc((size_t)P->tile, 1);
     seq = (zge_seq *)malloc(sizeof(zge_seq) * (ZGE_BLOCK / 3 + 8));
     lit = (uint8_t *)malloc(ZGE_BLOCK + 64);
     blk = (uint8_t *)malloc(ZGE_BLOCK + 1024);
@@ -839,7 +846,7 @@ int zge_encode_frame(const zge_params *P, const void *src_, size_t n, void *dst_
         uint32_t x = (uint32_t)oracle_xxh64(src, n, 0);
         dst[pos++] = (uint8_t)x; dst[pos++] = (uint8_t)(x >> 8); dst[pos++] = (uint8_t)(x >> 16); dst[pos++] = (uint8_t)(x >> 24);
     }
-    free(c.tl); free(c.ts); free(c.M); free(seq); free(lit); free(blk);
+    free(c.tl); free(c.ts); free(c.M); free(c.M2); free(c.next); free(c.take); free(c.mark); free(seq); free(lit); free(blk);
     *out_len = pos;
     return 0;
 }

@@ -26,6 +26,18 @@ __device__ __forceinline__ void wave_sync()
 #endif
 }
 
+// Ordering point between LDS instructions of ONE wave (e.g. table lookups that must precede the same wave's
+// inserts).  The LDS executes a wave's instructions in program order, so on hardware this only stops the
+// compiler from reordering; it costs no wait.  The emulator needs a rendezvous.
+__device__ __forceinline__ void wave_lds_order()
+{
+#ifdef ZARC_HIPEMU
+    hipemu_wave_sync();
+#else
+    asm volatile("" ::: "memory");
+#endif
+}
+
 // Same for global-memory hand-offs between lanes of one wave (store -> fence -> load by another lane):
 // the release/acquire pair at workgroup scope waits for the stores (s_waitcnt vmcnt(0)); all waves of
 // a workgroup share the CU's vector L1, so no cache maintenance is involved.

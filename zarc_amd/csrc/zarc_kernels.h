@@ -15,7 +15,7 @@ constexpr uint32_t ZARC_MAX_SEQ = ZARC_BLOCK / 3 + 8; // sequences per block (ev
 // ---- encoder tuning (mirrors oracle/zge_model.h zge_params; plain ints so the struct can be passed by value)
 struct ZgeParams {
     int level, checksum, window_log, long_log, short_log, short_bytes, tile, sub, cap, min_match, min_rep, rep_search,
-        back_cap, lazy, lazy_delta, lit_cost, match_cost, rep_cost, short_window_log;
+        back_cap, lazy, lazy_delta, lit_cost, match_cost, rep_cost, short_window_log, dbg;
 };
 
 // Per-block record written by the match finder and completed by the entropy coder.
@@ -51,7 +51,7 @@ __global__ void zarc_corpus_fill(uint8_t *base, const uint64_t *off, const uint6
 __global__ void zarc_zge_match(ZgeParams P, const uint8_t *src_base, const uint64_t *src_off, const uint64_t *src_len,
                                const uint32_t *order, uint32_t n_frames, const uint64_t *block_prefix, ZgeBlock *blocks,
                                uint64_t *seq_scratch, uint8_t *lit_scratch);
-__global__ void zarc_zge_entropy(uint32_t n_blocks, ZgeBlock *blocks, const uint64_t *seq_scratch, const uint8_t *lit_scratch,
+__global__ void zarc_zge_entropy(uint32_t n_blocks, ZgeBlock *blocks, uint64_t *seq_scratch, const uint8_t *lit_scratch,
                                  uint8_t *out_scratch);
 __global__ void zarc_zge_assemble(ZgeParams P, const uint8_t *src_base, const uint64_t *src_off, const uint64_t *src_len,
                                   const uint32_t *order, uint32_t n_frames, const uint64_t *block_prefix, const ZgeBlock *blocks, const uint8_t *out_scratch,

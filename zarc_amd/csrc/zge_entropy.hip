@@ -433,7 +433,7 @@ struct WavePacker {
 
 } // namespace
 
-__global__ void __launch_bounds__(64) zarc_zge_entropy(uint32_t n_blocks, ZgeBlock *__restrict__ blocks, const uint64_t *__restrict__ seq_scratch,
+__global__ void __launch_bounds__(64) zarc_zge_entropy(uint32_t n_blocks, ZgeBlock *__restrict__ blocks, uint64_t *__restrict__ seq_scratch,
                                                        const uint8_t *__restrict__ lit_scratch, uint8_t *__restrict__ out_scratch)
 {
     __shared__ EntLds L;
@@ -443,7 +443,7 @@ __global__ void __launch_bounds__(64) zarc_zge_entropy(uint32_t n_blocks, ZgeBlo
     ZgeBlock *rec = blocks + bi;
     if (rec->type == 1) return; // RLE block: nothing to code
     const uint32_t nlit = rec->nlit, nseq = rec->nseq, src_len = rec->src_len;
-    const uint64_t *seq = seq_scratch + (uint64_t)bi * ZARC_MAX_SEQ;
+    uint64_t *seq = seq_scratch + (uint64_t)bi * ZARC_MAX_SEQ;
     const uint8_t *lit = lit_scratch + (uint64_t)bi * (ZARC_BLOCK + 64);
     uint8_t *out = out_scratch + (uint64_t)bi * (ZARC_BLOCK + 1024);
     const uint32_t out_cap = ZARC_BLOCK + 1024;
@@ -535,6 +535,50 @@ __global__ void __launch_bounds__(64) zarc_zge_entropy(uint32_t n_blocks, ZgeBlo
         }
     }
     zd::wave_sync_global();
+
+    // ================= sequences pre-pass =================
+    // The match finder stores (literal position, match length, offset); here the literal length becomes the
+    // difference of neighbouring literal positions and the offset is resolved against the repcode history
+    // (RFC 8878 3.1.1.5).  The history is a serial chain: lane 0 walks 64 sequences per round out of LDS.  It
+    // starts UNKNOWN (0) in every block because blocks are coded independently of their predecessors' type.
+    {
+        uint32_t r0 = 0, r1 = 0, r2 = 0, carry = 0;
+        for (uint32_t base = 0; base < nseq; base += 64) {
+            const uint32_t cnt = nseq - base < 64 ? nseq - base : 64;
+            const bool valid = (uint32_t)lane < cnt;
+            const uint64_t s = valid ? seq[base + (uint32_t)lane] : 0;
+            const uint32_t litpos = zge_seq_ll(s), ml = zge_seq_ml(s), off = zge_seq_ofv(s);
+            uint32_t prev = zd::shfl_up(litpos, 1);
+            if (lane == 0) prev = carry;
+            const uint32_t ll = litpos - prev;
+            carry = zd::uniform(zd::shfl(litpos, (int)cnt - 1));
+            L.chain[0][lane] = off;
+            L.chain[1][lane] = ll;
+            zd::wave_sync();
+            if (lane == 0) {
+                for (uint32_t e = 0; e < cnt; e++) {
+                    const uint32_t o = L.chain[0][e];
+                    uint32_t ofv;
+                    if (L.chain[1][e] > 0) {
+                        if (o == r0) ofv = 1;
+                        else if (o == r1) { ofv = 2; r1 = r0; r0 = o; }
+                        else if (o == r2) { ofv = 3; r2 = r1; r1 = r0; r0 = o; }
+                        else { ofv = o + 3; r2 = r1; r1 = r0; r0 = o; }
+                    } else {
+                        if (o == r1) { ofv = 1; r1 = r0; r0 = o; }
+                        else if (o == r2) { ofv = 2; r2 = r1; r1 = r0; r0 = o; }
+                        else if (r0 > 1 && o == r0 - 1) { ofv = 3; r2 = r1; r1 = r0; r0 = o; }
+                        else { ofv = o + 3; r2 = r1; r1 = r0; r0 = o; }
+                    }
+                    L.chain[2][e] = ofv;
+                }
+            }
+            zd::wave_sync();
+            if (valid) seq[base + (uint32_t)lane] = zge_pack_seq(ll, ml, L.chain[2][lane]);
+            zd::wave_sync();
+        }
+        zd::wave_sync_global(); // the coding passes below read seq[] with a different lane mapping
+    }
 
     // ================= sequences section =================
     uint32_t ssz = 0;
