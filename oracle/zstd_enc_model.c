@@ -641,23 +641,33 @@ static uint32_t matchfind_block(mf_ctx *c, size_t bs, size_t be, zge_seq *seq, u
     for (tile = bs; tile < be; tile += (size_t)P->tile) {
         size_t tend = tile + (size_t)P->tile < be ? tile + (size_t)P->tile : be, p, sub;
         uint32_t tcount = (uint32_t)(tend - tile), t;
+        /* Table entries hold (position inside the current 2^seg_log segment + 1) << tag_bits | tag; the frame loop
+         * clears the tables at every segment boundary. */
         if (pos >= tend) continue; /* whole tile already covered by a match: skip it (nothing is inserted) */
-        /* S2: ordered lookup + insert, 64 positions at a time (lookups of a group see inserts of earlier groups) */
+        /* S2: ordered lookup + insert, 64 positions at a time (lookups of a group see inserts of earlier groups).
+         * The extra tag bits of the hash reject most false candidates without touching memory. */
         for (sub = tile; sub < tend; sub += (size_t)P->sub) {
             size_t send = sub + (size_t)P->sub < tend ? sub + (size_t)P->sub : tend;
+            const uint32_t tmask = (1u << P->tag_bits) - 1;
+            const size_t segbase = tile & ~(((size_t)1 << P->seg_log) - 1);
             for (p = sub; p < send; p++) {
                 cand *m = &c->M[p - tile];
                 m->len = 0; m->off = 0; m->back = 0; m->is_rep = 0;
                 if (p < hash_end) {
                     uint64_t v = rd64(src + p);
-                    m->off = c->tl[hash_long(v, P->long_log)];            /* stash candidates */
-                    m->len = c->ts[hash_short(v, P->short_log, P->short_bytes)];
+                    uint32_t hl = hash_long(v, P->long_log + P->tag_bits), hs = hash_short(v, P->short_log + P->tag_bits, P->short_bytes);
+                    uint32_t el = c->tl[hl >> P->tag_bits], es = c->ts[hs >> P->tag_bits];
+                    /* stash candidate positions (+1), 0 = none */
+                    m->off = (el && (el & tmask) == (hl & tmask)) ? (uint32_t)segbase + (el >> P->tag_bits) : 0;
+                    m->len = (es && (es & tmask) == (hs & tmask)) ? (uint32_t)segbase + (es >> P->tag_bits) : 0;
                 }
             }
             for (p = sub; p < send && p < hash_end; p++) {
                 uint64_t v = rd64(src + p);
-                c->tl[hash_long(v, P->long_log)] = (uint32_t)p + 1;       /* ascending: max wins */
-                c->ts[hash_short(v, P->short_log, P->short_bytes)] = (uint32_t)p + 1;
+                uint32_t hl = hash_long(v, P->long_log + P->tag_bits), hs = hash_short(v, P->short_log + P->tag_bits, P->short_bytes);
+                uint32_t code = (uint32_t)(p - segbase) + 1;
+                c->tl[hl >> P->tag_bits] = (code << P->tag_bits) | (hl & tmask);   /* ascending: max wins */
+                c->ts[hs >> P->tag_bits] = (code << P->tag_bits) | (hs & tmask);
             }
         }
         /* S3: every position scores its own candidates {long, short, guess0, guess1} */
@@ -759,7 +769,7 @@ void zge_default_params(zge_params *P, int level)
     memset(P, 0, sizeof *P);
     P->level = level;
     P->checksum = 1;
-    P->long_log = 14; P->short_log = 14; P->short_bytes = 5;
+    P->long_log = 13; P->short_log = 13; P->short_bytes = 5; P->tag_bits = 10; P->seg_log = 21;
     P->tile = 1024; P->sub = 64; P->cap = 256;
     P->min_match = 5; P->min_rep = 3; P->rep_search = 2;
     P->back_cap = 8; P->lazy = 1; P->lazy_delta = 5;
@@ -809,6 +819,12 @@ int zge_encode_frame(const zge_params *P, const void *src_, size_t n, void *dst_
         size_t be = bs + ZGE_BLOCK < n ? bs + ZGE_BLOCK : n, blen = be - bs, nlit = 0, i;
         int last = be == n, all_same = 1;
         uint32_t hdr;
+        /* table positions are relative to 2^seg_log segments (multiples of the block size): at a boundary the
+         * tables are cleared, so candidates never cross it (only frames larger than a segment notice) */
+        if (bs > 0 && (bs & (((size_t)1 << P->seg_log) - 1)) == 0) {
+            memset(c.tl, 0, sizeof(uint32_t) << P->long_log);
+            memset(c.ts, 0, sizeof(uint32_t) << P->short_log);
+        }
         for (i = 1; i < blen; i++) if (src[bs + i] != src[bs]) { all_same = 0; break; }
         if (all_same && blen >= 2) {
             /* RLE block.  The match finder still has to see the block so later blocks can reference it:

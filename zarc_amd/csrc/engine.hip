@@ -76,7 +76,7 @@ ZgeParams derive_params(const zarc_gpu_params &p)
     z.window_log = p.window_log ? p.window_log : (level >= 9 ? 22 : 21);
     if (z.window_log < 10) z.window_log = 10;
     if (z.window_log > 27) z.window_log = 27;
-    z.long_log = 14; z.short_log = 14; z.short_bytes = 5;
+    z.long_log = 13; z.short_log = 13; z.short_bytes = 5; z.tag_bits = 10; z.seg_log = 21;
     z.tile = 1024; z.sub = 64; z.cap = 256;
     z.min_match = p.min_match >= 4 && p.min_match <= 7 ? p.min_match : 5;
     z.min_rep = 3; z.rep_search = 2; z.back_cap = 8;
@@ -376,7 +376,7 @@ int zarc_gpu_pack_batch_device(zarc_gpu_t *h, size_t n, const void *d_src_base, 
         ZHIP(h->d_out.reserve(nb * (size_t)(ZARC_BLOCK + 1024)));
         int a, b, c, d;
         ZHIP(t.mark(&a));
-        hipLaunchKernelGGL(zarc_zge_match, dim3((unsigned)m), dim3(1024), 0, h->stream, P, base, d_off, d_len, h->d_order.as<uint32_t>(), (uint32_t)m,
+        hipLaunchKernelGGL(zarc_zge_match, dim3((unsigned)m), dim3(512), 0, h->stream, P, base, d_off, d_len, h->d_order.as<uint32_t>(), (uint32_t)m,
                            h->d_block_prefix.as<uint64_t>(), h->d_blocks.as<ZgeBlock>(), h->d_seq.as<uint64_t>(), h->d_lit.as<uint8_t>());
         ZHIP(hipGetLastError());
         ZHIP(t.mark(&b));

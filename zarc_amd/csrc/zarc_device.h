@@ -38,6 +38,18 @@ __device__ __forceinline__ void wave_lds_order()
 #endif
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains this wave's outstanding
+// global stores (s_waitcnt vmcnt(0)) -- a ~1-2 us stall per tile in kernels that stream results to HBM which
+// nobody in the workgroup reads back.  Use this one between LDS-only phases.
+__device__ __forceinline__ void lds_barrier()
+{
+#ifdef ZARC_HIPEMU
+    __syncthreads();
+#else
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+
 // Same for global-memory hand-offs between lanes of one wave (store -> fence -> load by another lane):
 // the release/acquire pair at workgroup scope waits for the stores (s_waitcnt vmcnt(0)); all waves of
 // a workgroup share the CU's vector L1, so no cache maintenance is involved.
@@ -59,6 +71,16 @@ __device__ __forceinline__ uint32_t uniform(uint32_t v)
     return hipemu_readfirstlane(v);
 #else
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+#endif
+}
+
+// v from lane `idx`, where idx is the same in every lane (v_readlane_b32: no LDS round trip)
+__device__ __forceinline__ uint32_t readlane(uint32_t v, uint32_t idx)
+{
+#ifdef ZARC_HIPEMU
+    return hipemu_readfirstlane((uint32_t)__shfl((int)v, (int)idx, 64));
+#else
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)__builtin_amdgcn_readfirstlane((int)idx));
 #endif
 }
 

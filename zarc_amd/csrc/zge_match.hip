@@ -3,19 +3,22 @@
 // Part of the replacement for `CCtx::compress2` at crates/zarc/src/encode/lowlevel_frames.rs:29-31
 // (called per entry from Encoder::add_data_frame, crates/zarc/src/encode/content_frame.rs:41).
 //
-// One 1024-thread workgroup per frame, one frame per CU at a time: the two position hash tables (8-byte
-// "long" hash and 5-byte "short" hash, 2^14 u32 entries each = 128 KiB) stay in LDS for the whole frame,
-// so matches reach back across all earlier blocks of the frame (window = frame, capped at 2^window_log).
-// A block (<= 128 KiB) is swept in tiles of 1024 positions, one position per thread:
+// One 512-thread workgroup per frame, TWO frames per CU (their latencies overlap): the two position hash
+// tables (8-byte "long" hash and 5-byte "short" hash, 2^13 u32 entries each = 64 KiB per frame) stay in LDS
+// for the whole frame, so matches reach back across all earlier blocks (window = frame, up to 2 MiB).  Each
+// entry packs (position+1) << 10 | 10 hash check bits: a lookup rejects most false candidates without
+// touching memory.
+// A block (<= 128 KiB) is swept in tiles of 1024 positions, two positions per thread (t and t+512):
 //   S0/S1 stage the tile's bytes in LDS (coalesced dword loads), hash every position (64-bit multiplies)
 //   S2    ordered lookup + insert by wave 0, 64 positions per step: LDS executes one wave's instructions in
 //         order, so a position sees every insert of earlier 64-groups with no waiting between steps
-//   S3    every position scores its candidates {long, short, 2 recent offsets}: common prefix (LDS for the
-//         tile side, L2/HBM for far sources), backward-extension potential, bit-cost model
+//   S3    every position scores its candidates {long, short, 2 recent offsets}: all source words are
+//         requested up front (one round trip to L2/HBM), tile side comes from LDS; backward-extension potential
 //   S4    backward propagation: position t may start the match found at t+k, k bytes earlier
 //   S5    one-byte lazy rule -> take flag and successor next[t] for every position
-//   S6    the greedy parse IS the path from the entry cursor through next[]: pointer doubling over the tile
-//         (10 rounds of jump[t] = jump[jump[t]] with monotone marking) instead of a serial walk
+//   S6    the greedy parse IS the path from the entry cursor through next[]: per 64-position chunk the exit of
+//         every position by 6 rounds of shuffle pointer-jumping, then the chunk entries by a short chain
+//         through LDS, then each wave marks its chunk's path with v_readlane -- no workgroup barriers
 //   S7    ballot/popcount prefix sums place literal bytes and sequences; nothing is serial per sequence
 // Output per block: packed (literal position, match length, offset) + literal bytes in HBM scratch; literal
 // lengths and repcodes are resolved by the entropy stage.  Deterministic and bit-identical to
@@ -26,20 +29,23 @@
 namespace {
 
 constexpr int TILE = 1024;
-constexpr int THREADS = 1024;
-constexpr int TAB_LOG_MAX = 14;
+constexpr int THREADS = 512;
+constexpr int WAVES = THREADS / 64;
+constexpr int PER = TILE / THREADS; // positions per thread
+constexpr int CHUNKS = TILE / 64;
+constexpr int TAB_LOG = 13;
+constexpr int TAG_BITS = 10;
+constexpr uint32_t TAG_MASK = (1u << TAG_BITS) - 1;
 constexpr int CAP_MAX = 256;
 constexpr int TB_BYTES = 12 + TILE + CAP_MAX + 24; // 8 bytes before the tile, compare overrun after it
 
 struct MatchLds {
-    uint32_t tl[1 << TAB_LOG_MAX];
-    uint32_t ts[1 << TAB_LOG_MAX];
-    uint32_t a0[TILE], a1[TILE]; // S1: hashes -> S2: candidates (pos+1) -> S3: own match {offset ; len | back<<16 | rep<<24}
-    uint32_t b0[TILE], b1[TILE]; // S4: match after backward propagation {offset ; len | rep<<24}
-    uint16_t ja[TILE + 2], jb[TILE + 2];
-    uint8_t mark[TILE];
+    uint32_t tl[1 << TAB_LOG];
+    uint32_t ts[1 << TAB_LOG];
+    uint32_t a0[TILE], a1[TILE]; // S1: hashes -> S2: candidates (pos+1) -> S3: own match {offset ; len | back<<16 | rep<<24} -> S4: final match
+    uint16_t ex[TILE];            // S6: first position outside its chunk reached from each position
     uint32_t tb[(TB_BYTES + 3) / 4];
-    uint32_t wsel[16], wlit[16];
+    uint32_t wsel[CHUNKS], wlit[CHUNKS];
     uint32_t ctrl[16];
 };
 enum { K_POS = 0, K_REP0 = 1, K_REP1 = 2, K_FLAG = 3, K_NEW0 = 4, K_NEW1 = 5 };
@@ -61,16 +67,17 @@ struct Win {
     const uint8_t *src;  // frame start in global memory
     const uint8_t *lds;  // LDS byte that corresponds to frame position `lo`
     uint64_t lo, hi;
+    __device__ __forceinline__ bool staged(uint64_t pos) const { return pos >= lo && pos + 8 <= hi; }
     __device__ __forceinline__ uint64_t ld8(uint64_t pos) const
     {
-        if (pos >= lo && pos + 8 <= hi) return zd::load_u64(lds + (pos - lo));
+        if (staged(pos)) return zd::load_u64(lds + (pos - lo));
         return zd::load_u64(src + pos);
     }
 };
 
-__device__ __forceinline__ uint32_t match_len(const Win &w, uint64_t p, uint64_t q, uint32_t limit)
+// continue a common-prefix count from `n` (a multiple of 8) matched bytes up to `limit`
+__device__ __forceinline__ uint32_t match_more(const Win &w, uint64_t p, uint64_t q, uint32_t n, uint32_t limit)
 {
-    uint32_t n = 0;
     while (n + 8 <= limit) {
         const uint64_t x = w.ld8(p + n) ^ w.ld8(q + n);
         if (x) return n + (uint32_t)(zd::ctz64(x) >> 3);
@@ -87,10 +94,10 @@ __device__ __forceinline__ uint32_t match_len(const Win &w, uint64_t p, uint64_t
 
 } // namespace
 
-__global__ void __launch_bounds__(1024) zarc_zge_match(ZgeParams P, const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off,
-                                                       const uint64_t *__restrict__ src_len, const uint32_t *__restrict__ order, uint32_t n_frames,
-                                                       const uint64_t *__restrict__ block_prefix, ZgeBlock *__restrict__ blocks,
-                                                       uint64_t *__restrict__ seq_scratch, uint8_t *__restrict__ lit_scratch)
+__global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off,
+                                                      const uint64_t *__restrict__ src_len, const uint32_t *__restrict__ order, uint32_t n_frames,
+                                                      const uint64_t *__restrict__ block_prefix, ZgeBlock *__restrict__ blocks,
+                                                      uint64_t *__restrict__ seq_scratch, uint8_t *__restrict__ lit_scratch)
 {
     __shared__ MatchLds L;
     const int tid = (int)threadIdx.x, lane = zd::lane_id(), wave = zd::wave_id();
@@ -103,9 +110,11 @@ __global__ void __launch_bounds__(1024) zarc_zge_match(ZgeParams P, const uint8_
     const uint64_t first_block = block_prefix[blockIdx.x];
     const uint32_t nblocks = (uint32_t)(block_prefix[blockIdx.x + 1] - first_block);
     const uint32_t cap_max = (uint32_t)(P.cap < CAP_MAX ? P.cap : CAP_MAX);
+    const uint64_t lt = (1ull << lane) - 1;
+    const uint64_t seg_mask = (1ull << P.seg_log) - 1;
 
-    for (int i = tid; i < (1 << TAB_LOG_MAX); i += THREADS) { L.tl[i] = 0; L.ts[i] = 0; }
-    __syncthreads();
+    for (int i = tid; i < (1 << TAB_LOG); i += THREADS) { L.tl[i] = 0; L.ts[i] = 0; }
+    zd::lds_barrier();
 
     for (uint32_t b = 0; b < nblocks; b++) {
         const uint64_t bs = (uint64_t)b * ZARC_BLOCK;
@@ -115,9 +124,12 @@ __global__ void __launch_bounds__(1024) zarc_zge_match(ZgeParams P, const uint8_
         uint64_t *seq_out = seq_scratch + (first_block + b) * (uint64_t)ZARC_MAX_SEQ;
         uint8_t *lit_out = lit_scratch + (first_block + b) * (uint64_t)(ZARC_BLOCK + 64);
 
+        if (bs > 0 && (bs & seg_mask) == 0) { // new 2^seg_log segment (a multiple of the block size): table positions restart
+            for (int i = tid; i < (1 << TAB_LOG); i += THREADS) { L.tl[i] = 0; L.ts[i] = 0; }
+        }
         // ---- RLE block detection: every byte equals the first one (8 bytes per load; blocks start 16-byte aligned) ----
         if (tid == 0) { L.ctrl[K_FLAG] = 0; L.ctrl[K_POS] = 0; L.ctrl[K_REP0] = 0; L.ctrl[K_REP1] = 0; }
-        __syncthreads();
+        zd::lds_barrier();
         {
             bool diff = false;
             const uint8_t first = blen ? src[bs] : 0;
@@ -128,20 +140,21 @@ __global__ void __launch_bounds__(1024) zarc_zge_match(ZgeParams P, const uint8_
             for (uint32_t i = nw * 8 + (uint32_t)tid; i < blen; i += THREADS) diff |= src[bs + i] != first;
             if (diff) L.ctrl[K_FLAG] = 1; // benign race: every writer stores 1
         }
-        __syncthreads();
+        zd::lds_barrier();
         const bool all_same = L.ctrl[K_FLAG] == 0;
         if (tid == 0) {
             rec->frame = f; rec->index = b; rec->src_len = blen; rec->nseq = 0; rec->nlit = 0;
             rec->type = (all_same && blen >= 2) ? 1u : 2u; rec->out_len = 0; rec->pad = 0;
         }
-        if (all_same && blen >= 2) { __syncthreads(); continue; } // nothing is inserted for RLE blocks (same rule as the model)
+        if (all_same && blen >= 2) { zd::lds_barrier(); continue; } // nothing is inserted for RLE blocks (same rule as the model)
 
         uint32_t nseq = 0, lp = 0; // replicated in every thread
 
         for (uint64_t tile = bs; tile < be; tile += TILE) {
             const uint64_t tend = tile + TILE < be ? tile + TILE : be;
             const uint32_t tcount = (uint32_t)(tend - tile);
-            __syncthreads(); // K_POS / K_REP* of the previous tile are final; LDS work arrays are free again
+            const uint64_t segbase = tile & ~seg_mask;
+            zd::lds_barrier(); // K_POS / K_REP* of the previous tile are final; LDS work arrays are free again
             const uint64_t pos = bs + L.ctrl[K_POS];
             if (pos >= tend) continue; // whole tile already covered by a match: skip it (nothing is inserted)
             const uint32_t erep0 = L.ctrl[K_REP0], erep1 = L.ctrl[K_REP1];
@@ -159,46 +172,66 @@ __global__ void __launch_bounds__(1024) zarc_zge_match(ZgeParams P, const uint8_
                 for (int i = tid; i < ndw; i += THREADS) L.tb[i] = w[i];
                 W.src = src; W.lds = (const uint8_t *)L.tb + mis; W.lo = lo; W.hi = hi;
             }
-            __syncthreads();
-            // ---- S1: hashes ----
-            const uint64_t p = tile + (uint64_t)tid;
-            const bool in_tile = (uint32_t)tid < tcount;
-            {
-                uint32_t h = 0xFFFFFFFFu;
-                if (in_tile && p < hash_end) {
-                    const uint64_t v = W.ld8(p);
-                    h = hash_long(v, P.long_log) | (hash_short(v, P.short_log, P.short_bytes) << 16);
-                }
-                L.a0[tid] = h;
-            }
-            __syncthreads();
-            // ---- S2: ordered lookup + insert (wave 0); no waits between the 16 steps on hardware ----
-            if (wave == 0) {
-                uint32_t cl[TILE / 64], cs[TILE / 64];
+            zd::lds_barrier();
+            // ---- S1: hashes (index << TAG_BITS | tag) ----
+            uint64_t p8[PER]; // first 8 bytes at each of this thread's positions
 #pragma unroll
-                for (int k = 0; k < TILE / 64; k++) {
-                    const uint32_t h = L.a0[k * 64 + lane];
-                    const bool act = h != 0xFFFFFFFFu;
-                    const uint32_t hl = h & 0xFFFF, hs = (h >> 16) & 0xFFFF;
-                    cl[k] = act ? L.tl[hl] : 0u;
-                    cs[k] = act ? L.ts[hs] : 0u;
-                    zd::wave_lds_order(); // lookups of this 64-group precede its inserts
-                    if (act) {
-                        const uint32_t v = (uint32_t)(tile + (uint32_t)(k * 64 + lane)) + 1;
-                        atomicMax(&L.tl[hl], v);
-                        atomicMax(&L.ts[hs], v);
+            for (int u = 0; u < PER; u++) {
+                const uint32_t idx = (uint32_t)(u * THREADS + tid);
+                const uint64_t p = tile + idx;
+                uint32_t hl = 0xFFFFFFFFu, hs = 0xFFFFFFFFu;
+                p8[u] = 0;
+                if (idx < tcount) {
+                    p8[u] = W.ld8(p);
+                    if (p < hash_end && !(P.dbg & 64)) {
+                        hl = hash_long(p8[u], TAB_LOG + TAG_BITS);
+                        hs = hash_short(p8[u], TAB_LOG + TAG_BITS, P.short_bytes);
                     }
-                    zd::wave_lds_order(); // inserts precede the next group's lookups
                 }
-#pragma unroll
-                for (int k = 0; k < TILE / 64; k++) { L.a0[k * 64 + lane] = cl[k]; L.a1[k * 64 + lane] = cs[k]; }
+                L.a0[idx] = hl;
+                L.a1[idx] = hs;
             }
-            __syncthreads();
+            zd::lds_barrier();
+            // ---- S2: ordered lookup + insert (wave 0); no waits between the steps on hardware ----
+            if (wave == 0 && !(P.dbg & 4)) {
+#pragma unroll 1
+                for (int half = 0; half < CHUNKS; half += 8) { // 8 groups at a time keeps everything in registers
+                    uint32_t hl[8], hs[8], el[8], es[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) { hl[k] = L.a0[(half + k) * 64 + lane]; hs[k] = L.a1[(half + k) * 64 + lane]; }
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const bool act = hl[k] != 0xFFFFFFFFu;
+                        el[k] = act ? L.tl[hl[k] >> TAG_BITS] : 0u;
+                        es[k] = act ? L.ts[hs[k] >> TAG_BITS] : 0u;
+                        zd::wave_lds_order(); // lookups of this 64-group precede its inserts
+                        if (act) {
+                            const uint32_t code = ((uint32_t)(tile - segbase) + (uint32_t)((half + k) * 64 + lane) + 1) << TAG_BITS;
+                            atomicMax(&L.tl[hl[k] >> TAG_BITS], code | (hl[k] & TAG_MASK));
+                            atomicMax(&L.ts[hs[k] >> TAG_BITS], code | (hs[k] & TAG_MASK));
+                        }
+                        zd::wave_lds_order(); // inserts precede the next group's lookups
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; k++) { // candidate positions (+1), 0 = none or check bits differ
+                        const uint32_t cl = (el[k] && (el[k] & TAG_MASK) == (hl[k] & TAG_MASK)) ? (uint32_t)segbase + (el[k] >> TAG_BITS) : 0u;
+                        const uint32_t cs = (es[k] && (es[k] & TAG_MASK) == (hs[k] & TAG_MASK)) ? (uint32_t)segbase + (es[k] >> TAG_BITS) : 0u;
+                        L.a0[(half + k) * 64 + lane] = cl;
+                        L.a1[(half + k) * 64 + lane] = cs;
+                    }
+                }
+            }
+            zd::lds_barrier();
             // ---- S3: own candidates ----
-            {
-                uint32_t o = 0, w = 0;
-                if (in_tile && !(P.dbg & 1)) {
-                    const uint32_t c0 = L.a0[tid], c1 = L.a1[tid];
+            uint32_t mo[PER], mw[PER];
+#pragma unroll
+            for (int u = 0; u < PER; u++) {
+                const uint32_t idx = (uint32_t)(u * THREADS + tid);
+                const uint64_t p = tile + idx;
+                mo[u] = 0; mw[u] = 0;
+                if (idx < tcount && !(P.dbg & 1)) {
+                    uint32_t c0 = L.a0[idx], c1 = L.a1[idx];
+                    if (P.dbg & 4) { c0 = 0; c1 = 0; }
                     const uint32_t limit = (uint32_t)(be - p), cap = limit < cap_max ? limit : cap_max;
                     uint32_t offs[4];
                     offs[0] = c0 ? (uint32_t)p - (c0 - 1) : 0u;
@@ -206,15 +239,26 @@ __global__ void __launch_bounds__(1024) zarc_zge_match(ZgeParams P, const uint8_
                     if (P.short_window_log < 32 && offs[1] > (1u << P.short_window_log)) offs[1] = 0;
                     offs[2] = P.rep_search > 0 ? erep0 : 0u;
                     offs[3] = (P.rep_search > 1 && erep1 != erep0) ? erep1 : 0u;
+                    // request the first source word of every candidate before looking at any of them
+                    uint64_t q8[4];
+                    bool ok[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        ok[k] = offs[k] != 0 && offs[k] <= p && offs[k] <= window;
+                        q8[k] = ok[k] ? W.ld8(p - offs[k]) : 0;
+                    }
                     uint32_t best_len = 0, best_off = 0;
                     bool best_rep = false;
                     int32_t best_score = -1000000;
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
+                        if (!ok[k]) continue;
                         const uint32_t off = offs[k];
-                        if (off == 0 || off > p || off > window) continue;
                         const bool is_rep = off == erep0 || off == erep1;
-                        const uint32_t len = match_len(W, p, p - off, cap);
+                        const uint64_t x = q8[k] ^ p8[u];
+                        uint32_t len;
+                        if (x) { len = (uint32_t)(zd::ctz64(x) >> 3); if (len > cap) len = cap; }
+                        else len = cap >= 8 ? match_more(W, p, p - off, 8, cap) : cap;
                         if (len < (uint32_t)(is_rep ? P.min_rep : P.min_match)) continue;
                         const int32_t sc = score_of(P, len, off, is_rep);
                         if (sc > best_score) { best_score = sc; best_len = len; best_off = off; best_rep = is_rep; }
@@ -235,102 +279,142 @@ __global__ void __launch_bounds__(1024) zarc_zge_match(ZgeParams P, const uint8_
                                 while (back < maxb && src[p - back - 1] == src[q - back - 1]) back++;
                             }
                         }
-                        o = best_off;
-                        w = best_len | (back << 16) | ((best_rep ? 1u : 0u) << 24);
+                        mo[u] = best_off;
+                        mw[u] = best_len | (back << 16) | ((best_rep ? 1u : 0u) << 24);
                     }
                 }
-                __syncthreads(); // every thread has read its candidates from a0/a1
-                L.a0[tid] = o;
-                L.a1[tid] = w;
             }
-            __syncthreads();
-            // ---- S4: backward propagation ----
-            {
-                uint32_t bo = 0, bw = 0;
-                if (in_tile) {
-                    const uint32_t mo = L.a0[tid], mw = L.a1[tid];
-                    uint32_t blen_ = mw & 0xFFFF, boff = mo;
-                    bool brep = (mw >> 24) & 1;
+            zd::lds_barrier(); // every thread has read its candidates from a0/a1
+#pragma unroll
+            for (int u = 0; u < PER; u++) { L.a0[u * THREADS + tid] = mo[u]; L.a1[u * THREADS + tid] = mw[u]; }
+            zd::lds_barrier();
+            // ---- S4: backward propagation (read neighbours, then overwrite in place) ----
+#pragma unroll
+            for (int u = 0; u < PER; u++) {
+                const uint32_t idx = (uint32_t)(u * THREADS + tid);
+                if (idx < tcount && !(P.dbg & 8)) {
+                    uint32_t nwv[8];
+#pragma unroll
+                    for (int k = 1; k <= 8; k++) nwv[k - 1] = (k <= P.back_cap && idx + k < tcount) ? L.a1[idx + k] : 0u;
+                    uint32_t blen_ = mw[u] & 0xFFFF, boff = mo[u];
+                    bool brep = (mw[u] >> 24) & 1;
                     int32_t bscore = blen_ ? score_of(P, blen_, boff, brep) : 0;
-                    for (uint32_t k = 1; k <= (uint32_t)P.back_cap && (uint32_t)tid + k < tcount; k++) {
-                        const uint32_t nw = L.a1[tid + k];
+#pragma unroll
+                    for (int k = 1; k <= 8; k++) {
+                        const uint32_t nw = nwv[k - 1];
                         const uint32_t nl = nw & 0xFFFF, nbk = (nw >> 16) & 0xFF;
-                        if (!nl || nbk < k) continue;
-                        const uint32_t no = L.a0[tid + k];
+                        if (!nl || nbk < (uint32_t)k) continue;
+                        const uint32_t no = L.a0[idx + k];
                         const bool nr = (nw >> 24) & 1;
                         const int32_t sc = score_of(P, nl + k, no, nr);
                         if (sc > bscore) { bscore = sc; blen_ = nl + k; boff = no; brep = nr; }
                     }
-                    bo = boff;
-                    bw = blen_ | ((brep ? 1u : 0u) << 24);
-                }
-                L.b0[tid] = bo;
-                L.b1[tid] = bw;
-            }
-            __syncthreads();
-            // ---- S5: take flag (one-byte lazy lookahead inside the tile) and successor ----
-            const uint32_t my_off = L.b0[tid], my_w = L.b1[tid];
-            const uint32_t my_len = my_w & 0xFFFF;
-            bool take = in_tile && my_len != 0;
-            if (take && P.lazy && (uint32_t)tid + 1 < tcount) {
-                const uint32_t w2 = L.b1[tid + 1];
-                const uint32_t l2 = w2 & 0xFFFF;
-                if (l2 && score_of(P, l2, L.b0[tid + 1], (w2 >> 24) & 1) > score_of(P, my_len, my_off, (my_w >> 24) & 1) + P.lazy_delta) take = false;
-            }
-            const uint32_t nx = take ? (uint32_t)tid + my_len : (uint32_t)tid + 1; // true successor (may leave the tile)
-            const uint32_t entry = (uint32_t)((pos > tile ? pos : tile) - tile);
-            L.ja[tid] = (uint16_t)(nx < tcount ? nx : tcount);
-            L.mark[tid] = (uint32_t)tid == entry ? 1 : 0;
-            if (tid == 0) { L.ja[tcount] = (uint16_t)tcount; L.jb[tcount] = (uint16_t)tcount; }
-            __syncthreads();
-            // ---- S6: parse path by pointer doubling (marking is monotone and only ever marks path nodes) ----
-            if (!(P.dbg & 2)) {
-#pragma unroll 1
-                for (int r = 0; r < 10; r++) {
-                    const uint16_t *A = (r & 1) ? L.jb : L.ja;
-                    uint16_t *B = (r & 1) ? L.ja : L.jb;
-                    if (in_tile) {
-                        const uint32_t j = A[tid];
-                        if (L.mark[tid] && j < tcount) L.mark[j] = 1;
-                        B[tid] = A[j];
-                    }
-                    __syncthreads();
+                    mo[u] = boff;
+                    mw[u] = blen_ | ((brep ? 1u : 0u) << 24);
+                } else {
+                    mw[u] &= 0x0100FFFFu;
                 }
             }
-            // ---- S7: emission ----
-            const bool marked = in_tile && L.mark[tid] != 0;
-            const bool sel = marked && take, islit = marked && !take;
-            const uint64_t msel = zd::ballot(sel), mlit = zd::ballot(islit);
-            if (lane == 0) { L.wsel[wave] = (uint32_t)__popcll(msel); L.wlit[wave] = (uint32_t)__popcll(mlit); }
-            if (marked && nx >= tcount) L.ctrl[K_POS] = (uint32_t)(tile - bs) + nx; // the last path node: unique writer
-            __syncthreads();
-            uint32_t sel_before = 0, lit_before = 0, sel_total = 0, lit_total = 0;
+            zd::lds_barrier();
 #pragma unroll
-            for (int wv = 0; wv < THREADS / 64; wv++) {
-                const uint32_t s_ = L.wsel[wv], l_ = L.wlit[wv];
-                if (wv < wave) { sel_before += s_; lit_before += l_; }
+            for (int u = 0; u < PER; u++) { L.a0[u * THREADS + tid] = mo[u]; L.a1[u * THREADS + tid] = mw[u]; }
+            zd::lds_barrier();
+            // ---- S5: take flag (one-byte lazy lookahead inside the tile) and successor ----
+            bool take[PER];
+            uint32_t nx[PER]; // true successor in tile coordinates (may leave the tile)
+#pragma unroll
+            for (int u = 0; u < PER; u++) {
+                const uint32_t idx = (uint32_t)(u * THREADS + tid);
+                const uint32_t my_len = mw[u] & 0xFFFF;
+                take[u] = idx < tcount && my_len != 0;
+                if (take[u] && P.lazy && idx + 1 < tcount) {
+                    const uint32_t w2 = L.a1[idx + 1];
+                    const uint32_t l2 = w2 & 0xFFFF;
+                    if (l2 && score_of(P, l2, L.a0[idx + 1], (w2 >> 24) & 1) > score_of(P, my_len, mo[u], (mw[u] >> 24) & 1) + P.lazy_delta) take[u] = false;
+                }
+                nx[u] = take[u] ? idx + my_len : idx + 1;
+            }
+            // ---- S6a: per chunk, the first position outside the chunk reached from every position ----
+#pragma unroll
+            for (int u = 0; u < PER; u++) {
+                const uint32_t idx = (uint32_t)(u * THREADS + tid);
+                const uint32_t cbase = idx & ~63u;
+                const uint32_t cend = cbase + 64 < tcount ? cbase + 64 : tcount;
+                uint32_t val = nx[u];
+#pragma unroll
+                for (int r = 0; r < 6; r++) {
+                    const uint32_t v2 = zd::shfl(val, (int)((val - cbase) & 63));
+                    if (val < cend) val = v2;
+                }
+                L.ex[idx] = (uint16_t)val;
+            }
+            zd::lds_barrier();
+            // ---- S6b/c + S7: chunk entries by a chain through ex[], path marks per chunk, emission ----
+            uint64_t msel[PER], mlit[PER];
+            {
+                uint32_t cur = (uint32_t)((pos > tile ? pos : tile) - tile);
+                int c = 0;
+#pragma unroll
+                for (int u = 0; u < PER; u++) {
+                    const int mychunk = wave + u * WAVES;
+                    for (; c < mychunk; c++) { // chunks before mine: hop over them
+                        const uint32_t cend = (uint32_t)(c * 64 + 64) < tcount ? (uint32_t)(c * 64 + 64) : tcount;
+                        if (cur < cend) cur = L.ex[cur];
+                    }
+                    cur = zd::uniform(cur);
+                    const uint32_t cbase = (uint32_t)mychunk * 64;
+                    const uint32_t cend = cbase + 64 < tcount ? cbase + 64 : tcount;
+                    uint64_t mask = 0;
+                    if (!(P.dbg & 2)) {
+                        while (cur < cend) { // walk the path inside my chunk (uniform loop, v_readlane)
+                            mask |= 1ull << (cur - cbase);
+                            cur = zd::readlane(nx[u], cur - cbase);
+                        }
+                    }
+                    c = mychunk + 1;
+                    const uint64_t tk = zd::ballot(take[u]);
+                    msel[u] = mask & tk;
+                    mlit[u] = mask & ~tk;
+                    if (lane == 0) { L.wsel[mychunk] = (uint32_t)__popcll(msel[u]); L.wlit[mychunk] = (uint32_t)__popcll(mlit[u]); }
+                }
+                // the wave that owns the last chunk knows where the path leaves the tile
+                if (wave == WAVES - 1 && lane == 0) L.ctrl[K_POS] = (uint32_t)(tile - bs) + cur;
+            }
+            zd::lds_barrier();
+            uint32_t sel_total = 0, lit_total = 0, sel_before[PER], lit_before[PER];
+#pragma unroll
+            for (int u = 0; u < PER; u++) { sel_before[u] = 0; lit_before[u] = 0; }
+#pragma unroll
+            for (int cc = 0; cc < CHUNKS; cc++) {
+                const uint32_t s_ = L.wsel[cc], l_ = L.wlit[cc];
+#pragma unroll
+                for (int u = 0; u < PER; u++)
+                    if (cc < wave + u * WAVES) { sel_before[u] += s_; lit_before[u] += l_; }
                 sel_total += s_;
                 lit_total += l_;
             }
-            const uint64_t lt = (1ull << lane) - 1;
-            const uint32_t my_sel_idx = sel_before + (uint32_t)__popcll(msel & lt);
-            const uint32_t my_lit_idx = lit_before + (uint32_t)__popcll(mlit & lt);
-            if (sel) {
-                // the literal position stands in for the literal length (difference of neighbours, taken in stage 2)
-                seq_out[nseq + my_sel_idx] = zge_pack_seq(lp + my_lit_idx, my_len, my_off);
-                if (my_sel_idx + 1 == sel_total) L.ctrl[K_NEW0] = my_off;
-                if (my_sel_idx + 2 == sel_total) L.ctrl[K_NEW1] = my_off;
+#pragma unroll
+            for (int u = 0; u < PER; u++) {
+                const uint32_t my_sel_idx = sel_before[u] + (uint32_t)__popcll(msel[u] & lt);
+                const uint32_t my_lit_idx = lit_before[u] + (uint32_t)__popcll(mlit[u] & lt);
+                if (P.dbg & 32) continue;
+                if ((msel[u] >> lane) & 1) {
+                    // the literal position stands in for the literal length (difference of neighbours, taken in stage 2)
+                    seq_out[nseq + my_sel_idx] = zge_pack_seq(lp + my_lit_idx, mw[u] & 0xFFFF, mo[u]);
+                    if (my_sel_idx + 1 == sel_total) L.ctrl[K_NEW0] = mo[u];
+                    if (my_sel_idx + 2 == sel_total) L.ctrl[K_NEW1] = mo[u];
+                }
+                if ((mlit[u] >> lane) & 1) lit_out[lp + my_lit_idx] = (uint8_t)p8[u];
             }
-            if (islit) lit_out[lp + my_lit_idx] = W.lds[p - W.lo];
             nseq += sel_total;
             lp += lit_total;
-            __syncthreads();
+            zd::lds_barrier();
             if (tid == 0) { // offset guesses for the next tile: offsets of the last two matches selected so far
                 if (sel_total >= 2) { L.ctrl[K_REP0] = L.ctrl[K_NEW0]; L.ctrl[K_REP1] = L.ctrl[K_NEW1]; }
                 else if (sel_total == 1) { L.ctrl[K_REP1] = L.ctrl[K_REP0]; L.ctrl[K_REP0] = L.ctrl[K_NEW0]; }
             }
         }
         if (tid == 0) { rec->nseq = nseq; rec->nlit = lp; }
-        __syncthreads();
+        zd::lds_barrier();
     }
 }
