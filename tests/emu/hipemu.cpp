@@ -1,6 +1,7 @@
 // tests/emu/hipemu.cpp -- TEST INFRASTRUCTURE ONLY: runtime of the HIP emulator (see hip/hip_runtime.h).
 #include "hip/hip_runtime.h"
 #include <chrono>
+#include <csetjmp>
 #include <sys/mman.h>
 #include <ucontext.h>
 #include <vector>
@@ -11,6 +12,8 @@ enum State { RUNNABLE = 0, AT_BARRIER = 1, AT_WAVE = 2, DONE = 3 };
 
 struct ThreadCtx {
     ucontext_t ctx;
+    jmp_buf jb;          // after the first entry, switches use _setjmp/_longjmp (no sigprocmask syscalls)
+    bool started = false;
     char *stack = nullptr;
     dim3 tidx;
     int linear = 0, wave = 0, lane = 0;
@@ -26,6 +29,7 @@ struct WaveCtx {
 
 static const size_t STACK_BYTES = 256 * 1024;
 static ucontext_t g_sched;
+static jmp_buf g_sched_jb;
 static ThreadCtx *g_cur = nullptr;
 static std::vector<ThreadCtx> g_threads;
 static std::vector<WaveCtx> g_waves;
@@ -42,7 +46,18 @@ dim3 &gdim() { return g_gdim; }
 void *dyn_smem() { return g_dyn; }
 int lane() { return g_cur->lane; }
 
-static void yield_to_sched() { swapcontext(&g_cur->ctx, &g_sched); }
+static void yield_to_sched()
+{
+    if (!_setjmp(g_cur->jb)) _longjmp(g_sched_jb, 1);
+}
+static void resume(ThreadCtx &t)
+{
+    g_cur = &t;
+    if (!_setjmp(g_sched_jb)) {
+        if (!t.started) { t.started = true; swapcontext(&g_sched, &t.ctx); }
+        else _longjmp(t.jb, 1);
+    }
+}
 
 void block_barrier()
 {
@@ -71,7 +86,7 @@ static void trampoline()
 {
     (*g_body)();
     g_cur->state = DONE;
-    swapcontext(&g_cur->ctx, &g_sched);
+    _longjmp(g_sched_jb, 1);
 }
 
 static char *get_stack(size_t i)
@@ -108,8 +123,7 @@ static void run_block(dim3 block)
         for (size_t i = 0; i < n; i++) {
             ThreadCtx &t = g_threads[i];
             if (t.state != RUNNABLE) continue;
-            g_cur = &t;
-            swapcontext(&g_sched, &t.ctx);
+            resume(t);
             progressed = true;
             if (t.state == DONE) live--;
         }

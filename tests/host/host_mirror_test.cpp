@@ -1,0 +1,77 @@
+// tests/host/host_mirror_test.cpp -- exercises zarc::Encoder / zarc::FrameReader (zarc_amd/host/zarc_host.hpp) the
+// way the reference's CLI drives its library (crates/zarc-cli/src/pack.rs:219-272, unpack.rs:94-124).
+// Linked against the product library on a GPU box, or against the emulated build of the same sources on CPU.
+#include "../../zarc_amd/host/zarc_host.hpp"
+#include "../../zarc_amd/csrc/corpus.h"
+#include <cstdio>
+#include <cstdlib>
+#include <sstream>
+
+#define CHECK(c) do { if (!(c)) { std::fprintf(stderr, "CHECK failed: %s (line %d)\n", #c, __LINE__); return 1; } } while (0)
+
+int main(int argc, char **argv)
+{
+    const size_t big = argc > 1 ? (size_t)std::atol(argv[1]) : 65536;
+    // --- config C1 (BASELINE.json configs[0]): 10 x 64 KiB random entries, checksum on, default level ---
+    {
+        std::ostringstream file;
+        zarc::Encoder enc(file);
+        enc.set_zstd_parameter(ZARC_GPU_P_CHECKSUM_FLAG, 1); // crates/zarc-cli/src/pack.rs:227
+        std::vector<std::vector<uint8_t>> ents(10, std::vector<uint8_t>(65536));
+        std::vector<const void *> ptr;
+        std::vector<size_t> len;
+        for (size_t i = 0; i < ents.size(); i++) { zarc_corpus_entry(ents[i].data(), ents[i].size(), i, 3); ptr.push_back(ents[i].data()); len.push_back(ents[i].size()); }
+        auto dig = enc.add_data_frames(ptr.data(), len.data(), ptr.size());
+        const std::string bytes = file.str();
+        CHECK(bytes.size() == 12 + 10 * 65550);
+        CHECK(std::memcmp(bytes.data(), zarc::FILE_MAGIC, 12) == 0);
+        CHECK(enc.offset() == bytes.size());
+        for (size_t i = 0; i < 10; i++) {
+            const zarc::Frame &f = enc.frames().at(dig[i]);
+            CHECK(f.offset == 12 + 65550 * i && f.length == 65550 && f.uncompressed == 65536 && f.edition == 1);
+            CHECK((uint8_t)bytes[f.offset] == 0x28 && (uint8_t)bytes[f.offset + 3] == 0xFD);
+        }
+    }
+    // --- mixed entries with duplicates: first occurrence wins, later identical content writes nothing ---
+    std::ostringstream file;
+    zarc::Encoder enc(file);
+    enc.set_zstd_parameter(ZARC_GPU_P_CHECKSUM_FLAG, 1);
+    enc.set_zstd_parameter(ZARC_GPU_P_COMPRESSION_LEVEL, 3);
+    std::vector<std::vector<uint8_t>> ents;
+    const size_t sizes[] = {0, 1, 300, big, big + 17, 1000};
+    for (size_t i = 0; i < 6; i++) { ents.emplace_back(sizes[i]); zarc_corpus_entry(ents.back().data(), sizes[i], 100 + i, (int)(i & 3)); }
+    ents.push_back(ents[3]); // duplicate of entry 3 inside the same batch
+    std::vector<const void *> ptr;
+    std::vector<size_t> len;
+    for (auto &e : ents) { ptr.push_back(e.data()); len.push_back(e.size()); }
+    auto dig = enc.add_data_frames(ptr.data(), len.data(), ptr.size());
+    CHECK(dig.size() == 7 && dig[6] == dig[3]);
+    CHECK(enc.frames().size() == 6);
+    const uint64_t off_after = enc.offset();
+    auto again = enc.add_data_frame(ents[4].data(), ents[4].size()); // duplicate across calls
+    CHECK(again == dig[4] && enc.offset() == off_after && enc.frames().size() == 6);
+    // offsets are running sums starting at 12, in call order
+    uint64_t expect_off = 12;
+    for (const auto &d : enc.frame_order()) { const zarc::Frame &f = enc.frames().at(d); CHECK(f.offset == expect_off); expect_off += f.length; }
+    CHECK(expect_off == enc.offset());
+    // --- read back: read_content_frame + verify ---
+    const std::string image = file.str();
+    std::vector<zarc::Frame> wanted;
+    for (size_t i = 0; i < 6; i++) wanted.push_back(enc.frames().at(dig[i]));
+    zarc::Frame bad = wanted[2];
+    bad.digest.bytes[0] ^= 0xFF; // wrong expected digest: reported, bytes still delivered (unpack.rs:118-120)
+    wanted.push_back(bad);
+    zarc::FrameReader rd;
+    auto res = rd.read_content_frames((const uint8_t *)image.data(), image.size(), wanted);
+    for (size_t i = 0; i < 6; i++) {
+        CHECK(res[i].status == ZARC_GPU_FRAME_OK && res[i].verify.has_value() && *res[i].verify);
+        CHECK(res[i].data == ents[i] && res[i].digest == dig[i]);
+    }
+    CHECK(res[6].status == ZARC_GPU_FRAME_DIGEST && res[6].verify.has_value() && !*res[6].verify && res[6].data == ents[2]);
+    // --- parameter errors surface as exceptions carrying the libzstd-style name ---
+    bool threw = false;
+    try { enc.set_zstd_parameter(ZARC_GPU_P_COMPRESSION_LEVEL, 99); } catch (const zarc::Error &e) { threw = e.code == ZARC_GPU_E_PARAM; }
+    CHECK(threw);
+    std::printf("host mirror OK: %zu frames, archive body %llu bytes\n", enc.frames().size(), (unsigned long long)enc.offset());
+    return 0;
+}

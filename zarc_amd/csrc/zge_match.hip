@@ -100,7 +100,8 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                                                       uint64_t *__restrict__ seq_scratch, uint8_t *__restrict__ lit_scratch)
 {
     __shared__ MatchLds L;
-    const int tid = (int)threadIdx.x, lane = zd::lane_id(), wave = zd::wave_id();
+    const int tid = (int)threadIdx.x, lane = zd::lane_id();
+    const int wave = (int)zd::uniform((uint32_t)zd::wave_id()); // scalar: chunk bounds and the parse walk stay on the SALU
     const uint32_t f = order[blockIdx.x];
     const uint8_t *src = src_base + src_off[f];
     const uint64_t n = src_len[f];

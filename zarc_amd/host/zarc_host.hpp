@@ -1,0 +1,206 @@
+// zarc_amd/host/zarc_host.hpp -- host-side mirror of the reference's library API for the content path,
+// written above the C ABI (include/zarc_gpu.h).  The reference is Rust (no rustc/cargo on the build image), so
+// this is the C++ stand-in for what a patched `crates/zarc` would do around the FFI calls; names, argument
+// meaning and error behaviour follow the reference:
+//
+//   zarc::Encoder            crates/zarc/src/encode.rs:27-97 (struct + new/set_zstd_parameter/enable_compression)
+//   Encoder::add_data_frame  crates/zarc/src/encode/content_frame.rs:20-60 (hash -> dedup -> compress -> Frame record)
+//   zarc::Frame              crates/zarc/src/directory/frame.rs:10-32
+//   zarc::Digest             crates/zarc/src/integrity.rs:14-36 (constant-time equality :17-22)
+//   zarc::FrameReader        crates/zarc/src/decode/frame_iterator.rs:14-104 (read_content_frame + verify)
+//
+// What differs, on purpose: the engine is batched, so `add_data_frames` takes many entries at once (frames
+// are independent: a fresh session per frame, content_frame.rs:37-39).  Call order is preserved: frame order
+// = call order, first occurrence of a digest wins, later duplicates write nothing (content_frame.rs:30-33),
+// offsets are running sums starting at 12 (encode.rs:65,75).  Unlike the reference, writes use write-all
+// semantics (the reference's `writer.write` can short-write, lowlevel_frames.rs:38 -- SURVEY quirk 1).
+// The archive directory / trailer (`finalise`) stay host plumbing outside this path.
+#pragma once
+#include "../../include/zarc_gpu.h"
+#include <array>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <optional>
+#include <ostream>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace zarc {
+
+// header.rs:35-40: skippable-frame magic 0x184D2A50, length 4, ZARC_MAGIC 65 AA DC, version 1
+static const uint8_t FILE_MAGIC[12] = {0x50, 0x2A, 0x4D, 0x18, 0x04, 0x00, 0x00, 0x00, 0x65, 0xAA, 0xDC, 0x01};
+
+struct Digest {
+    std::array<uint8_t, 32> bytes{};
+    // constant-time equality (integrity.rs:17-22 uses subtle::ConstantTimeEq)
+    bool operator==(const Digest &o) const
+    {
+        uint8_t d = 0;
+        for (size_t i = 0; i < 32; i++) d |= (uint8_t)(bytes[i] ^ o.bytes[i]);
+        return d == 0;
+    }
+    bool operator<(const Digest &o) const { return std::memcmp(bytes.data(), o.bytes.data(), 32) < 0; } // map key only
+};
+
+struct Frame { // directory/frame.rs:12-32
+    uint16_t edition = 1;
+    uint64_t offset = 0;
+    Digest digest;
+    uint64_t length = 0;       // compressed bytes in the archive
+    uint64_t uncompressed = 0;
+};
+
+struct Error : std::runtime_error { // lib.rs:27-30: io::Error::other(ZSTD_getErrorName(code))
+    int code;
+    Error(int c, const std::string &what) : std::runtime_error(what), code(c) {}
+};
+
+class Engine { // CCtx/DCtx analogue: one per Encoder / reader (encode.rs:60-62, zstd_iterator.rs:29)
+  public:
+    explicit Engine(int device = 0)
+    {
+        int rc = zarc_gpu_create(&h_, device);
+        if (rc != ZARC_GPU_OK) throw Error(rc, "failed allocating zstd context"); // encode.rs:61 / ErrorKind::ZstdInit
+    }
+    ~Engine() { zarc_gpu_destroy(h_); }
+    Engine(const Engine &) = delete;
+    Engine &operator=(const Engine &) = delete;
+    zarc_gpu_t *get() const { return h_; }
+    void check(int rc) const
+    {
+        if (rc != ZARC_GPU_OK) throw Error(rc, std::string(zarc_gpu_error_name(rc)) + ": " + zarc_gpu_last_error(h_));
+    }
+
+  private:
+    zarc_gpu_t *h_ = nullptr;
+};
+
+class Encoder {
+  public:
+    // Encoder::new: creates the context and writes the 12-byte header (encode.rs:58-78)
+    explicit Encoder(std::ostream &writer, int device = 0) : writer_(writer), engine_(device)
+    {
+        writer_.write((const char *)FILE_MAGIC, sizeof FILE_MAGIC);
+        offset_ = sizeof FILE_MAGIC;
+    }
+    // Encoder::set_zstd_parameter -- sticky for future frames (encode.rs:84-89); id = ZSTD_cParameter value
+    void set_zstd_parameter(int id, int value) { engine_.check(zarc_gpu_set_parameter(engine_.get(), id, value)); }
+    // Encoder::enable_compression (encode.rs:95-97)
+    void enable_compression(bool compress) { zarc_gpu_enable_compression(engine_.get(), compress ? 1 : 0); }
+
+    // Encoder::add_data_frame for one entry (content_frame.rs:20)
+    Digest add_data_frame(const uint8_t *content, size_t len)
+    {
+        const void *p = content;
+        return add_data_frames(&p, &len, 1)[0];
+    }
+
+    // Batched add_data_frame: returns the digest of every entry in call order.
+    std::vector<Digest> add_data_frames(const void *const *content, const size_t *len, size_t n)
+    {
+        std::vector<Digest> digests(n);
+        if (n == 0) return digests;
+        // 1. content hashes first: the digest must be known before compression for dedup (content_frame.rs:26-33)
+        engine_.check(zarc_gpu_blake3_batch(engine_.get(), n, content, len, (uint8_t(*)[32])digests.data()));
+        // 2. first occurrence wins -- against frames already written and inside this batch
+        std::vector<size_t> uniq;
+        std::map<Digest, size_t> seen;
+        for (size_t i = 0; i < n; i++) {
+            if (frames_.count(digests[i]) || seen.count(digests[i])) continue; // "frame already exists, skipping"
+            seen.emplace(digests[i], i);
+            uniq.push_back(i);
+        }
+        if (uniq.empty()) return digests;
+        // 3. one fresh session per frame (reset(SessionOnly), content_frame.rs:37-39) == one independent frame each
+        std::vector<const void *> src(uniq.size());
+        std::vector<size_t> slen(uniq.size()), doff(uniq.size()), dlen(uniq.size());
+        size_t cap = 0;
+        for (size_t k = 0; k < uniq.size(); k++) { src[k] = content[uniq[k]]; slen[k] = len[uniq[k]]; cap += zarc_gpu_bound(slen[k]); }
+        std::vector<uint8_t> buffer(cap);
+        std::vector<Digest> d2(uniq.size());
+        std::vector<int> status(uniq.size());
+        engine_.check(zarc_gpu_pack_batch(engine_.get(), uniq.size(), src.data(), slen.data(), buffer.data(), cap, doff.data(), dlen.data(),
+                                          (uint8_t(*)[32])d2.data(), status.data()));
+        // 4. append in call order; offset/length bookkeeping as content_frame.rs:22,45-57
+        for (size_t k = 0; k < uniq.size(); k++) {
+            if (status[k] != ZARC_GPU_FRAME_OK) throw Error(status[k], zarc_gpu_frame_status_name(status[k]));
+            if (!(d2[k] == digests[uniq[k]])) throw Error(ZARC_GPU_E_DEVICE, "digest mismatch between hash and pack passes");
+            Frame f;
+            f.edition = edition_;
+            f.offset = offset_;
+            f.digest = d2[k];
+            f.length = dlen[k];
+            f.uncompressed = slen[k];
+            writer_.write((const char *)buffer.data() + doff[k], (std::streamsize)dlen[k]);
+            if (!writer_) throw Error(ZARC_GPU_E_DEVICE, "write failed");
+            offset_ += dlen[k];
+            frames_.emplace(f.digest, f);
+            order_.push_back(f.digest);
+        }
+        return digests;
+    }
+
+    const std::map<Digest, Frame> &frames() const { return frames_; }
+    const std::vector<Digest> &frame_order() const { return order_; } // insertion order (the reference uses a HashMap)
+    uint64_t offset() const { return offset_; }
+
+  private:
+    std::ostream &writer_;
+    Engine engine_;
+    uint16_t edition_ = 1;
+    std::map<Digest, Frame> frames_;
+    std::vector<Digest> order_;
+    uint64_t offset_ = 0;
+};
+
+// Decoder::read_content_frame + FrameIterator for a batch of frames of one archive image held in memory.
+class FrameReader {
+  public:
+    struct Result {
+        std::vector<uint8_t> data;       // the concatenation of what FrameIterator::next would yield
+        Digest digest;                   // FrameIterator::digest() once the frame is done
+        std::optional<bool> verify;      // FrameIterator::verify(): None if the frame did not decode
+        int status = ZARC_GPU_FRAME_OK;  // Error::Zstd analogue (decode/error.rs:35-38) via zarc_gpu_frame_status_name
+    };
+    explicit FrameReader(int device = 0) : engine_(device) {}
+
+    // `archive` is the whole file; `wanted` are directory records (offset/length/uncompressed/digest).
+    std::vector<Result> read_content_frames(const uint8_t *archive, size_t archive_len, const std::vector<Frame> &wanted)
+    {
+        const size_t n = wanted.size();
+        std::vector<Result> out(n);
+        std::vector<const void *> fp(n);
+        std::vector<void *> dp(n);
+        std::vector<size_t> fl(n), rl(n);
+        std::vector<Digest> expect(n), got(n);
+        std::vector<int> status(n);
+        for (size_t i = 0; i < n; i++) {
+            if (wanted[i].offset + wanted[i].length > archive_len) throw Error(ZARC_GPU_E_PARAM, "frame outside the archive");
+            out[i].data.resize(wanted[i].uncompressed);
+            fp[i] = archive + wanted[i].offset;
+            fl[i] = wanted[i].length;
+            rl[i] = wanted[i].uncompressed;
+            dp[i] = out[i].data.data();
+            expect[i] = wanted[i].digest;
+        }
+        if (n == 0) return out;
+        engine_.check(zarc_gpu_unpack_batch(engine_.get(), n, fp.data(), fl.data(), rl.data(), dp.data(), (const uint8_t(*)[32])expect.data(),
+                                            (uint8_t(*)[32])got.data(), status.data()));
+        for (size_t i = 0; i < n; i++) {
+            out[i].status = status[i];
+            out[i].digest = got[i];
+            const bool decoded = status[i] == ZARC_GPU_FRAME_OK || status[i] == ZARC_GPU_FRAME_DIGEST;
+            if (decoded) out[i].verify = got[i] == expect[i]; // a mismatch is reported, not fatal (zarc-cli/src/unpack.rs:118-120)
+            else out[i].data.clear();
+        }
+        return out;
+    }
+
+  private:
+    Engine engine_;
+};
+
+} // namespace zarc
