@@ -166,6 +166,18 @@ def main():
         dom = max(names, key=lambda i: k_ms[i])
         alg_bytes = raw_bytes + comp_bytes + 32.0 * n
         achieved = alg_bytes / (k_ms[dom] * 1e-3) / 1e9 if k_ms[dom] > 0 else 0.0
+        # HBM traffic of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
+        # runs; FETCH_SIZE doubled per MI355X_MICROARCH.md -- calibrated here on zarc_xxh64, which reads exactly N bytes
+        # and reports N/2), scaled from the profiled batch (2048 x 1 MiB) to this one by uncompressed bytes.
+        traffic, traffic_src = None, None
+        pmc_file = os.path.join(ROOT, "profiles", "r01_bench2048_pmc_summary.json")
+        if os.path.exists(pmc_file):
+            pmc = json.load(open(pmc_file))
+            kname = "zarc_" + names[dom]
+            if kname in pmc.get("fetch", {}) and kname in pmc.get("write", {}):
+                per = (2.0 * pmc["fetch"][kname]["per_dispatch"] + pmc["write"][kname]["per_dispatch"]) * 1024.0
+                traffic = per * raw_bytes / (2048.0 * (1 << 20))
+                traffic_src = "profiles/r01_bench2048_pmc_summary.json, scaled by uncompressed bytes"
         line = {
             "metric": "uncompressed GiB/s (pack) at zstd -3", "value": round(pack_gibs, 3), "unit": "GiB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(tp / args.steps * 1e3, 3),
@@ -180,7 +192,7 @@ def main():
             "unpack_kernel_ms": {"zstd_decode": round(float(u_ms[_lib.T_DECODE]), 3), "xxh64": round(float(u_ms[_lib.T_XXH64]), 3),
                                  "blake3": round(float(u_ms[_lib.T_BLAKE3]), 3)},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(float(k_ms[dom]), 3)},
         }
         if world == 1 and not args.no_cpu_baseline:
