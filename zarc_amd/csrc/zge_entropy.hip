@@ -78,26 +78,37 @@ struct BitW {
 
 struct FseCtab { uint16_t *state_tab; int32_t *dnb; int32_t *dfs; int al; };
 
+// The Huffman-construction arrays are dead once the literals section is coded, and the FSE sequence tables are
+// only needed after it: the two live in a union, which keeps the footprint under 10 KiB (16 waves per CU).
 struct EntLds {
-    uint32_t count[256];
     uint32_t code[256]; // code | len << 16
-    uint32_t w[512];
-    uint16_t parent[512];
-    uint16_t order[256];
-    uint8_t depth[512];
-    uint8_t cellsym[512];
-    uint8_t len8[256], wt[256];
-    uint16_t st_ll[512], st_ml[512], st_of[256], st_w[64];
-    int32_t dnb_ll[36], dfs_ll[36], dnb_ml[53], dfs_ml[53], dnb_of[32], dfs_of[32], dnb_w[16], dfs_w[16];
-    uint32_t cl[36], co[32], cm[53], cw[16];
-    int16_t norm[3][64];
-    int16_t wnorm[16];
-    uint8_t desc[3][80];
-    uint8_t tmp[192], hdesc[192];
     uint32_t stage[224];
-    uint32_t chain[3][64]; // value | nb << 16 for LL / OF / ML transitions of the current 64 sequences
-    uint8_t symc[3][64];   // LL / OF / ML codes of the current 64 sequences
+    uint8_t cellsym[512];
     int32_t ctrl[32];
+    union {
+        struct {
+            uint32_t count[256];
+            uint32_t w[512];
+            uint16_t parent[512];
+            uint16_t order[256];
+            uint8_t depth[512];
+            uint8_t len8[256], wt[256];
+            uint16_t st_w[64];
+            int32_t dnb_w[16], dfs_w[16];
+            uint32_t cw[16];
+            int16_t wnorm[16];
+            uint8_t tmp[192], hdesc[192];
+        } h;
+        struct {
+            uint16_t st_ll[512], st_ml[512], st_of[256];
+            int32_t dnb_ll[36], dfs_ll[36], dnb_ml[53], dfs_ml[53], dnb_of[32], dfs_of[32];
+            uint32_t cl[36], co[32], cm[53];
+            int16_t norm[3][64];
+            uint8_t desc[3][80];
+            uint32_t chain[3][64]; // value | nb << 16 for LL / OF / ML transitions of the current 64 sequences
+            uint8_t symc[3][64];   // LL / OF / ML codes of the current 64 sequences
+        } s;
+    };
 };
 enum { X_TMP = 0, X_DLEN = 1, X_MODE_L = 2, X_MODE_O = 3, X_MODE_M = 4, X_AL_L = 5, X_AL_O = 6, X_AL_M = 7, X_DL_L = 8, X_DL_O = 9,
        X_DL_M = 10, X_RLE_L = 11, X_RLE_O = 12, X_RLE_M = 13, X_NSYM_L = 14, X_NSYM_O = 15, X_NSYM_M = 16, X_MAXBITS = 17, X_NSYM_LAST = 18 };
@@ -220,7 +231,7 @@ __device__ void choose_table(EntLds &L, int which, const uint32_t *count, int ma
 {
     int distinct = 0, last = 0;
     for (int s = 0; s <= maxsym; s++) if (count[s]) { distinct++; last = s; }
-    int16_t *norm = L.norm[which];
+    int16_t *norm = L.s.norm[which];
     if (distinct == 1) { L.ctrl[X_MODE_L + which] = 1; L.ctrl[X_RLE_L + which] = last; L.ctrl[X_DL_L + which] = 0; return; }
     uint64_t cost_def = ~0ull;
     if (last < def_n) {
@@ -234,7 +245,7 @@ __device__ void choose_table(EntLds &L, int which, const uint32_t *count, int ma
     while ((1 << al) < distinct) al++;
     const int nsym = last + 1;
     fse_normalize(count, nsym, nseq, al, norm);
-    const uint32_t dl = fse_write_desc(L.desc[which], 80, norm, nsym, al);
+    const uint32_t dl = fse_write_desc(L.s.desc[which], 80, norm, nsym, al);
     const uint64_t cost_dyn = dl ? dist_cost(count, norm, nsym, al) + (uint64_t)dl * 8 * 256 : ~0ull;
     if (cost_def <= cost_dyn) {
         for (int s = 0; s < def_n; s++) norm[s] = def[s];
@@ -245,7 +256,7 @@ __device__ void choose_table(EntLds &L, int which, const uint32_t *count, int ma
 }
 
 // ---- Huffman construction (lane 0 for the serial parts) ----
-// L.count -> L.len8 (code lengths).  Uniform; returns number of present symbols.
+// L.h.count -> L.h.len8 (code lengths).  Uniform; returns number of present symbols.
 __device__ int huf_build_lengths(EntLds &L, int lane)
 {
     // rank by counting: order ascending by (count, symbol)
@@ -253,38 +264,38 @@ __device__ int huf_build_lengths(EntLds &L, int lane)
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int s = r * 64 + lane;
-        const uint32_t c = L.count[s];
-        L.len8[s] = 0;
+        const uint32_t c = L.h.count[s];
+        L.h.len8[s] = 0;
         if (c) {
             uint32_t rank = 0;
             for (int t = 0; t < 256; t++) {
-                const uint32_t ct = L.count[t];
+                const uint32_t ct = L.h.count[t];
                 rank += (ct != 0 && (ct < c || (ct == c && t < s))) ? 1u : 0u;
             }
-            L.order[rank] = (uint16_t)s;
+            L.h.order[rank] = (uint16_t)s;
         }
         present += (uint32_t)__popcll(zd::ballot(c != 0));
     }
     zd::wave_sync();
     const int n = (int)present;
-    if (n < 2) { if (n == 1 && lane == 0) L.len8[L.order[0]] = 1; zd::wave_sync(); return n; }
+    if (n < 2) { if (n == 1 && lane == 0) L.h.len8[L.h.order[0]] = 1; zd::wave_sync(); return n; }
     if (lane == 0) {
-        for (int i = 0; i < n; i++) L.w[i] = L.count[L.order[i]];
+        for (int i = 0; i < n; i++) L.h.w[i] = L.h.count[L.h.order[i]];
         int leaf = 0, inode = n, next = n;
         while (next < 2 * n - 1) {
             int a, b;
-            if (leaf < n && (inode >= next || L.w[leaf] <= L.w[inode])) a = leaf++; else a = inode++;
-            if (leaf < n && (inode >= next || L.w[leaf] <= L.w[inode])) b = leaf++; else b = inode++;
-            L.w[next] = L.w[a] + L.w[b];
-            L.parent[a] = (uint16_t)next;
-            L.parent[b] = (uint16_t)next;
+            if (leaf < n && (inode >= next || L.h.w[leaf] <= L.h.w[inode])) a = leaf++; else a = inode++;
+            if (leaf < n && (inode >= next || L.h.w[leaf] <= L.h.w[inode])) b = leaf++; else b = inode++;
+            L.h.w[next] = L.h.w[a] + L.h.w[b];
+            L.h.parent[a] = (uint16_t)next;
+            L.h.parent[b] = (uint16_t)next;
             next++;
         }
-        L.depth[2 * n - 2] = 0;
-        for (int i = 2 * n - 3; i >= 0; i--) { const int d = L.depth[L.parent[i]] + 1; L.depth[i] = (uint8_t)(d > 63 ? 63 : d); }
+        L.h.depth[2 * n - 2] = 0;
+        for (int i = 2 * n - 3; i >= 0; i--) { const int d = L.h.depth[L.h.parent[i]] + 1; L.h.depth[i] = (uint8_t)(d > 63 ? 63 : d); }
         int num[64];
         for (int k = 0; k < 64; k++) num[k] = 0;
-        for (int i = 0; i < n; i++) num[L.depth[i]]++;
+        for (int i = 0; i < n; i++) num[L.h.depth[i]]++;
         for (int k = HUF_MAXBITS + 1; k < 64; k++) { num[HUF_MAXBITS] += num[k]; num[k] = 0; }
         uint32_t total = 0;
         for (int k = 1; k <= HUF_MAXBITS; k++) total += (uint32_t)num[k] << (HUF_MAXBITS - k);
@@ -294,7 +305,7 @@ __device__ int huf_build_lengths(EntLds &L, int lane)
             total--;
         }
         int i = n - 1;
-        for (int k = 1; k <= HUF_MAXBITS; k++) for (int c = 0; c < num[k]; c++) L.len8[L.order[i--]] = (uint8_t)k;
+        for (int k = 1; k <= HUF_MAXBITS; k++) for (int c = 0; c < num[k]; c++) L.h.len8[L.h.order[i--]] = (uint8_t)k;
     }
     zd::wave_sync();
     return n;
@@ -304,71 +315,71 @@ __device__ int huf_build_lengths(EntLds &L, int lane)
 __device__ void huf_assign_codes(EntLds &L)
 {
     int maxlen = 0, last = 0;
-    for (int i = 0; i < 256; i++) if (L.len8[i]) { if (L.len8[i] > maxlen) maxlen = L.len8[i]; last = i; }
+    for (int i = 0; i < 256; i++) if (L.h.len8[i]) { if (L.h.len8[i] > maxlen) maxlen = L.h.len8[i]; last = i; }
     uint32_t rank_start[16], rank_count[16];
     for (int w = 0; w < 16; w++) rank_count[w] = 0;
-    for (int i = 0; i < 256; i++) if (L.len8[i]) rank_count[maxlen + 1 - L.len8[i]]++;
+    for (int i = 0; i < 256; i++) if (L.h.len8[i]) rank_count[maxlen + 1 - L.h.len8[i]]++;
     uint32_t pos = 0;
     for (int w = 1; w <= maxlen; w++) { rank_start[w] = pos; pos += rank_count[w] << (w - 1); }
     for (int i = 0; i < 256; i++) {
-        if (!L.len8[i]) { L.code[i] = 0; continue; }
-        const int w = maxlen + 1 - L.len8[i];
-        L.code[i] = (rank_start[w] >> (w - 1)) | ((uint32_t)L.len8[i] << 16);
+        if (!L.h.len8[i]) { L.code[i] = 0; continue; }
+        const int w = maxlen + 1 - L.h.len8[i];
+        L.code[i] = (rank_start[w] >> (w - 1)) | ((uint32_t)L.h.len8[i] << 16);
         rank_start[w] += 1u << (w - 1);
     }
     L.ctrl[X_MAXBITS] = maxlen;
     L.ctrl[X_NSYM_LAST] = last;
 }
 
-// lane 0: Huffman tree description into L.hdesc; returns its length (0 = not representable)
+// lane 0: Huffman tree description into L.h.hdesc; returns its length (0 = not representable)
 __device__ uint32_t huf_write_desc(EntLds &L)
 {
     const int n = L.ctrl[X_NSYM_LAST], max_bits = L.ctrl[X_MAXBITS];
-    for (int i = 0; i < n; i++) L.wt[i] = L.len8[i] ? (uint8_t)(max_bits + 1 - L.len8[i]) : 0;
+    for (int i = 0; i < n; i++) L.h.wt[i] = L.h.len8[i] ? (uint8_t)(max_bits + 1 - L.h.len8[i]) : 0;
     if (n > 1) {
-        for (int s = 0; s < 16; s++) L.cw[s] = 0;
-        for (int i = 0; i < n; i++) L.cw[L.wt[i]]++;
+        for (int s = 0; s < 16; s++) L.h.cw[s] = 0;
+        for (int i = 0; i < n; i++) L.h.cw[L.h.wt[i]]++;
         int nsym = 0, distinct = 0, al = 6;
         uint32_t maxc = 0;
-        for (int s = 0; s < 13; s++) if (L.cw[s]) { nsym = s + 1; distinct++; if (L.cw[s] > maxc) maxc = L.cw[s]; }
+        for (int s = 0; s < 13; s++) if (L.h.cw[s]) { nsym = s + 1; distinct++; if (L.h.cw[s] > maxc) maxc = L.h.cw[s]; }
         if (distinct > 1 && maxc > 1) {
             { int lim = zd::hb32((uint32_t)(n - 1)) - 2; if (lim < al) al = lim; if (al < 5) al = 5; }
             while ((1 << al) < distinct) al++;
-            fse_normalize(L.cw, nsym, (uint32_t)n, al, L.wnorm);
-            const uint32_t hdr = fse_write_desc(L.tmp, 192, L.wnorm, nsym, al);
+            fse_normalize(L.h.cw, nsym, (uint32_t)n, al, L.h.wnorm);
+            const uint32_t hdr = fse_write_desc(L.h.tmp, 192, L.h.wnorm, nsym, al);
             if (hdr) {
-                FseCtab ct = {L.st_w, L.dnb_w, L.dfs_w, 0};
-                fse_build_ctab(ct, L.wnorm, nsym, al, L.cellsym);
+                FseCtab ct = {L.h.st_w, L.h.dnb_w, L.h.dfs_w, 0};
+                fse_build_ctab(ct, L.h.wnorm, nsym, al, L.cellsym);
                 BitW b;
-                b.init(L.tmp + hdr, 192 - hdr);
+                b.init(L.h.tmp + hdr, 192 - hdr);
                 uint32_t s1, s2, bits;
                 int ip = n;
                 if (n & 1) {
-                    s1 = fse_init_state(ct, L.wt[--ip]);
-                    s2 = fse_init_state(ct, L.wt[--ip]);
-                    s1 = fse_step(ct, s1, L.wt[--ip], &bits); b.add(bits & 0xFFFF, (int)(bits >> 16));
+                    s1 = fse_init_state(ct, L.h.wt[--ip]);
+                    s2 = fse_init_state(ct, L.h.wt[--ip]);
+                    s1 = fse_step(ct, s1, L.h.wt[--ip], &bits); b.add(bits & 0xFFFF, (int)(bits >> 16));
                 } else {
-                    s2 = fse_init_state(ct, L.wt[--ip]);
-                    s1 = fse_init_state(ct, L.wt[--ip]);
+                    s2 = fse_init_state(ct, L.h.wt[--ip]);
+                    s1 = fse_init_state(ct, L.h.wt[--ip]);
                 }
                 while (ip > 0) {
-                    s2 = fse_step(ct, s2, L.wt[--ip], &bits); b.add(bits & 0xFFFF, (int)(bits >> 16));
-                    s1 = fse_step(ct, s1, L.wt[--ip], &bits); b.add(bits & 0xFFFF, (int)(bits >> 16));
+                    s2 = fse_step(ct, s2, L.h.wt[--ip], &bits); b.add(bits & 0xFFFF, (int)(bits >> 16));
+                    s1 = fse_step(ct, s1, L.h.wt[--ip], &bits); b.add(bits & 0xFFFF, (int)(bits >> 16));
                 }
                 b.add(s2, al);
                 b.add(s1, al);
                 const uint32_t body = b.close();
                 if (!b.overflow && hdr + body < 128 && (n > 128 || hdr + body < (uint32_t)(n + 1) / 2)) {
-                    L.hdesc[0] = (uint8_t)(hdr + body);
-                    for (uint32_t i = 0; i < hdr + body; i++) L.hdesc[1 + i] = L.tmp[i];
+                    L.h.hdesc[0] = (uint8_t)(hdr + body);
+                    for (uint32_t i = 0; i < hdr + body; i++) L.h.hdesc[1 + i] = L.h.tmp[i];
                     return 1 + hdr + body;
                 }
             }
         }
     }
     if (n > 128) return 0;
-    L.hdesc[0] = (uint8_t)(127 + n);
-    for (int i = 0; i < n; i += 2) L.hdesc[1 + i / 2] = (uint8_t)((L.wt[i] << 4) | (i + 1 < n ? L.wt[i + 1] : 0));
+    L.h.hdesc[0] = (uint8_t)(127 + n);
+    for (int i = 0; i < n; i += 2) L.h.hdesc[1 + i / 2] = (uint8_t)((L.h.wt[i] << 4) | (i + 1 < n ? L.h.wt[i + 1] : 0));
     return (uint32_t)(1 + (n + 1) / 2);
 }
 
@@ -454,13 +465,13 @@ __global__ void __launch_bounds__(64) zarc_zge_entropy(uint32_t n_blocks, ZgeBlo
     {
         const uint32_t n = nlit;
         const uint32_t raw_hdr = n < 32 ? 1u : (n < 4096 ? 2u : 3u);
-        for (int i = lane; i < 256; i += 64) L.count[i] = 0;
+        for (int i = lane; i < 256; i += 64) L.h.count[i] = 0;
         zd::wave_sync();
-        for (uint32_t i = (uint32_t)lane; i < n; i += 64) atomicAdd(&L.count[lit[i]], 1u);
+        for (uint32_t i = (uint32_t)lane; i < n; i += 64) atomicAdd(&L.h.count[lit[i]], 1u);
         zd::wave_sync();
         uint32_t distinct = 0;
 #pragma unroll
-        for (int r = 0; r < 4; r++) distinct += (uint32_t)__popcll(zd::ballot(L.count[r * 64 + lane] != 0));
+        for (int r = 0; r < 4; r++) distinct += (uint32_t)__popcll(zd::ballot(L.h.count[r * 64 + lane] != 0));
         int kind = 0; // 0 raw, 1 rle, 2 huffman
         if (n >= 2 && distinct == 1) kind = 1;
         else if (n >= MIN_HUF_LITERALS && distinct >= 2) {
@@ -469,7 +480,7 @@ __global__ void __launch_bounds__(64) zarc_zge_entropy(uint32_t n_blocks, ZgeBlo
                 huf_assign_codes(L);
                 const uint32_t dlen = huf_write_desc(L);
                 uint64_t est_bits = 0;
-                for (int i = 0; i < 256; i++) est_bits += (uint64_t)L.count[i] * L.len8[i];
+                for (int i = 0; i < 256; i++) est_bits += (uint64_t)L.h.count[i] * L.h.len8[i];
                 const uint64_t est = dlen + (est_bits + 7) / 8 + (n >= 256 ? 10 : 1);
                 L.ctrl[X_DLEN] = (dlen && est + 3 < n) ? (int)dlen : 0;
             }
@@ -480,7 +491,7 @@ __global__ void __launch_bounds__(64) zarc_zge_entropy(uint32_t n_blocks, ZgeBlo
                 const bool single = n < 256;
                 const uint32_t hdr = single ? 3u : (n < 1024 ? 3u : (n < 16384 ? 4u : 5u));
                 uint8_t *body = out + hdr;
-                for (uint32_t i = (uint32_t)lane; i < dlen; i += 64) body[i] = L.hdesc[i];
+                for (uint32_t i = (uint32_t)lane; i < dlen; i += 64) body[i] = L.h.hdesc[i];
                 uint32_t pos = dlen, ssz[4] = {0, 0, 0, 0};
                 const uint32_t nstreams = single ? 1u : 4u, per = single ? n : (n + 3) / 4, jt = pos;
                 if (!single) pos += 6;
@@ -552,14 +563,14 @@ __global__ void __launch_bounds__(64) zarc_zge_entropy(uint32_t n_blocks, ZgeBlo
             if (lane == 0) prev = carry;
             const uint32_t ll = litpos - prev;
             carry = zd::uniform(zd::shfl(litpos, (int)cnt - 1));
-            L.chain[0][lane] = off;
-            L.chain[1][lane] = ll;
+            L.s.chain[0][lane] = off;
+            L.s.chain[1][lane] = ll;
             zd::wave_sync();
             if (lane == 0) {
                 for (uint32_t e = 0; e < cnt; e++) {
-                    const uint32_t o = L.chain[0][e];
+                    const uint32_t o = L.s.chain[0][e];
                     uint32_t ofv;
-                    if (L.chain[1][e] > 0) {
+                    if (L.s.chain[1][e] > 0) {
                         if (o == r0) ofv = 1;
                         else if (o == r1) { ofv = 2; r1 = r0; r0 = o; }
                         else if (o == r2) { ofv = 3; r2 = r1; r1 = r0; r0 = o; }
@@ -570,11 +581,11 @@ __global__ void __launch_bounds__(64) zarc_zge_entropy(uint32_t n_blocks, ZgeBlo
                         else if (r0 > 1 && o == r0 - 1) { ofv = 3; r2 = r1; r1 = r0; r0 = o; }
                         else { ofv = o + 3; r2 = r1; r1 = r0; r0 = o; }
                     }
-                    L.chain[2][e] = ofv;
+                    L.s.chain[2][e] = ofv;
                 }
             }
             zd::wave_sync();
-            if (valid) seq[base + (uint32_t)lane] = zge_pack_seq(ll, ml, L.chain[2][lane]);
+            if (valid) seq[base + (uint32_t)lane] = zge_pack_seq(ll, ml, L.s.chain[2][lane]);
             zd::wave_sync();
         }
         zd::wave_sync_global(); // the coding passes below read seq[] with a different lane mapping
@@ -594,25 +605,25 @@ __global__ void __launch_bounds__(64) zarc_zge_entropy(uint32_t n_blocks, ZgeBlo
         pos = nseq < 128 ? 1u : (nseq < 0x7F00 ? 2u : 3u);
         if (nseq == 0) ssz = pos;
         else {
-            for (int i = lane; i < 36; i += 64) L.cl[i] = 0;
-            for (int i = lane; i < 32; i += 64) L.co[i] = 0;
-            for (int i = lane; i < 53; i += 64) L.cm[i] = 0;
+            for (int i = lane; i < 36; i += 64) L.s.cl[i] = 0;
+            for (int i = lane; i < 32; i += 64) L.s.co[i] = 0;
+            for (int i = lane; i < 53; i += 64) L.s.cm[i] = 0;
             zd::wave_sync();
             for (uint32_t i = (uint32_t)lane; i < nseq; i += 64) {
                 const uint64_t s = seq[i];
-                atomicAdd(&L.cl[ll_code(zge_seq_ll(s))], 1u);
-                atomicAdd(&L.cm[ml_code(zge_seq_ml(s))], 1u);
-                atomicAdd(&L.co[zd::hb32(zge_seq_ofv(s))], 1u);
+                atomicAdd(&L.s.cl[ll_code(zge_seq_ll(s))], 1u);
+                atomicAdd(&L.s.cm[ml_code(zge_seq_ml(s))], 1u);
+                atomicAdd(&L.s.co[zd::hb32(zge_seq_ofv(s))], 1u);
             }
             zd::wave_sync();
             if (lane == 0) {
-                choose_table(L, 0, L.cl, 35, nseq, E_LL_DEFAULT, 36, 6, 9);
-                choose_table(L, 1, L.co, 31, nseq, E_OF_DEFAULT, 29, 5, 8);
-                choose_table(L, 2, L.cm, 52, nseq, E_ML_DEFAULT, 53, 6, 9);
-                FseCtab tl_ = {L.st_ll, L.dnb_ll, L.dfs_ll, 0}, to_ = {L.st_of, L.dnb_of, L.dfs_of, 0}, tm_ = {L.st_ml, L.dnb_ml, L.dfs_ml, 0};
-                if (L.ctrl[X_MODE_L] != 1) fse_build_ctab(tl_, L.norm[0], L.ctrl[X_NSYM_L], L.ctrl[X_AL_L], L.cellsym);
-                if (L.ctrl[X_MODE_O] != 1) fse_build_ctab(to_, L.norm[1], L.ctrl[X_NSYM_O], L.ctrl[X_AL_O], L.cellsym);
-                if (L.ctrl[X_MODE_M] != 1) fse_build_ctab(tm_, L.norm[2], L.ctrl[X_NSYM_M], L.ctrl[X_AL_M], L.cellsym);
+                choose_table(L, 0, L.s.cl, 35, nseq, E_LL_DEFAULT, 36, 6, 9);
+                choose_table(L, 1, L.s.co, 31, nseq, E_OF_DEFAULT, 29, 5, 8);
+                choose_table(L, 2, L.s.cm, 52, nseq, E_ML_DEFAULT, 53, 6, 9);
+                FseCtab tl_ = {L.s.st_ll, L.s.dnb_ll, L.s.dfs_ll, 0}, to_ = {L.s.st_of, L.s.dnb_of, L.s.dfs_of, 0}, tm_ = {L.s.st_ml, L.s.dnb_ml, L.s.dfs_ml, 0};
+                if (L.ctrl[X_MODE_L] != 1) fse_build_ctab(tl_, L.s.norm[0], L.ctrl[X_NSYM_L], L.ctrl[X_AL_L], L.cellsym);
+                if (L.ctrl[X_MODE_O] != 1) fse_build_ctab(to_, L.s.norm[1], L.ctrl[X_NSYM_O], L.ctrl[X_AL_O], L.cellsym);
+                if (L.ctrl[X_MODE_M] != 1) fse_build_ctab(tm_, L.s.norm[2], L.ctrl[X_NSYM_M], L.ctrl[X_AL_M], L.cellsym);
             }
             zd::wave_sync();
             const int mode_l = L.ctrl[X_MODE_L], mode_o = L.ctrl[X_MODE_O], mode_m = L.ctrl[X_MODE_M];
@@ -623,17 +634,17 @@ __global__ void __launch_bounds__(64) zarc_zge_entropy(uint32_t n_blocks, ZgeBlo
                 if (lane == 0) {
                     so[pos] = (uint8_t)((mode_l << 6) | (mode_o << 4) | (mode_m << 2));
                     uint32_t q = pos + 1;
-                    if (mode_l == 1) so[q++] = (uint8_t)L.ctrl[X_RLE_L]; else for (uint32_t i = 0; i < dl_l; i++) so[q++] = L.desc[0][i];
-                    if (mode_o == 1) so[q++] = (uint8_t)L.ctrl[X_RLE_O]; else for (uint32_t i = 0; i < dl_o; i++) so[q++] = L.desc[1][i];
-                    if (mode_m == 1) so[q++] = (uint8_t)L.ctrl[X_RLE_M]; else for (uint32_t i = 0; i < dl_m; i++) so[q++] = L.desc[2][i];
+                    if (mode_l == 1) so[q++] = (uint8_t)L.ctrl[X_RLE_L]; else for (uint32_t i = 0; i < dl_l; i++) so[q++] = L.s.desc[0][i];
+                    if (mode_o == 1) so[q++] = (uint8_t)L.ctrl[X_RLE_O]; else for (uint32_t i = 0; i < dl_o; i++) so[q++] = L.s.desc[1][i];
+                    if (mode_m == 1) so[q++] = (uint8_t)L.ctrl[X_RLE_M]; else for (uint32_t i = 0; i < dl_m; i++) so[q++] = L.s.desc[2][i];
                 }
                 pos += 1 + (mode_l == 1 ? 1u : dl_l) + (mode_o == 1 ? 1u : dl_o) + (mode_m == 1 ? 1u : dl_m);
                 // FSE state chains: lane 0 = LL, lane 1 = OF, lane 2 = ML; 64 sequences per round, last -> first
                 FseCtab ct;
                 int my_mode = 1;
-                if (lane == 0) { ct = FseCtab{L.st_ll, L.dnb_ll, L.dfs_ll, al_l}; my_mode = mode_l; }
-                else if (lane == 1) { ct = FseCtab{L.st_of, L.dnb_of, L.dfs_of, al_o}; my_mode = mode_o; }
-                else { ct = FseCtab{L.st_ml, L.dnb_ml, L.dfs_ml, al_m}; my_mode = lane == 2 ? mode_m : 1; }
+                if (lane == 0) { ct = FseCtab{L.s.st_ll, L.s.dnb_ll, L.s.dfs_ll, al_l}; my_mode = mode_l; }
+                else if (lane == 1) { ct = FseCtab{L.s.st_of, L.s.dnb_of, L.s.dfs_of, al_o}; my_mode = mode_o; }
+                else { ct = FseCtab{L.s.st_ml, L.s.dnb_ml, L.s.dfs_ml, al_m}; my_mode = lane == 2 ? mode_m : 1; }
                 uint32_t state = 0;
                 WavePacker pk;
                 pk.begin(L.stage, so + pos, scap - pos, lane);
@@ -645,25 +656,25 @@ __global__ void __launch_bounds__(64) zarc_zge_entropy(uint32_t n_blocks, ZgeBlo
                         const uint64_t s = seq[nseq - 1 - done - (uint32_t)lane];
                         ll = zge_seq_ll(s); ml = zge_seq_ml(s); ofv = zge_seq_ofv(s);
                         llc = ll_code(ll); mlc = ml_code(ml); ofc = (uint32_t)zd::hb32(ofv);
-                        L.symc[0][lane] = (uint8_t)llc; L.symc[1][lane] = (uint8_t)ofc; L.symc[2][lane] = (uint8_t)mlc;
+                        L.s.symc[0][lane] = (uint8_t)llc; L.s.symc[1][lane] = (uint8_t)ofc; L.s.symc[2][lane] = (uint8_t)mlc;
                     }
                     zd::wave_sync();
                     if (lane < 3) {
                         for (uint32_t e = 0; e < cnt; e++) {
-                            const int sym = L.symc[lane][e];
+                            const int sym = L.s.symc[lane][e];
                             uint32_t bits = 0;
                             if (my_mode != 1) {
                                 if (done + e == 0) state = fse_init_state(ct, sym);
                                 else state = fse_step(ct, state, sym, &bits);
                             }
-                            L.chain[lane][e] = bits;
+                            L.s.chain[lane][e] = bits;
                         }
                     }
                     zd::wave_sync();
                     uint64_t lo = 0;
                     uint32_t hi = 0, nb = 0;
                     if ((uint32_t)lane < cnt) {
-                        const uint32_t bo = L.chain[1][lane], bm = L.chain[2][lane], bl = L.chain[0][lane];
+                        const uint32_t bo = L.s.chain[1][lane], bm = L.s.chain[2][lane], bl = L.s.chain[0][lane];
                         // order: OF state bits, ML state bits, LL state bits, LL extra, ML extra, OF extra
                         uint64_t acc = bo & 0xFFFF; uint32_t sh = bo >> 16;
                         acc |= (uint64_t)(bm & 0xFFFF) << sh; sh += bm >> 16;

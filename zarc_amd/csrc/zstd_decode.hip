@@ -19,7 +19,7 @@
 namespace {
 
 constexpr int BLOCK_MAX = 128 * 1024;
-constexpr int SEQ_BATCH = 32;
+constexpr int SEQ_BATCH = 64;
 
 __constant__ const uint32_t D_LL_BASE[36] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18,
                                              20, 22, 24, 28, 32, 40, 48, 64, 128, 256, 512, 1024, 2048,
@@ -171,6 +171,7 @@ struct Lds {
     uint16_t next[64];
     uint32_t wtab[64];    // FSE table for Huffman weights (accuracy <= 6)
     uint32_t seq[SEQ_BATCH * 3];
+    uint32_t llx[36], mlx[53]; // code -> baseline | extra bits << 24 (LDS copies: a VGPR-indexed __constant__ read is a global load)
     int32_t ctrl[16];
 };
 enum { C_ERR = 0, C_HUF_BITS = 1, C_HUF_VALID = 2, C_LL_AL = 3, C_OF_AL = 4, C_ML_AL = 5, C_LL_OK = 6, C_OF_OK = 7, C_ML_OK = 8,
@@ -363,6 +364,8 @@ __global__ void __launch_bounds__(64) zarc_zstd_decode(const uint8_t *__restrict
     if (lane == 0) {
         for (int i = 0; i < 16; i++) L.ctrl[i] = 0;
     }
+    if (lane < 36) L.llx[lane] = D_LL_BASE[lane] | ((uint32_t)D_LL_BITS[lane] << 24);
+    if (lane < 53) L.mlx[lane] = D_ML_BASE[lane] | ((uint32_t)D_ML_BITS[lane] << 24);
     zd::wave_sync();
 
     // ---- frame header (every lane computes the same values) ----
@@ -538,7 +541,6 @@ __global__ void __launch_bounds__(64) zarc_zstd_decode(const uint8_t *__restrict
                 if (okb) { sl = b.read(al_l); so = b.read(al_o); sm = b.read(al_m); okb = b.bitpos >= 0; }
             }
             if (zd::ballot(!okb) != 0) { err = ZARC_FRAME_CORRUPT; break; }
-            uint64_t fenced = opos; // output bytes below this are known visible to every lane
             for (uint32_t base = 0; base < nseq && !err; base += SEQ_BATCH) {
                 const uint32_t cnt = nseq - base < SEQ_BATCH ? nseq - base : SEQ_BATCH;
                 if (lane == 0) {
@@ -547,8 +549,9 @@ __global__ void __launch_bounds__(64) zarc_zstd_decode(const uint8_t *__restrict
                         const uint32_t ofc = cell_sym(co), mlc = cell_sym(cm), llc = cell_sym(cl);
                         if (ofc > 31 || mlc > 52 || llc > 35) { okb = false; break; }
                         const uint32_t ofv = (1u << ofc) + b.read((int)ofc);
-                        const uint32_t ml = D_ML_BASE[mlc] + b.read(D_ML_BITS[mlc]);
-                        const uint32_t ll = D_LL_BASE[llc] + b.read(D_LL_BITS[llc]);
+                        const uint32_t mx = L.mlx[mlc], lx = L.llx[llc];
+                        const uint32_t ml = (mx & 0xFFFFFF) + b.read((int)(mx >> 24));
+                        const uint32_t ll = (lx & 0xFFFFFF) + b.read((int)(lx >> 24));
                         uint32_t offset;
                         if (ofv > 3) { offset = ofv - 3; rep2 = rep1; rep1 = rep0; rep0 = offset; }
                         else {
@@ -573,25 +576,96 @@ __global__ void __launch_bounds__(64) zarc_zstd_decode(const uint8_t *__restrict
                 }
                 zd::wave_sync();
                 if (zd::ballot(!okb) != 0) { err = ZARC_FRAME_CORRUPT; break; }
-                for (uint32_t i = 0; i < cnt; i++) {
-                    const uint32_t ll = L.seq[i * 3], ml = L.seq[i * 3 + 1], offset = L.seq[i * 3 + 2];
-                    if (lp + ll > lit_len) { err = ZARC_FRAME_CORRUPT; break; }
-                    if (opos + ll + ml > cap) { err = ZARC_FRAME_DSTSIZE; break; }
-                    if (lit_rle) { for (uint32_t k = (uint32_t)lane; k < ll; k += 64) out[opos + k] = lit_rle_byte; }
-                    else wave_copy(out + opos, lit + lp, ll, lane);
-                    lp += ll;
-                    opos += ll;
-                    if (offset > opos) { err = ZARC_FRAME_CORRUPT; break; }
-                    const uint64_t mstart = opos - offset;
-                    const uint64_t send = mstart + ml < opos ? mstart + ml : opos;
-                    if (send > fenced) { zd::wave_sync_global(); fenced = opos; }
-                    // all reads come from below the match start: byte i <- source[i mod offset]
-                    for (uint32_t k = (uint32_t)lane; k < ml; k += 64) {
-                        uint32_t j = k;
-                        if (j >= offset) j = j % offset;
-                        out[opos + k] = out[mstart + j];
+                // ---- execute the batch: lane i does the bookkeeping of sequence i; copies of different sequences
+                // are independent unless a match source reaches into this batch's own output ("near" matches) ----
+                {
+                    const bool have = (uint32_t)lane < cnt;
+                    const uint32_t ll = have ? L.seq[lane * 3] : 0u, ml = have ? L.seq[lane * 3 + 1] : 0u;
+                    const uint32_t offset = have ? L.seq[lane * 3 + 2] : 1u;
+                    const uint32_t incl_ll = zd::wave_scan_incl(ll), incl_all = zd::wave_scan_incl(ll + ml);
+                    const uint32_t tot_ll = zd::uniform(zd::shfl(incl_ll, 63)), tot_all = zd::uniform(zd::shfl(incl_all, 63));
+                    if (lp + tot_ll > lit_len) { err = ZARC_FRAME_CORRUPT; break; }
+                    if (opos + tot_all > cap) { err = ZARC_FRAME_DSTSIZE; break; }
+                    const uint32_t bpos = (uint32_t)opos;                      // output position where this batch starts
+                    const uint32_t dlit = bpos + (incl_all - ll - ml);         // this sequence's literals go here
+                    const uint32_t dmat = dlit + ll;                           // and its match here
+                    const uint32_t slit = lp + (incl_ll - ll);                 // its first literal
+                    if (zd::ballot(have && offset > dmat) != 0) { err = ZARC_FRAME_CORRUPT; break; }
+                    const uint32_t msrc = dmat - offset;
+                    const bool far = have && msrc + ml <= bpos;                // source entirely below this batch's output
+                    // (1) literal runs: short ones one lane per sequence (4 bytes in flight per lane), long ones wave-wide
+                    {
+                        const uint32_t ns = ll <= 16 ? ll : 0u;
+                        for (uint32_t r = 0; r < 16; r += 4) {
+                            if (zd::ballot(ns > r) == 0) break;
+                            uint8_t v0 = lit_rle_byte, v1 = lit_rle_byte, v2 = lit_rle_byte, v3 = lit_rle_byte;
+                            if (!lit_rle) {
+                                if (r < ns) v0 = lit[slit + r];
+                                if (r + 1 < ns) v1 = lit[slit + r + 1];
+                                if (r + 2 < ns) v2 = lit[slit + r + 2];
+                                if (r + 3 < ns) v3 = lit[slit + r + 3];
+                            }
+                            if (r < ns) out[dlit + r] = v0;
+                            if (r + 1 < ns) out[dlit + r + 1] = v1;
+                            if (r + 2 < ns) out[dlit + r + 2] = v2;
+                            if (r + 3 < ns) out[dlit + r + 3] = v3;
+                        }
+                        uint64_t longs = zd::ballot(ll > 16);
+                        while (longs) {
+                            const int i = zd::ctz64(longs);
+                            longs &= longs - 1;
+                            const uint32_t n_ = zd::readlane(ll, (uint32_t)i), d_ = zd::readlane(dlit, (uint32_t)i), s_ = zd::readlane(slit, (uint32_t)i);
+                            if (lit_rle) { for (uint32_t k = (uint32_t)lane; k < n_; k += 64) out[d_ + k] = lit_rle_byte; }
+                            else wave_copy(out + d_, lit + s_, n_, lane);
+                        }
                     }
-                    opos += ml;
+                    // (2) far matches: no dependence on this batch (and no self-overlap: offset >= length)
+                    {
+                        const uint32_t ns = (far && ml <= 32) ? ml : 0u;
+                        for (uint32_t r = 0; r < 32; r += 4) {
+                            if (zd::ballot(ns > r) == 0) break;
+                            uint8_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+                            if (r < ns) v0 = out[msrc + r];
+                            if (r + 1 < ns) v1 = out[msrc + r + 1];
+                            if (r + 2 < ns) v2 = out[msrc + r + 2];
+                            if (r + 3 < ns) v3 = out[msrc + r + 3];
+                            if (r < ns) out[dmat + r] = v0;
+                            if (r + 1 < ns) out[dmat + r + 1] = v1;
+                            if (r + 2 < ns) out[dmat + r + 2] = v2;
+                            if (r + 3 < ns) out[dmat + r + 3] = v3;
+                        }
+                        uint64_t longs = zd::ballot(far && ml > 32);
+                        while (longs) {
+                            const int i = zd::ctz64(longs);
+                            longs &= longs - 1;
+                            const uint32_t n_ = zd::readlane(ml, (uint32_t)i), d_ = zd::readlane(dmat, (uint32_t)i), s_ = zd::readlane(msrc, (uint32_t)i);
+                            wave_copy(out + d_, out + s_, n_, lane);
+                        }
+                    }
+                    // (3) near matches, in order; their sources may be bytes written above or by earlier near matches
+                    uint64_t near = zd::ballot(have && !far);
+                    if (near) {
+                        zd::wave_sync_global();
+                        uint32_t unfenced_lo = 0xFFFFFFFFu; // lowest output byte written by a near match since the last fence
+                        while (near) {
+                            const int i = zd::ctz64(near);
+                            near &= near - 1;
+                            const uint32_t n_ = zd::readlane(ml, (uint32_t)i), d_ = zd::readlane(dmat, (uint32_t)i), o_ = zd::readlane(offset, (uint32_t)i);
+                            const uint32_t s_ = d_ - o_;
+                            const uint32_t send = s_ + n_ < d_ ? s_ + n_ : d_;
+                            if (send > unfenced_lo) { zd::wave_sync_global(); unfenced_lo = 0xFFFFFFFFu; }
+                            // all reads come from below the match start: byte k <- source[k mod offset]
+                            for (uint32_t k = (uint32_t)lane; k < n_; k += 64) {
+                                uint32_t j = k;
+                                if (j >= o_) j = j % o_;
+                                out[d_ + k] = out[s_ + j];
+                            }
+                            if (d_ < unfenced_lo) unfenced_lo = d_;
+                        }
+                    }
+                    zd::wave_sync_global(); // later batches may copy from anything written here
+                    lp += tot_ll;
+                    opos += tot_all;
                 }
                 zd::wave_sync(); // L.seq is rewritten by lane 0 in the next batch
             }
