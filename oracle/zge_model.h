@@ -22,6 +22,7 @@ typedef struct {
     int min_match, min_rep, rep_search, back_cap, lazy, lazy_delta;
     int lit_cost, match_cost, rep_cost;
     int short_window_log; /* reach of the short-hash table (16 when its entries are u16) */
+    int rep_back; /* recent-offset guesses must start at most this many bytes before the tile */
     int tag_bits, seg_log; /* hash check bits kept in each table entry; tables restart every 2^seg_log bytes */
 } zge_params;
 

@@ -681,6 +681,10 @@ static uint32_t matchfind_block(mf_ctx *c, size_t bs, size_t be, zge_seq *seq, u
             if (offs[1] > ((uint32_t)1 << P->short_window_log)) offs[1] = 0;
             offs[2] = P->rep_search > 0 ? erep0 : 0;
             offs[3] = (P->rep_search > 1 && erep1 != erep0) ? erep1 : 0;
+            /* recent-offset guesses are only tried when their source lies in the tile window the kernel keeps in LDS
+             * (rep_back bytes before the tile): far guesses almost never match and would cost an HBM access each */
+            if (offs[2] > (uint32_t)(p - tile) + (uint32_t)P->rep_back) offs[2] = 0;
+            if (offs[3] > (uint32_t)(p - tile) + (uint32_t)P->rep_back) offs[3] = 0;
             m->len = 0; m->off = 0;
             for (k = 0; k < 4; k++) {
                 uint32_t off = offs[k], len; int is_rep; int32_t sc;
@@ -769,7 +773,7 @@ void zge_default_params(zge_params *P, int level)
     memset(P, 0, sizeof *P);
     P->level = level;
     P->checksum = 1;
-    P->long_log = 13; P->short_log = 13; P->short_bytes = 5; P->tag_bits = 10; P->seg_log = 21;
+    P->long_log = 13; P->short_log = 13; P->short_bytes = 5; P->tag_bits = 10; P->seg_log = 21; P->rep_back = 256;
     P->tile = 1024; P->sub = 64; P->cap = 256;
     P->min_match = 5; P->min_rep = 3; P->rep_search = 2;
     P->back_cap = 8; P->lazy = 1; P->lazy_delta = 5;

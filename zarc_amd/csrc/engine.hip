@@ -76,7 +76,7 @@ ZgeParams derive_params(const zarc_gpu_params &p)
     z.window_log = p.window_log ? p.window_log : (level >= 9 ? 22 : 21);
     if (z.window_log < 10) z.window_log = 10;
     if (z.window_log > 27) z.window_log = 27;
-    z.long_log = 13; z.short_log = 13; z.short_bytes = 5; z.tag_bits = 10; z.seg_log = 21;
+    z.long_log = 13; z.short_log = 13; z.short_bytes = 5; z.tag_bits = 10; z.seg_log = 21; z.rep_back = 256;
     z.tile = 1024; z.sub = 64; z.cap = 256;
     z.min_match = p.min_match >= 4 && p.min_match <= 7 ? p.min_match : 5;
     z.min_rep = 3; z.rep_search = 2; z.back_cap = 8;

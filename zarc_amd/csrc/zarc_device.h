@@ -120,29 +120,20 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v)
     return v;
 }
 
-// little-endian loads from byte pointers with no alignment requirement.  Built from aligned dword
-// loads so they are legal for LDS and global memory alike; they may touch up to 3 bytes before and
-// 7 bytes after the addressed range, which every engine buffer pads for (ZARC_GPU_PAD).
+// little-endian loads from byte pointers with no alignment requirement.  gfx950 executes unaligned
+// global_load_dwordx2 / ds_read_b64 natively (the HSA ABI runs compute queues in unaligned access mode, and
+// hipcc lowers a byte-pointer memcpy to exactly one such instruction), so these are single loads.
 __device__ __forceinline__ uint32_t load_u32(const uint8_t *p)
 {
-    uintptr_t a = (uintptr_t)p;
-    const uint32_t *w = (const uint32_t *)(a & ~(uintptr_t)3);
-    unsigned sh = (unsigned)(a & 3) * 8;
-    uint32_t lo = w[0];
-    if (sh == 0) return lo;
-    return (lo >> sh) | (w[1] << (32 - sh));
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
 }
 __device__ __forceinline__ uint64_t load_u64(const uint8_t *p)
 {
-    uintptr_t a = (uintptr_t)p;
-    const uint32_t *w = (const uint32_t *)(a & ~(uintptr_t)3);
-    unsigned sh = (unsigned)(a & 3) * 8;
-    uint32_t w0 = w[0], w1 = w[1];
-    if (sh == 0) return (uint64_t)w0 | ((uint64_t)w1 << 32);
-    uint32_t w2 = w[2];
-    uint32_t lo = (w0 >> sh) | (w1 << (32 - sh));
-    uint32_t hi = (w1 >> sh) | (w2 << (32 - sh));
-    return (uint64_t)lo | ((uint64_t)hi << 32);
+    uint64_t v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
 }
 
 } // namespace zd

@@ -15,7 +15,7 @@ constexpr uint32_t ZARC_MAX_SEQ = ZARC_BLOCK / 3 + 8; // sequences per block (ev
 // ---- encoder tuning (mirrors oracle/zge_model.h zge_params; plain ints so the struct can be passed by value)
 struct ZgeParams {
     int level, checksum, window_log, long_log, short_log, short_bytes, tile, sub, cap, min_match, min_rep, rep_search,
-        back_cap, lazy, lazy_delta, lit_cost, match_cost, rep_cost, short_window_log, tag_bits, seg_log, dbg;
+        back_cap, lazy, lazy_delta, lit_cost, match_cost, rep_cost, short_window_log, rep_back, tag_bits, seg_log, dbg;
 };
 
 // Per-block record written by the match finder and completed by the entropy coder.

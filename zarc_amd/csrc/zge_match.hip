@@ -37,7 +37,8 @@ constexpr int TAB_LOG = 13;
 constexpr int TAG_BITS = 10;
 constexpr uint32_t TAG_MASK = (1u << TAG_BITS) - 1;
 constexpr int CAP_MAX = 256;
-constexpr int TB_BYTES = 12 + TILE + CAP_MAX + 24; // 8 bytes before the tile, compare overrun after it
+constexpr int REP_BACK_MAX = 256;
+constexpr int TB_BYTES = 12 + REP_BACK_MAX + TILE + CAP_MAX + 24; // rep window + 8 bytes before the tile, compare overrun after it
 
 struct MatchLds {
     uint32_t tl[1 << TAB_LOG];
@@ -163,7 +164,8 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
             // ---- S0: tile bytes (8 before .. cap+16 after) -> LDS ----
             Win W;
             {
-                const uint64_t lo = tile >= 8 ? tile - 8 : 0;
+                const uint64_t before = (uint64_t)(P.rep_back < REP_BACK_MAX ? P.rep_back : REP_BACK_MAX) + 8;
+                const uint64_t lo = tile >= before ? tile - before : 0;
                 uint64_t hi = tend + cap_max + 16;
                 if (hi > n + 16) hi = n + 16;             // the arena is padded by ZARC_GPU_PAD
                 const uintptr_t a = (uintptr_t)(src + lo);
@@ -242,21 +244,20 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                     offs[3] = (P.rep_search > 1 && erep1 != erep0) ? erep1 : 0u;
                     // request every source word that may be needed (8 bytes before, first 16 bytes) of every candidate
                     // before looking at any of them: one round trip to L2/HBM instead of up to three per candidate
-                    uint64_t q8[4], q16[4], qb[4];
+                    // (measured: S3 is bound by the NUMBER of random L2/HBM requests, not by their latency, so only the
+                    //  first source word of each candidate is requested up front; longer compares load on demand)
+                    if (offs[2] > idx + (uint32_t)P.rep_back) offs[2] = 0; // recent-offset guesses only from the LDS window
+                    if (offs[3] > idx + (uint32_t)P.rep_back) offs[3] = 0;
+                    uint64_t q8[4];
                     bool ok[4];
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         ok[k] = offs[k] != 0 && offs[k] <= p && offs[k] <= window;
-                        const uint64_t q = p - offs[k];
-                        q8[k] = ok[k] ? W.ld8(q) : 0;
-                        q16[k] = (ok[k] && cap > 8) ? W.ld8(q + 8) : 0;
-                        qb[k] = (ok[k] && q >= 8) ? W.ld8(q - 8) : 0;
+                        q8[k] = ok[k] ? W.ld8(p - offs[k]) : 0;
                     }
-                    const uint64_t p16 = cap > 8 ? W.ld8(p + 8) : 0, pb = p >= 8 ? W.ld8(p - 8) : 0;
                     uint32_t best_len = 0, best_off = 0;
                     bool best_rep = false;
                     int32_t best_score = -1000000;
-                    uint64_t best_qb = 0;
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         if (!ok[k]) continue;
@@ -264,17 +265,11 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                         const bool is_rep = off == erep0 || off == erep1;
                         const uint64_t x = q8[k] ^ p8[u];
                         uint32_t len;
-                        if (x) len = (uint32_t)(zd::ctz64(x) >> 3);
-                        else {
-                            const uint64_t x2 = q16[k] ^ p16;
-                            if (cap <= 8) len = 8;
-                            else if (x2) len = 8 + (uint32_t)(zd::ctz64(x2) >> 3);
-                            else len = cap >= 16 ? match_more(W, p, p - off, 16, cap) : 16;
-                        }
-                        if (len > cap) len = cap;
+                        if (x) { len = (uint32_t)(zd::ctz64(x) >> 3); if (len > cap) len = cap; }
+                        else len = cap >= 8 ? match_more(W, p, p - off, 8, cap) : cap;
                         if (len < (uint32_t)(is_rep ? P.min_rep : P.min_match)) continue;
                         const int32_t sc = score_of(P, len, off, is_rep);
-                        if (sc > best_score) { best_score = sc; best_len = len; best_off = off; best_rep = is_rep; best_qb = qb[k]; }
+                        if (sc > best_score) { best_score = sc; best_len = len; best_off = off; best_rep = is_rep; }
                     }
                     if (best_len && best_score > 0) {
                         // backward-extension potential: equal bytes just before the match and its source
@@ -285,7 +280,7 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                         uint32_t back = 0;
                         if (maxb) {
                             if (q >= 8) { // then p >= 8 too
-                                const uint64_t x = pb ^ best_qb;
+                                const uint64_t x = W.ld8(p - 8) ^ W.ld8(q - 8);
                                 back = x ? (uint32_t)(__clzll((long long)x) >> 3) : 8u;
                                 if (back > maxb) back = maxb;
                             } else {
