@@ -196,33 +196,27 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
             }
             zd::lds_barrier();
             // ---- S2: ordered lookup + insert (wave 0); no waits between the steps on hardware ----
-            if (wave == 0 && !(P.dbg & 4)) {
-#pragma unroll 1
-                for (int half = 0; half < CHUNKS; half += 8) { // 8 groups at a time keeps everything in registers
-                    uint32_t hl[8], hs[8], el[8], es[8];
+            // The two tables are independent: wave 0 owns the long table, wave 1 the short one.
+            if (wave < 2 && !(P.dbg & 4)) {
+                uint32_t *tab = wave == 0 ? L.tl : L.ts;
+                uint32_t *hc = wave == 0 ? L.a0 : L.a1; // hashes in, candidates out
+                uint32_t h[CHUNKS], e[CHUNKS];
 #pragma unroll
-                    for (int k = 0; k < 8; k++) { hl[k] = L.a0[(half + k) * 64 + lane]; hs[k] = L.a1[(half + k) * 64 + lane]; }
+                for (int k = 0; k < CHUNKS; k++) h[k] = hc[k * 64 + lane];
 #pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        const bool act = hl[k] != 0xFFFFFFFFu;
-                        el[k] = act ? L.tl[hl[k] >> TAG_BITS] : 0u;
-                        es[k] = act ? L.ts[hs[k] >> TAG_BITS] : 0u;
-                        zd::wave_lds_order(); // lookups of this 64-group precede its inserts
-                        if (act) {
-                            const uint32_t code = ((uint32_t)(tile - segbase) + (uint32_t)((half + k) * 64 + lane) + 1) << TAG_BITS;
-                            atomicMax(&L.tl[hl[k] >> TAG_BITS], code | (hl[k] & TAG_MASK));
-                            atomicMax(&L.ts[hs[k] >> TAG_BITS], code | (hs[k] & TAG_MASK));
-                        }
-                        zd::wave_lds_order(); // inserts precede the next group's lookups
+                for (int k = 0; k < CHUNKS; k++) {
+                    const bool act = h[k] != 0xFFFFFFFFu;
+                    e[k] = act ? tab[h[k] >> TAG_BITS] : 0u;
+                    zd::wave_lds_order(); // lookups of this 64-group precede its inserts
+                    if (act) {
+                        const uint32_t code = ((uint32_t)(tile - segbase) + (uint32_t)(k * 64 + lane) + 1) << TAG_BITS;
+                        atomicMax(&tab[h[k] >> TAG_BITS], code | (h[k] & TAG_MASK));
                     }
-#pragma unroll
-                    for (int k = 0; k < 8; k++) { // candidate positions (+1), 0 = none or check bits differ
-                        const uint32_t cl = (el[k] && (el[k] & TAG_MASK) == (hl[k] & TAG_MASK)) ? (uint32_t)segbase + (el[k] >> TAG_BITS) : 0u;
-                        const uint32_t cs = (es[k] && (es[k] & TAG_MASK) == (hs[k] & TAG_MASK)) ? (uint32_t)segbase + (es[k] >> TAG_BITS) : 0u;
-                        L.a0[(half + k) * 64 + lane] = cl;
-                        L.a1[(half + k) * 64 + lane] = cs;
-                    }
+                    zd::wave_lds_order(); // inserts precede the next group's lookups
                 }
+#pragma unroll
+                for (int k = 0; k < CHUNKS; k++) // candidate position (+1), 0 = none or check bits differ
+                    hc[k * 64 + lane] = (e[k] && (e[k] & TAG_MASK) == (h[k] & TAG_MASK)) ? (uint32_t)segbase + (e[k] >> TAG_BITS) : 0u;
             }
             zd::lds_barrier();
             // ---- S3: own candidates ----
@@ -372,17 +366,29 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                     cur = zd::uniform(cur);
                     const uint32_t cbase = (uint32_t)mychunk * 64;
                     const uint32_t cend = cbase + 64 < tcount ? cbase + 64 : tcount;
-                    uint64_t mask = 0;
+                    // walk the path inside my chunk: literal nodes step by one, so only the selected matches are
+                    // visited (uniform loop on the scalar unit, one v_readlane per match)
+                    const uint64_t tk = zd::ballot(take[u]);
+                    const uint32_t span = cend > cbase ? cend - cbase : 0u; // positions of this chunk inside the tile
+                    uint64_t sel = 0, lits = 0;
                     if (!(P.dbg & 2)) {
-                        while (cur < cend) { // walk the path inside my chunk (uniform loop, v_readlane)
-                            mask |= 1ull << (cur - cbase);
-                            cur = zd::readlane(nx[u], cur - cbase);
+                        while (cur < cend) {
+                            const uint32_t rel = cur - cbase;
+                            const uint64_t ahead = tk >> rel;              // take flags at or after the cursor
+                            if (ahead == 0) {                              // only literals up to the end of the chunk
+                                lits |= ((span >= 64 ? ~0ull : ((1ull << span) - 1)) >> rel) << rel;
+                                cur = cend;
+                                break;
+                            }
+                            const uint32_t q = rel + (uint32_t)zd::ctz64(ahead);
+                            lits |= (((1ull << q) - 1) >> rel) << rel;     // literals [rel, q)
+                            sel |= 1ull << q;
+                            cur = zd::readlane(nx[u], q);
                         }
                     }
                     c = mychunk + 1;
-                    const uint64_t tk = zd::ballot(take[u]);
-                    msel[u] = mask & tk;
-                    mlit[u] = mask & ~tk;
+                    msel[u] = sel;
+                    mlit[u] = lits;
                     if (lane == 0) { L.wsel[mychunk] = (uint32_t)__popcll(msel[u]); L.wlit[mychunk] = (uint32_t)__popcll(mlit[u]); }
                 }
                 // the wave that owns the last chunk knows where the path leaves the tile
