@@ -563,10 +563,19 @@ static size_t encode_sequences(const zge_seq *seq, uint32_t nseq, uint8_t *dst, 
 }
 
 /* ------------------------------------------------------------------ match finder ------------- */
-static uint32_t hash_long(uint64_t v, int bits) { return (uint32_t)((v * 0xCF1BBCDCB7A56463ULL) >> (64 - bits)); }
+/* Hashes built from 32-bit multiplies only (a 64-bit multiply costs four quarter-rate VALU ops on gfx950):
+ * two odd multipliers, wrapping sum, top `bits` bits. */
+static uint32_t hash_long(uint64_t v, int bits)
+{
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    return (lo * 0x9E3779B1u + hi * 0x85EBCA77u) >> (32 - bits);
+}
 static uint32_t hash_short(uint64_t v, int bits, int nbytes)
 {
-    return (uint32_t)(((v << (64 - 8 * nbytes)) * 0x9E3779B185EBCA87ULL) >> (64 - bits));
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    if (nbytes < 8) hi &= (nbytes > 4) ? ((1u << (8 * (nbytes - 4))) - 1) : 0u;
+    if (nbytes < 4) lo &= (1u << (8 * nbytes)) - 1;
+    return (lo * 0xC2B2AE3Du + hi * 0x27D4EB2Fu) >> (32 - bits);
 }
 
 /* common prefix length of src[p..] and src[q..], q < p, at most `limit` bytes */

@@ -44,32 +44,43 @@ struct MatchLds {
     uint32_t tl[1 << TAB_LOG];
     uint32_t ts[1 << TAB_LOG];
     uint32_t a0[TILE], a1[TILE]; // S1: hashes -> S2: candidates (pos+1) -> S3: own match {offset ; len | back<<16 | rep<<24} -> S4: final match
-    uint16_t ex[TILE];            // S6: first position outside its chunk reached from each position
+    uint32_t ex[TILE];            // S4: best backward offer per position; S6: first position outside its chunk reached from each position
     uint32_t tb[(TB_BYTES + 3) / 4];
     uint32_t wsel[CHUNKS], wlit[CHUNKS];
     uint32_t ctrl[16];
 };
 enum { K_POS = 0, K_REP0 = 1, K_REP1 = 2, K_FLAG = 3, K_NEW0 = 4, K_NEW1 = 5 };
 
-__device__ __forceinline__ uint32_t hash_long(uint64_t v, int bits) { return (uint32_t)((v * 0xCF1BBCDCB7A56463ULL) >> (64 - bits)); }
+// Hashes from 32-bit multiplies only (a 64-bit multiply is four quarter-rate VALU ops on gfx950).
+__device__ __forceinline__ uint32_t hash_long(uint64_t v, int bits)
+{
+    const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    return (lo * 0x9E3779B1u + hi * 0x85EBCA77u) >> (32 - bits);
+}
 __device__ __forceinline__ uint32_t hash_short(uint64_t v, int bits, int nbytes)
 {
-    return (uint32_t)(((v << (64 - 8 * nbytes)) * 0x9E3779B185EBCA87ULL) >> (64 - bits));
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    if (nbytes < 8) hi &= (nbytes > 4) ? ((1u << (8 * (nbytes - 4))) - 1) : 0u;
+    if (nbytes < 4) lo &= (1u << (8 * nbytes)) - 1;
+    return (lo * 0xC2B2AE3Du + hi * 0x27D4EB2Fu) >> (32 - bits);
 }
 
-__device__ __forceinline__ int32_t score_of(const ZgeParams &P, uint32_t len, uint32_t off, bool is_rep)
+// Bit-cost model (lit_cost 5, match_cost 12, rep_cost 9: the engine's fixed defaults, so the literal cost is a
+// shift-add instead of a quarter-rate multiply).  The engine refuses to launch with other values.
+constexpr int LIT_COST = 5, MATCH_COST = 12, REP_COST = 9;
+__device__ __forceinline__ int32_t score_of(const ZgeParams &, uint32_t len, uint32_t off, bool is_rep)
 {
-    if (is_rep) return (int32_t)(P.lit_cost * (int)len) - P.rep_cost;
-    return (int32_t)(P.lit_cost * (int)len) - P.match_cost - zd::hb32(off);
+    const int32_t lits = (int32_t)((len << 2) + len);
+    return is_rep ? lits - REP_COST : lits - MATCH_COST - zd::hb32(off);
 }
 
 // 8 bytes at frame position `pos`: from the staged window [lo, hi) in LDS when fully inside, else from HBM/L2
 struct Win {
     const uint8_t *src;  // frame start in global memory
     const uint8_t *lds;  // LDS byte that corresponds to frame position `lo`
-    uint64_t lo, hi;
-    __device__ __forceinline__ bool staged(uint64_t pos) const { return pos >= lo && pos + 8 <= hi; }
-    __device__ __forceinline__ uint64_t ld8(uint64_t pos) const
+    uint32_t lo, hi;
+    __device__ __forceinline__ bool staged(uint32_t pos) const { return pos >= lo && pos + 8 <= hi; }
+    __device__ __forceinline__ uint64_t ld8(uint32_t pos) const
     {
         if (staged(pos)) return zd::load_u64(lds + (pos - lo));
         return zd::load_u64(src + pos);
@@ -77,7 +88,7 @@ struct Win {
 };
 
 // continue a common-prefix count from `n` (a multiple of 8) matched bytes up to `limit`
-__device__ __forceinline__ uint32_t match_more(const Win &w, uint64_t p, uint64_t q, uint32_t n, uint32_t limit)
+__device__ __forceinline__ uint32_t match_more(const Win &w, uint32_t p, uint32_t q, uint32_t n, uint32_t limit)
 {
     while (n + 8 <= limit) {
         const uint64_t x = w.ld8(p + n) ^ w.ld8(q + n);
@@ -105,22 +116,22 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
     const int wave = (int)zd::uniform((uint32_t)zd::wave_id()); // scalar: chunk bounds and the parse walk stay on the SALU
     const uint32_t f = order[blockIdx.x];
     const uint8_t *src = src_base + src_off[f];
-    const uint64_t n = src_len[f];
-    const uint64_t window = n <= (1ull << P.window_log) ? (n ? n : 1) : (1ull << P.window_log);
-    const uint64_t hash_end = n >= 8 ? n - 7 : 0;
+    const uint32_t n = (uint32_t)src_len[f]; // the engine rejects entries of 4 GiB or more: positions are 32-bit
+    const uint32_t window = n <= (1u << P.window_log) ? (n ? n : 1u) : (1u << P.window_log);
+    const uint32_t hash_end = n >= 8 ? n - 7 : 0;
     // block records / scratch slots are numbered within the sub-batch: block_prefix is indexed by blockIdx
     const uint64_t first_block = block_prefix[blockIdx.x];
     const uint32_t nblocks = (uint32_t)(block_prefix[blockIdx.x + 1] - first_block);
     const uint32_t cap_max = (uint32_t)(P.cap < CAP_MAX ? P.cap : CAP_MAX);
     const uint64_t lt = (1ull << lane) - 1;
-    const uint64_t seg_mask = (1ull << P.seg_log) - 1;
+    const uint32_t seg_mask = (1u << P.seg_log) - 1;
 
     for (int i = tid; i < (1 << TAB_LOG); i += THREADS) { L.tl[i] = 0; L.ts[i] = 0; }
     zd::lds_barrier();
 
     for (uint32_t b = 0; b < nblocks; b++) {
-        const uint64_t bs = (uint64_t)b * ZARC_BLOCK;
-        const uint64_t be = bs + ZARC_BLOCK < n ? bs + ZARC_BLOCK : n;
+        const uint32_t bs = b * ZARC_BLOCK;
+        const uint32_t be = n - bs > ZARC_BLOCK ? bs + ZARC_BLOCK : n;
         const uint32_t blen = (uint32_t)(be - bs);
         ZgeBlock *rec = blocks + first_block + b;
         uint64_t *seq_out = seq_scratch + (first_block + b) * (uint64_t)ZARC_MAX_SEQ;
@@ -152,21 +163,21 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
 
         uint32_t nseq = 0, lp = 0; // replicated in every thread
 
-        for (uint64_t tile = bs; tile < be; tile += TILE) {
-            const uint64_t tend = tile + TILE < be ? tile + TILE : be;
+        for (uint32_t tile = bs; tile < be; tile += TILE) {
+            const uint32_t tend = be - tile > TILE ? tile + TILE : be;
             const uint32_t tcount = (uint32_t)(tend - tile);
-            const uint64_t segbase = tile & ~seg_mask;
+            const uint32_t segbase = tile & ~seg_mask;
             zd::lds_barrier(); // K_POS / K_REP* of the previous tile are final; LDS work arrays are free again
-            const uint64_t pos = bs + L.ctrl[K_POS];
+            const uint32_t pos = bs + L.ctrl[K_POS];
             if (pos >= tend) continue; // whole tile already covered by a match: skip it (nothing is inserted)
             const uint32_t erep0 = L.ctrl[K_REP0], erep1 = L.ctrl[K_REP1];
 
             // ---- S0: tile bytes (8 before .. cap+16 after) -> LDS ----
             Win W;
             {
-                const uint64_t before = (uint64_t)(P.rep_back < REP_BACK_MAX ? P.rep_back : REP_BACK_MAX) + 8;
-                const uint64_t lo = tile >= before ? tile - before : 0;
-                uint64_t hi = tend + cap_max + 16;
+                const uint32_t before = (uint32_t)(P.rep_back < REP_BACK_MAX ? P.rep_back : REP_BACK_MAX) + 8;
+                const uint32_t lo = tile >= before ? tile - before : 0;
+                uint32_t hi = tend + cap_max + 16;
                 if (hi > n + 16) hi = n + 16;             // the arena is padded by ZARC_GPU_PAD
                 const uintptr_t a = (uintptr_t)(src + lo);
                 const uint32_t mis = (uint32_t)(a & 3);
@@ -181,14 +192,14 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
 #pragma unroll
             for (int u = 0; u < PER; u++) {
                 const uint32_t idx = (uint32_t)(u * THREADS + tid);
-                const uint64_t p = tile + idx;
+                const uint32_t p = tile + idx;
                 uint32_t hl = 0xFFFFFFFFu, hs = 0xFFFFFFFFu;
                 p8[u] = 0;
                 if (idx < tcount) {
                     p8[u] = W.ld8(p);
                     if (p < hash_end && !(P.dbg & 64)) {
                         hl = hash_long(p8[u], TAB_LOG + TAG_BITS);
-                        hs = hash_short(p8[u], TAB_LOG + TAG_BITS, P.short_bytes);
+                        hs = hash_short(p8[u], TAB_LOG + TAG_BITS, 5); // short_bytes is fixed at 5 by the engine
                     }
                 }
                 L.a0[idx] = hl;
@@ -219,103 +230,111 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                     hc[k * 64 + lane] = (e[k] && (e[k] & TAG_MASK) == (h[k] & TAG_MASK)) ? (uint32_t)segbase + (e[k] >> TAG_BITS) : 0u;
             }
             zd::lds_barrier();
-            // ---- S3: own candidates ----
+            // ---- S3: own candidates.  Phase A requests the first source word of every candidate of BOTH positions
+            // (measured: the stage is bound by the number of random L2/HBM requests and their latency, so nothing else is
+            // fetched speculatively); phase B scores them, loading more only for candidates that match 8 bytes. ----
             uint32_t mo[PER], mw[PER];
+            uint32_t offs[PER][4];
+            uint64_t q8[PER][4];
 #pragma unroll
             for (int u = 0; u < PER; u++) {
                 const uint32_t idx = (uint32_t)(u * THREADS + tid);
-                const uint64_t p = tile + idx;
+                const uint32_t p = tile + idx;
+                uint32_t c0 = 0, c1 = 0;
+                if (idx < tcount && !(P.dbg & 5)) { c0 = L.a0[idx]; c1 = L.a1[idx]; }
+                offs[u][0] = c0 ? p - (c0 - 1) : 0u;
+                offs[u][1] = (c1 && c1 != c0) ? p - (c1 - 1) : 0u;
+                if (P.short_window_log < 32 && offs[u][1] > (1u << P.short_window_log)) offs[u][1] = 0;
+                offs[u][2] = P.rep_search > 0 ? erep0 : 0u;
+                offs[u][3] = (P.rep_search > 1 && erep1 != erep0) ? erep1 : 0u;
+                if (offs[u][2] > idx + (uint32_t)P.rep_back) offs[u][2] = 0; // recent-offset guesses only from the LDS window
+                if (offs[u][3] > idx + (uint32_t)P.rep_back) offs[u][3] = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (offs[u][k] > p || offs[u][k] > window || idx >= tcount || (P.dbg & 1)) offs[u][k] = 0;
+                    q8[u][k] = offs[u][k] ? W.ld8(p - offs[u][k]) : 0;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < PER; u++) {
+                const uint32_t idx = (uint32_t)(u * THREADS + tid);
+                const uint32_t p = tile + idx;
                 mo[u] = 0; mw[u] = 0;
-                if (idx < tcount && !(P.dbg & 1)) {
-                    uint32_t c0 = L.a0[idx], c1 = L.a1[idx];
-                    if (P.dbg & 4) { c0 = 0; c1 = 0; }
-                    const uint32_t limit = (uint32_t)(be - p), cap = limit < cap_max ? limit : cap_max;
-                    uint32_t offs[4];
-                    offs[0] = c0 ? (uint32_t)p - (c0 - 1) : 0u;
-                    offs[1] = (c1 && c1 != c0) ? (uint32_t)p - (c1 - 1) : 0u;
-                    if (P.short_window_log < 32 && offs[1] > (1u << P.short_window_log)) offs[1] = 0;
-                    offs[2] = P.rep_search > 0 ? erep0 : 0u;
-                    offs[3] = (P.rep_search > 1 && erep1 != erep0) ? erep1 : 0u;
-                    // request every source word that may be needed (8 bytes before, first 16 bytes) of every candidate
-                    // before looking at any of them: one round trip to L2/HBM instead of up to three per candidate
-                    // (measured: S3 is bound by the NUMBER of random L2/HBM requests, not by their latency, so only the
-                    //  first source word of each candidate is requested up front; longer compares load on demand)
-                    if (offs[2] > idx + (uint32_t)P.rep_back) offs[2] = 0; // recent-offset guesses only from the LDS window
-                    if (offs[3] > idx + (uint32_t)P.rep_back) offs[3] = 0;
-                    uint64_t q8[4];
-                    bool ok[4];
+                const uint32_t limit = idx < tcount ? (uint32_t)(be - p) : 0u, cap = limit < cap_max ? limit : cap_max;
+                uint32_t best_len = 0, best_off = 0;
+                bool best_rep = false;
+                int32_t best_score = -1000000;
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        ok[k] = offs[k] != 0 && offs[k] <= p && offs[k] <= window;
-                        q8[k] = ok[k] ? W.ld8(p - offs[k]) : 0;
-                    }
-                    uint32_t best_len = 0, best_off = 0;
-                    bool best_rep = false;
-                    int32_t best_score = -1000000;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        if (!ok[k]) continue;
-                        const uint32_t off = offs[k];
-                        const bool is_rep = off == erep0 || off == erep1;
-                        const uint64_t x = q8[k] ^ p8[u];
-                        uint32_t len;
-                        if (x) { len = (uint32_t)(zd::ctz64(x) >> 3); if (len > cap) len = cap; }
-                        else len = cap >= 8 ? match_more(W, p, p - off, 8, cap) : cap;
-                        if (len < (uint32_t)(is_rep ? P.min_rep : P.min_match)) continue;
-                        const int32_t sc = score_of(P, len, off, is_rep);
-                        if (sc > best_score) { best_score = sc; best_len = len; best_off = off; best_rep = is_rep; }
-                    }
-                    if (best_len && best_score > 0) {
-                        // backward-extension potential: equal bytes just before the match and its source
-                        const uint64_t q = p - best_off;
-                        uint32_t maxb = (uint32_t)P.back_cap;
-                        if (p - bs < maxb) maxb = (uint32_t)(p - bs);
-                        if (q < maxb) maxb = (uint32_t)q;
-                        uint32_t back = 0;
-                        if (maxb) {
-                            if (q >= 8) { // then p >= 8 too
-                                const uint64_t x = W.ld8(p - 8) ^ W.ld8(q - 8);
-                                back = x ? (uint32_t)(__clzll((long long)x) >> 3) : 8u;
-                                if (back > maxb) back = maxb;
-                            } else {
-                                while (back < maxb && src[p - back - 1] == src[q - back - 1]) back++;
-                            }
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t off = offs[u][k];
+                    if (!off) continue;
+                    const bool is_rep = off == erep0 || off == erep1;
+                    const uint64_t x = q8[u][k] ^ p8[u];
+                    uint32_t len;
+                    if (x) { len = (uint32_t)(zd::ctz64(x) >> 3); if (len > cap) len = cap; }
+                    else len = cap >= 8 ? match_more(W, p, p - off, 8, cap) : cap;
+                    if (len < (uint32_t)(is_rep ? P.min_rep : P.min_match)) continue;
+                    const int32_t sc = score_of(P, len, off, is_rep);
+                    if (sc > best_score) { best_score = sc; best_len = len; best_off = off; best_rep = is_rep; }
+                }
+                if (best_len && best_score > 0) {
+                    // backward-extension potential: equal bytes just before the match and its source
+                    const uint32_t q = p - best_off;
+                    uint32_t maxb = (uint32_t)P.back_cap;
+                    if (p - bs < maxb) maxb = (uint32_t)(p - bs);
+                    if (q < maxb) maxb = (uint32_t)q;
+                    uint32_t back = 0;
+                    if (maxb) {
+                        if (q >= 8) { // then p >= 8 too
+                            const uint64_t x = W.ld8(p - 8) ^ W.ld8(q - 8);
+                            back = x ? (uint32_t)(__clzll((long long)x) >> 3) : 8u;
+                            if (back > maxb) back = maxb;
+                        } else {
+                            while (back < maxb && src[p - back - 1] == src[q - back - 1]) back++;
                         }
-                        mo[u] = best_off;
-                        mw[u] = best_len | (back << 16) | ((best_rep ? 1u : 0u) << 24);
                     }
+                    mo[u] = best_off;
+                    mw[u] = best_len | (back << 16) | ((best_rep ? 1u : 0u) << 24);
                 }
             }
             zd::lds_barrier(); // every thread has read its candidates from a0/a1
 #pragma unroll
-            for (int u = 0; u < PER; u++) { L.a0[u * THREADS + tid] = mo[u]; L.a1[u * THREADS + tid] = mw[u]; }
+            for (int u = 0; u < PER; u++) { L.a0[u * THREADS + tid] = mo[u]; L.a1[u * THREADS + tid] = mw[u]; L.ex[u * THREADS + tid] = 0; }
             zd::lds_barrier();
-            // ---- S4: backward propagation (read neighbours, then overwrite in place) ----
+            // ---- S4: backward propagation.  A position whose match extends b bytes backwards offers it to the b
+            // positions before it (ds_max of score << 4 | 8-k: best score wins, then the nearest source); every position
+            // then adopts the best offer if it beats its own match.  Same result as scanning the 8 following positions.
 #pragma unroll
             for (int u = 0; u < PER; u++) {
                 const uint32_t idx = (uint32_t)(u * THREADS + tid);
-                if (idx < tcount && !(P.dbg & 8)) {
-                    uint32_t nwv[8];
-#pragma unroll
-                    for (int k = 1; k <= 8; k++) nwv[k - 1] = (k <= P.back_cap && idx + k < tcount) ? L.a1[idx + k] : 0u;
-                    uint32_t blen_ = mw[u] & 0xFFFF, boff = mo[u];
-                    bool brep = (mw[u] >> 24) & 1;
-                    int32_t bscore = blen_ ? score_of(P, blen_, boff, brep) : 0;
-#pragma unroll
-                    for (int k = 1; k <= 8; k++) {
-                        const uint32_t nw = nwv[k - 1];
-                        const uint32_t nl = nw & 0xFFFF, nbk = (nw >> 16) & 0xFF;
-                        if (!nl || nbk < (uint32_t)k) continue;
-                        const uint32_t no = L.a0[idx + k];
-                        const bool nr = (nw >> 24) & 1;
-                        const int32_t sc = score_of(P, nl + k, no, nr);
-                        if (sc > bscore) { bscore = sc; blen_ = nl + k; boff = no; brep = nr; }
+                const uint32_t len = mw[u] & 0xFFFF, back = (mw[u] >> 16) & 0xFF;
+                if (len && back && !(P.dbg & 8)) {
+                    const bool rep = (mw[u] >> 24) & 1;
+                    for (uint32_t k = 1; k <= back && k <= idx; k++) {
+                        const int32_t sc = score_of(P, len + k, mo[u], rep);
+                        if (sc > 0) atomicMax(&L.ex[idx - k], ((uint32_t)sc << 4) | (8u - k));
                     }
-                    mo[u] = boff;
-                    mw[u] = blen_ | ((brep ? 1u : 0u) << 24);
-                } else {
-                    mw[u] &= 0x0100FFFFu;
                 }
+            }
+            zd::lds_barrier();
+#pragma unroll
+            for (int u = 0; u < PER; u++) {
+                const uint32_t idx = (uint32_t)(u * THREADS + tid);
+                const uint32_t offer = L.ex[idx];
+                uint32_t blen_ = mw[u] & 0xFFFF, boff = mo[u];
+                bool brep = (mw[u] >> 24) & 1;
+                if (offer) {
+                    const int32_t own = blen_ ? score_of(P, blen_, boff, brep) : 0;
+                    if ((int32_t)(offer >> 4) > own) {
+                        const uint32_t k = 8u - (offer & 15u);
+                        const uint32_t nw = L.a1[idx + k];
+                        boff = L.a0[idx + k];
+                        blen_ = (nw & 0xFFFF) + k;
+                        brep = (nw >> 24) & 1;
+                    }
+                }
+                mo[u] = boff;
+                mw[u] = blen_ | ((brep ? 1u : 0u) << 24);
             }
             zd::lds_barrier();
 #pragma unroll
@@ -348,7 +367,7 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                     const uint32_t v2 = zd::shfl(val, (int)((val - cbase) & 63));
                     if (val < cend) val = v2;
                 }
-                L.ex[idx] = (uint16_t)val;
+                L.ex[idx] = val;
             }
             zd::lds_barrier();
             // ---- S6b/c + S7: chunk entries by a chain through ex[], path marks per chunk, emission ----
