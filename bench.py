@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--size", type=int, default=1 << 20, help="bytes per entry (BASELINE configs[1]: 1 MiB)")
     ap.add_argument("--cpu-sample", type=int, default=48, help="entries timed on the host for cpu_baseline (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kind", type=int, default=-1, help="diagnostics: use one corpus kind for every entry (default: round-robin)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -95,7 +96,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:  # under torchrun always go through RCCL, even with one rank
         import torch.distributed as dist_mod
         torch.cuda.set_device(local_rank)
         dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -116,7 +117,7 @@ def main():
     d_dst = eng.malloc(cap + _lib.PAD)
     d_out = eng.malloc(n * stride + _lib.PAD)
     first = shard_indices(rank, n)
-    eng.corpus_fill(d_src, off, lens, first_index=first, kind=-1)
+    eng.corpus_fill(d_src, off, lens, first_index=first, kind=args.kind)
 
     def barrier():
         if dist is not None:

@@ -85,3 +85,49 @@ def test_gpu_full_size_properties(engine, oracle, corpus):
     finally:
         for p in (d_src, d_dst, d_out):
             engine.free(p)
+
+
+def test_gpu_mixed_sizes_config5_shape(engine, oracle, corpus):
+    """BASELINE configs[4] shape at reduced volume: entry sizes log-uniform in 64 KiB..16 MiB, kinds round-robin,
+    level 3; every frame bit-identical to the model on a sample, all frames round-trip (digest equality)."""
+    import random
+    rnd = random.Random(5)
+    sizes = [int(65536 * 2 ** (rnd.random() * 8)) for _ in range(24)] + [16 << 20, (2 << 20) + 1, 2 << 20]
+    n = len(sizes)
+    off, pos = [], 0
+    for s in sizes:
+        off.append(pos)
+        pos += (s + 15) // 16 * 16
+    cap = sum(engine.bound(s) for s in sizes)
+    d_src, d_dst, d_out = engine.malloc(pos + _lib.PAD), engine.malloc(cap + _lib.PAD), engine.malloc(pos + _lib.PAD)
+    try:
+        engine.corpus_fill(d_src, off, sizes, first_index=7000, kind=-1)
+        doff, dlen, dig, st = engine.pack_device(d_src, off, sizes, d_dst, cap)
+        assert (st == 0).all()
+        for i in (0, 5, n - 3, n - 2, n - 1):
+            raw = corpus.entry(7000 + i, sizes[i], -1)
+            frame = bytes(engine.d2h(d_dst + int(doff[i]), int(dlen[i])))
+            assert bytes(dig[i]) == oracle.blake3(raw)
+            assert frame == oracle.zge_encode(raw), (i, sizes[i])
+            rc, out, used = oracle.zstd_decode(frame, len(raw))
+            assert rc == 0 and out == raw
+        dig2, st2 = engine.unpack_device(d_dst, doff, dlen, d_out, off, sizes, expect=dig)
+        assert (st2 == 0).all() and (dig2 == dig).all()
+    finally:
+        for p in (d_src, d_dst, d_out):
+            engine.free(p)
+
+
+def test_gpu_level9_parameter_config4_shape(engine, oracle, corpus, libzstds):
+    """BASELINE configs[3] shape: 4 MiB frames at level 9 (window log 22: still single-segment frames)."""
+    from zarc_amd import Engine
+    e9 = Engine(0)
+    e9.set_parameter(_lib.P_CHECKSUM_FLAG, 1)
+    e9.set_parameter(_lib.P_COMPRESSION_LEVEL, 9)
+    raws = [corpus.entry(9000 + i, 4 << 20, 2) for i in range(3)]
+    for raw, (frame, dig) in zip(raws, e9.pack(raws)):
+        assert frame[4] & 0x20                                   # Single_Segment
+        assert frame == oracle.zge_encode(raw, oracle.params(level=9, window_log=22))
+        for z in libzstds:
+            assert z.decompress(frame, len(raw))[0] == raw
+    e9.close()

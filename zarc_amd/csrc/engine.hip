@@ -77,7 +77,7 @@ ZgeParams derive_params(const zarc_gpu_params &p)
     if (z.window_log < 10) z.window_log = 10;
     if (z.window_log > 27) z.window_log = 27;
     z.long_log = 13; z.short_log = 13; z.short_bytes = 5; z.tag_bits = 10; z.seg_log = 21; z.rep_back = 256;
-    z.tile = 1024; z.sub = 64; z.cap = 256;
+    z.tile = 1024; z.sub = 64; z.cap = getenv("ZARC_GPU_CAP") ? atoi(getenv("ZARC_GPU_CAP")) : 256;
     z.min_match = p.min_match >= 4 && p.min_match <= 7 ? p.min_match : 5;
     z.min_rep = 3; z.rep_search = 2; z.back_cap = 8;
     z.lazy = level >= 2 ? 1 : 0; z.lazy_delta = 5;
@@ -441,7 +441,8 @@ int zarc_gpu_unpack_batch_device(zarc_gpu_t *h, size_t n, const void *d_frames_b
     ZHIP(t.mark(&e0));
     hipLaunchKernelGGL(zarc_zstd_decode, dim3((unsigned)n), dim3(64), 0, h->stream, (const uint8_t *)d_frames_base, h->d_frame_off.as<uint64_t>(),
                        h->d_frame_len.as<uint64_t>(), (uint8_t *)d_dst_base, h->d_dst_off.as<uint64_t>(), h->d_raw_len.as<uint64_t>(),
-                       h->d_order.as<uint32_t>(), (uint32_t)n, h->d_declit.as<uint8_t>(), h->d_status.as<int32_t>(), h->d_stored_ck.as<uint32_t>());
+                       h->d_order.as<uint32_t>(), (uint32_t)n, h->d_declit.as<uint8_t>(), h->d_status.as<int32_t>(), h->d_stored_ck.as<uint32_t>(),
+                       getenv("ZARC_GPU_DBG_DEC") ? atoi(getenv("ZARC_GPU_DBG_DEC")) : 0);
     ZHIP(hipGetLastError());
     ZHIP(t.mark(&e1));
     // verification passes over the decoded bytes (K2 + XXH64 inside libzstd in the reference)

@@ -212,14 +212,21 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                 uint32_t *tab = wave == 0 ? L.tl : L.ts;
                 uint32_t *hc = wave == 0 ? L.a0 : L.a1; // hashes in, candidates out
                 uint32_t h[CHUNKS], e[CHUNKS];
+                uint64_t dupmask = 0; // bit k: the next lane of group k has the same hash, so its insert supersedes mine
 #pragma unroll
-                for (int k = 0; k < CHUNKS; k++) h[k] = hc[k * 64 + lane];
+                for (int k = 0; k < CHUNKS; k++) {
+                    h[k] = hc[k * 64 + lane];
+                    const uint32_t hn = lane < 63 ? hc[k * 64 + lane + 1] : 0xFFFFFFFFu;
+                    if (hn == h[k]) dupmask |= 1ull << k;
+                }
 #pragma unroll
                 for (int k = 0; k < CHUNKS; k++) {
                     const bool act = h[k] != 0xFFFFFFFFu;
                     e[k] = act ? tab[h[k] >> TAG_BITS] : 0u;
                     zd::wave_lds_order(); // lookups of this 64-group precede its inserts
-                    if (act) {
+                    // runs of equal hashes (zero runs, repeated bytes) would serialise 64 atomics on one LDS word: only the
+                    // last lane of a run inserts -- ds_max keeps the highest position anyway, so the table ends up identical
+                    if (act && !((dupmask >> k) & 1)) {
                         const uint32_t code = ((uint32_t)(tile - segbase) + (uint32_t)(k * 64 + lane) + 1) << TAG_BITS;
                         atomicMax(&tab[h[k] >> TAG_BITS], code | (h[k] & TAG_MASK));
                     }
@@ -250,10 +257,11 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                 if (offs[u][2] > idx + (uint32_t)P.rep_back) offs[u][2] = 0; // recent-offset guesses only from the LDS window
                 if (offs[u][3] > idx + (uint32_t)P.rep_back) offs[u][3] = 0;
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
+                for (int k = 0; k < 4; k++)
                     if (offs[u][k] > p || offs[u][k] > window || idx >= tcount || (P.dbg & 1)) offs[u][k] = 0;
-                    q8[u][k] = offs[u][k] ? W.ld8(p - offs[u][k]) : 0;
-                }
+                // (tried: compacting live candidates to the front so that fewer evaluation slots run -- no gain on hardware)
+#pragma unroll
+                for (int k = 0; k < 4; k++) q8[u][k] = offs[u][k] ? W.ld8(p - offs[u][k]) : 0;
             }
 #pragma unroll
             for (int u = 0; u < PER; u++) {

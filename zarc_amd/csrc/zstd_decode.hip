@@ -81,6 +81,71 @@ struct BackBits {
     }
 };
 
+// ---- backward bit reader for the sequence stream (lane 0): same interface as BackBits, but refills come out of a
+// three-word register window [B-16, B+8) that is reloaded one word ahead, so the L1/L2 latency of the bitstream is
+// off the per-sequence dependency chain ----
+struct SeqBits {
+    const uint8_t *p;
+    int32_t bitpos, used, B;
+    uint64_t c, w_hi, w_mid, w_lo; // bytes [B,B+8), [B-8,B), [B-16,B-8) of the stream (zero below its start)
+    __device__ __forceinline__ uint64_t load8z(int32_t idx) const
+    {
+        if (idx >= 0) return zd::load_u64(p + idx);
+        if (idx > -8) return zd::load_u64(p) << (8 * (-idx));
+        return 0;
+    }
+    __device__ __forceinline__ void refill()
+    {
+        const int32_t T = (bitpos + 7) >> 3; // the next bits end at byte T (exclusive)
+        if (T < B) { w_hi = w_mid; w_mid = w_lo; B -= 8; w_lo = load8z(B - 16); }
+        const int32_t s = B + 8 - T;         // 0..8 bytes of w_hi are already consumed
+        c = s <= 0 ? w_hi : (s >= 8 ? w_mid : ((w_hi << (8 * s)) | (w_mid >> (64 - 8 * s))));
+        used = 8 * T - bitpos;
+    }
+    __device__ __forceinline__ bool init(const uint8_t *ptr, uint32_t len)
+    {
+        p = ptr;
+        if (len == 0) return false;
+        const uint32_t last = ptr[len - 1];
+        if (last == 0) return false;
+        bitpos = (int32_t)(len - 1) * 8 + zd::hb32(last);
+        const int32_t T = (bitpos + 7) >> 3;
+        B = T - 8;
+        w_hi = load8z(B); w_mid = load8z(B - 8); w_lo = load8z(B - 16);
+        refill();
+        return true;
+    }
+    __device__ __forceinline__ uint32_t read(int k) // 0 <= k <= 32
+    {
+        if (k == 0) return 0;
+        if (used + k > 64) refill();
+        const uint32_t v = (uint32_t)((c << used) >> (64 - k));
+        used += k;
+        bitpos -= k;
+        return v;
+    }
+};
+
+// literal-length / match-length code -> baseline and number of extra bits, in registers (RFC 8878 tables 15 and 16)
+__device__ __forceinline__ void ll_code_info(uint32_t code, uint32_t &base, uint32_t &bits)
+{
+    if (code < 16) { base = code; bits = 0; }
+    else if (code < 25) {
+        const uint32_t i = code - 16;
+        bits = (uint32_t)(0x433221111ull >> (4 * i)) & 15u;
+        base = i == 8 ? 48u : (uint32_t)(0x28201C1816141210ull >> (8 * i)) & 0xFFu;
+    } else { bits = code - 19; base = 1u << bits; }
+}
+__device__ __forceinline__ void ml_code_info(uint32_t code, uint32_t &base, uint32_t &bits)
+{
+    if (code < 32) { base = code + 3; bits = 0; }
+    else if (code < 43) {
+        const uint32_t i = code - 32;
+        bits = (uint32_t)(0x54433221111ull >> (4 * i)) & 15u;
+        base = i >= 8 ? 67u + 16u * (i - 8) : (uint32_t)(0x3B332F2B29272523ull >> (8 * i)) & 0xFFu;
+    } else { bits = code - 36; base = (1u << bits) + 3; }
+}
+
 // ---- forward bit reader (one lane), for FSE table descriptions -----------------------------------
 struct FwdBits {
     const uint8_t *p;
@@ -163,15 +228,20 @@ __device__ int fse_read_desc(const uint8_t *src, uint32_t len, int max_al, int m
     return (int)((b.bitpos + 7) >> 3);
 }
 
+// 10 212 bytes per wave -> 16 frames in flight per CU.  The table-construction scratch (weights, normalised counts)
+// and the per-batch sequence buffer are never live at the same time and share storage.
 struct Lds {
     uint16_t huf[2048];   // sym | nbits << 8
     uint32_t ll[512], ml[512], of[256];
-    uint8_t weights[256];
-    int16_t norm[64];
-    uint16_t next[64];
-    uint32_t wtab[64];    // FSE table for Huffman weights (accuracy <= 6)
-    uint32_t seq[SEQ_BATCH * 3];
-    uint32_t llx[36], mlx[53]; // code -> baseline | extra bits << 24 (LDS copies: a VGPR-indexed __constant__ read is a global load)
+    union {
+        struct {
+            uint8_t weights[256];
+            int16_t norm[64];
+            uint16_t next[64];
+            uint32_t wtab[64]; // FSE table for Huffman weights (accuracy <= 6)
+        } b;
+        uint32_t seq[SEQ_BATCH * 3];
+    };
     int32_t ctrl[16];
 };
 enum { C_ERR = 0, C_HUF_BITS = 1, C_HUF_VALID = 2, C_LL_AL = 3, C_OF_AL = 4, C_ML_AL = 5, C_LL_OK = 6, C_OF_OK = 7, C_ML_OK = 8,
@@ -195,29 +265,29 @@ __device__ int huf_read_weights(Lds &L, const uint8_t *src, uint32_t len, int la
         if ((uint32_t)consumed > len) return -1;
         for (int i = lane; i < n; i += 64) {
             uint8_t byte = src[1 + i / 2];
-            L.weights[i] = (i & 1) ? (byte & 15) : (byte >> 4);
+            L.b.weights[i] = (i & 1) ? (byte & 15) : (byte >> 4);
         }
         zd::wave_sync();
     } else {
         if (hb == 0 || 1 + hb > len) return -1;
         if (lane == 0) {
             int nsym = 0, al = 0, cnt = -1;
-            int used = fse_read_desc(src + 1, hb, 6, 63, L.norm, &nsym, &al); // weights are <= 11; 63 bounds L.norm
+            int used = fse_read_desc(src + 1, hb, 6, 63, L.b.norm, &nsym, &al); // weights are <= 11; 63 bounds L.b.norm
             BackBits b;
-            if (used > 0 && (uint32_t)used < hb && fse_build_dtable(L.wtab, L.norm, nsym, al, L.next) &&
+            if (used > 0 && (uint32_t)used < hb && fse_build_dtable(L.b.wtab, L.b.norm, nsym, al, L.b.next) &&
                 b.init(src + 1 + used, hb - (uint32_t)used)) {
                 uint32_t s1 = b.read(al), s2 = b.read(al);
                 if (b.bitpos >= 0) {
                     cnt = 0;
                     for (;;) {
                         if (cnt > 253) { cnt = -1; break; }
-                        L.weights[cnt++] = (uint8_t)cell_sym(L.wtab[s1]);
-                        s1 = cell_base(L.wtab[s1]) + b.read((int)cell_nbits(L.wtab[s1]));
-                        if (b.bitpos < 0) { L.weights[cnt++] = (uint8_t)cell_sym(L.wtab[s2]); break; }
+                        L.b.weights[cnt++] = (uint8_t)cell_sym(L.b.wtab[s1]);
+                        s1 = cell_base(L.b.wtab[s1]) + b.read((int)cell_nbits(L.b.wtab[s1]));
+                        if (b.bitpos < 0) { L.b.weights[cnt++] = (uint8_t)cell_sym(L.b.wtab[s2]); break; }
                         if (cnt > 253) { cnt = -1; break; }
-                        L.weights[cnt++] = (uint8_t)cell_sym(L.wtab[s2]);
-                        s2 = cell_base(L.wtab[s2]) + b.read((int)cell_nbits(L.wtab[s2]));
-                        if (b.bitpos < 0) { L.weights[cnt++] = (uint8_t)cell_sym(L.wtab[s1]); break; }
+                        L.b.weights[cnt++] = (uint8_t)cell_sym(L.b.wtab[s2]);
+                        s2 = cell_base(L.b.wtab[s2]) + b.read((int)cell_nbits(L.b.wtab[s2]));
+                        if (b.bitpos < 0) { L.b.weights[cnt++] = (uint8_t)cell_sym(L.b.wtab[s1]); break; }
                     }
                 }
             }
@@ -240,7 +310,7 @@ __device__ bool huf_build_table(Lds &L, int n, int lane)
     uint32_t part = 0;
     bool bad = false;
     for (int i = lane; i < n; i += 64) {
-        uint32_t w = L.weights[i];
+        uint32_t w = L.b.weights[i];
         if (w > 11) bad = true;
         else if (w) part += 1u << (w - 1);
     }
@@ -251,7 +321,7 @@ __device__ bool huf_build_table(Lds &L, int n, int lane)
     const uint32_t left = (1u << max_bits) - sum;
     if (left & (left - 1)) return false;
     const uint32_t last_w = (uint32_t)zd::hb32(left) + 1;
-    if (lane == 0) L.weights[n] = (uint8_t)last_w;
+    if (lane == 0) L.b.weights[n] = (uint8_t)last_w;
     zd::wave_sync();
     const int nsym = n + 1;
     // rank_start[w] for w = 1..max_bits, computed redundantly by every lane from ballots
@@ -266,7 +336,7 @@ __device__ bool huf_build_table(Lds &L, int n, int lane)
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int s = r * 64 + lane;
-        const uint32_t w = s < nsym ? L.weights[s] : 0u;
+        const uint32_t w = s < nsym ? L.b.weights[s] : 0u;
         my_w[r] = w;
 #pragma unroll
         for (int ww = 1; ww < 12; ww++) cnt[ww] += (uint32_t)__popcll(zd::ballot(w == (uint32_t)ww));
@@ -322,14 +392,14 @@ __device__ int seq_table(Lds &L, uint32_t *tab, int ctrl_al, int ctrl_ok, int mo
     if (lane == 0) {
         int res = -1;
         if (mode == 0) {
-            for (int i = 0; i < def_n; i++) L.norm[i] = def[i];
-            if (fse_build_dtable(tab, L.norm, def_n, def_al, L.next)) { L.ctrl[ctrl_al] = def_al; L.ctrl[ctrl_ok] = 1; res = 0; }
+            for (int i = 0; i < def_n; i++) L.b.norm[i] = def[i];
+            if (fse_build_dtable(tab, L.b.norm, def_n, def_al, L.b.next)) { L.ctrl[ctrl_al] = def_al; L.ctrl[ctrl_ok] = 1; res = 0; }
         } else if (mode == 1) {
             if (len >= 1 && src[0] <= max_sym) { tab[0] = src[0]; L.ctrl[ctrl_al] = 0; L.ctrl[ctrl_ok] = 1; res = 1; }
         } else if (mode == 2) {
             int nsym = 0, al = 0;
-            int used = fse_read_desc(src, len, max_al, max_sym, L.norm, &nsym, &al);
-            if (used > 0 && fse_build_dtable(tab, L.norm, nsym, al, L.next)) { L.ctrl[ctrl_al] = al; L.ctrl[ctrl_ok] = 1; res = used; }
+            int used = fse_read_desc(src, len, max_al, max_sym, L.b.norm, &nsym, &al);
+            if (used > 0 && fse_build_dtable(tab, L.b.norm, nsym, al, L.b.next)) { L.ctrl[ctrl_al] = al; L.ctrl[ctrl_ok] = 1; res = used; }
         } else {
             res = L.ctrl[ctrl_ok] ? 0 : -1;
         }
@@ -349,7 +419,8 @@ __global__ void __launch_bounds__(64) zarc_zstd_decode(const uint8_t *__restrict
                                                        const uint64_t *__restrict__ dst_off, const uint64_t *__restrict__ raw_len,
                                                        const uint32_t *__restrict__ order, uint32_t n_frames,
                                                        uint8_t *__restrict__ lit_scratch, int32_t *__restrict__ status,
-                                                       uint32_t *__restrict__ stored_checksum /* 2 words/frame: has, value */)
+                                                       uint32_t *__restrict__ stored_checksum /* 2 words/frame: has, value */,
+                                                       int dbg /* timing-only ablations: 1 no copies, 2 no sequence decode, 4 no Huffman decode */)
 {
     __shared__ Lds L;
     const int lane = zd::lane_id();
@@ -364,8 +435,6 @@ __global__ void __launch_bounds__(64) zarc_zstd_decode(const uint8_t *__restrict
     if (lane == 0) {
         for (int i = 0; i < 16; i++) L.ctrl[i] = 0;
     }
-    if (lane < 36) L.llx[lane] = D_LL_BASE[lane] | ((uint32_t)D_LL_BITS[lane] << 24);
-    if (lane < 53) L.mlx[lane] = D_ML_BASE[lane] | ((uint32_t)D_ML_BITS[lane] << 24);
     zd::wave_sync();
 
     // ---- frame header (every lane computes the same values) ----
@@ -488,14 +557,14 @@ __global__ void __launch_bounds__(64) zarc_zstd_decode(const uint8_t *__restrict
             const int max_bits = L.ctrl[C_HUF_BITS];
             bool ok = true;
             if (streams == 1) {
-                if (lane == 0) ok = huf_decode_stream(L, max_bits, hp, rem, lit_buf, lit_len);
+                if (lane == 0 && !(dbg & 4)) ok = huf_decode_stream(L, max_bits, hp, rem, lit_buf, lit_len);
             } else {
                 if (rem < 6) { err = ZARC_FRAME_CORRUPT; break; }
                 const uint32_t s1 = hp[0] | ((uint32_t)hp[1] << 8), s2 = hp[2] | ((uint32_t)hp[3] << 8), s3 = hp[4] | ((uint32_t)hp[5] << 8);
                 const uint32_t per = (lit_len + 3) / 4;
                 if (6 + s1 + s2 + s3 > rem || per * 3 > lit_len) { err = ZARC_FRAME_CORRUPT; break; }
                 const uint32_t s4 = rem - 6 - s1 - s2 - s3;
-                if (lane < 4) {
+                if (lane < 4 && !(dbg & 4)) {
                     const uint32_t so = lane == 0 ? 0 : (lane == 1 ? s1 : (lane == 2 ? s1 + s2 : s1 + s2 + s3));
                     const uint32_t sl = lane == 0 ? s1 : (lane == 1 ? s2 : (lane == 2 ? s3 : s4));
                     const uint32_t cntl = lane < 3 ? per : lit_len - 3 * per;
@@ -533,7 +602,7 @@ __global__ void __launch_bounds__(64) zarc_zstd_decode(const uint8_t *__restrict
             sp += r; srem -= (uint32_t)r;
             const int al_l = L.ctrl[C_LL_AL], al_o = L.ctrl[C_OF_AL], al_m = L.ctrl[C_ML_AL];
             // lane 0 owns the bitstream and the FSE states
-            BackBits b;
+            SeqBits b;
             uint32_t sl = 0, so = 0, sm = 0;
             bool okb = true;
             if (lane == 0) {
@@ -543,15 +612,18 @@ __global__ void __launch_bounds__(64) zarc_zstd_decode(const uint8_t *__restrict
             if (zd::ballot(!okb) != 0) { err = ZARC_FRAME_CORRUPT; break; }
             for (uint32_t base = 0; base < nseq && !err; base += SEQ_BATCH) {
                 const uint32_t cnt = nseq - base < SEQ_BATCH ? nseq - base : SEQ_BATCH;
+                if (dbg & 2) continue;
                 if (lane == 0) {
                     for (uint32_t i = 0; i < cnt; i++) {
                         const uint32_t cl = L.ll[sl], co = L.of[so], cm = L.ml[sm];
                         const uint32_t ofc = cell_sym(co), mlc = cell_sym(cm), llc = cell_sym(cl);
                         if (ofc > 31 || mlc > 52 || llc > 35) { okb = false; break; }
                         const uint32_t ofv = (1u << ofc) + b.read((int)ofc);
-                        const uint32_t mx = L.mlx[mlc], lx = L.llx[llc];
-                        const uint32_t ml = (mx & 0xFFFFFF) + b.read((int)(mx >> 24));
-                        const uint32_t ll = (lx & 0xFFFFFF) + b.read((int)(lx >> 24));
+                        uint32_t mbase, mbits, lbase, lbits;
+                        ml_code_info(mlc, mbase, mbits);
+                        ll_code_info(llc, lbase, lbits);
+                        const uint32_t ml = mbase + b.read((int)mbits);
+                        const uint32_t ll = lbase + b.read((int)lbits);
                         uint32_t offset;
                         if (ofv > 3) { offset = ofv - 3; rep2 = rep1; rep1 = rep0; rep0 = offset; }
                         else {
@@ -593,6 +665,7 @@ __global__ void __launch_bounds__(64) zarc_zstd_decode(const uint8_t *__restrict
                     if (zd::ballot(have && offset > dmat) != 0) { err = ZARC_FRAME_CORRUPT; break; }
                     const uint32_t msrc = dmat - offset;
                     const bool far = have && msrc + ml <= bpos;                // source entirely below this batch's output
+                    if (!(dbg & 1)) {
                     // (1) literal runs: short ones one lane per sequence (4 bytes in flight per lane), long ones wave-wide
                     {
                         const uint32_t ns = ll <= 16 ? ll : 0u;
@@ -664,6 +737,7 @@ __global__ void __launch_bounds__(64) zarc_zstd_decode(const uint8_t *__restrict
                         }
                     }
                     zd::wave_sync_global(); // later batches may copy from anything written here
+                    }
                     lp += tot_ll;
                     opos += tot_all;
                 }
