@@ -439,7 +439,7 @@ int zarc_gpu_unpack_batch_device(zarc_gpu_t *h, size_t n, const void *d_frames_b
     Timer t{h};
     int e0, e1, e2, e3;
     ZHIP(t.mark(&e0));
-    hipLaunchKernelGGL(zarc_zstd_decode, dim3((unsigned)n), dim3(64), 0, h->stream, (const uint8_t *)d_frames_base, h->d_frame_off.as<uint64_t>(),
+    hipLaunchKernelGGL(zarc_zstd_decode, dim3((unsigned)n), dim3(64), getenv("ZARC_GPU_DEC_PADLDS") ? atoi(getenv("ZARC_GPU_DEC_PADLDS")) : 0, h->stream, (const uint8_t *)d_frames_base, h->d_frame_off.as<uint64_t>(),
                        h->d_frame_len.as<uint64_t>(), (uint8_t *)d_dst_base, h->d_dst_off.as<uint64_t>(), h->d_raw_len.as<uint64_t>(),
                        h->d_order.as<uint32_t>(), (uint32_t)n, h->d_declit.as<uint8_t>(), h->d_status.as<int32_t>(), h->d_stored_ck.as<uint32_t>(),
                        getenv("ZARC_GPU_DBG_DEC") ? atoi(getenv("ZARC_GPU_DBG_DEC")) : 0);

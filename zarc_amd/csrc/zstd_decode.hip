@@ -153,35 +153,36 @@ struct FwdBits {
     __device__ __forceinline__ uint32_t peek(int k) { return (zd::load_u32(p + (bitpos >> 3)) >> (bitpos & 7)) & ((1u << k) - 1); }
 };
 
-// FSE decode cell: sym | nbits << 8 | base << 16
-__device__ __forceinline__ uint32_t cell_sym(uint32_t c) { return c & 0xFF; }
-__device__ __forceinline__ uint32_t cell_nbits(uint32_t c) { return (c >> 8) & 0xFF; }
-__device__ __forceinline__ uint32_t cell_base(uint32_t c) { return c >> 16; }
+// FSE decode cell, 16 bits: sym (6 bits) | x << 6, where x is the cell's state counter in [count, 2*count).  The
+// number of bits to read and the new-state baseline follow from x and the table accuracy (nbits = al - floor(log2 x),
+// base = (x << nbits) - 2^al), three ALU ops instead of two more bytes per cell: the three sequence tables take
+// 2.5 KiB of LDS instead of 5, which buys decoder occupancy (the kernel is latency-bound: time ~ 1 / waves in flight).
+__device__ __forceinline__ uint32_t cell_sym(uint32_t c) { return c & 63u; }
+__device__ __forceinline__ uint32_t cell_nbits(uint32_t c, int al) { return (uint32_t)(al - zd::hb32(c >> 6)); }
+__device__ __forceinline__ uint32_t cell_base(uint32_t c, int al) { return ((c >> 6) << cell_nbits(c, al)) - (1u << al); }
 
 // Build an FSE decode table from normalized counts (lane-serial).  Returns false on bad distributions.
-__device__ bool fse_build_dtable(uint32_t *tab, const int16_t *norm, int nsym, int al, uint16_t *next /*>=nsym*/)
+__device__ bool fse_build_dtable(uint16_t *tab, const int16_t *norm, int nsym, int al, uint16_t *next /*>=nsym*/)
 {
     const int T = 1 << al;
     int high = T - 1;
     for (int s = 0; s < nsym; s++) {
-        if (norm[s] == -1) { tab[high--] = (uint32_t)s; next[s] = 1; }
+        if (norm[s] == -1) { tab[high--] = (uint16_t)s; next[s] = 1; }
         else next[s] = (uint16_t)norm[s];
     }
     const int step = (T >> 1) + (T >> 3) + 3, mask = T - 1;
     int pos = 0;
     for (int s = 0; s < nsym; s++) {
         for (int i = 0; i < norm[s]; i++) {
-            tab[pos] = (uint32_t)s;
+            tab[pos] = (uint16_t)s;
             do { pos = (pos + step) & mask; } while (pos > high);
         }
     }
     if (pos != 0) return false;
     for (int i = 0; i < T; i++) {
-        uint32_t s = tab[i];
-        uint32_t x = next[s]++;
-        uint32_t nb = (uint32_t)(al - zd::hb32(x));
-        uint32_t base = (x << nb) - (uint32_t)T;
-        tab[i] = s | (nb << 8) | (base << 16);
+        const uint32_t s = tab[i];
+        const uint32_t x = next[s]++;
+        tab[i] = (uint16_t)(s | (x << 6));
     }
     return true;
 }
@@ -228,17 +229,17 @@ __device__ int fse_read_desc(const uint8_t *src, uint32_t len, int max_al, int m
     return (int)((b.bitpos + 7) >> 3);
 }
 
-// 10 212 bytes per wave -> 16 frames in flight per CU.  The table-construction scratch (weights, normalised counts)
+// About 7.5 KiB per wave.  The table-construction scratch (weights, normalised counts)
 // and the per-batch sequence buffer are never live at the same time and share storage.
 struct Lds {
     uint16_t huf[2048];   // sym | nbits << 8
-    uint32_t ll[512], ml[512], of[256];
+    uint16_t ll[512], ml[512], of[256];
     union {
         struct {
             uint8_t weights[256];
             int16_t norm[64];
             uint16_t next[64];
-            uint32_t wtab[64]; // FSE table for Huffman weights (accuracy <= 6)
+            uint16_t wtab[64]; // FSE table for Huffman weights (accuracy <= 6)
         } b;
         uint32_t seq[SEQ_BATCH * 3];
     };
@@ -282,11 +283,11 @@ __device__ int huf_read_weights(Lds &L, const uint8_t *src, uint32_t len, int la
                     for (;;) {
                         if (cnt > 253) { cnt = -1; break; }
                         L.b.weights[cnt++] = (uint8_t)cell_sym(L.b.wtab[s1]);
-                        s1 = cell_base(L.b.wtab[s1]) + b.read((int)cell_nbits(L.b.wtab[s1]));
+                        s1 = cell_base(L.b.wtab[s1], al) + b.read((int)cell_nbits(L.b.wtab[s1], al));
                         if (b.bitpos < 0) { L.b.weights[cnt++] = (uint8_t)cell_sym(L.b.wtab[s2]); break; }
                         if (cnt > 253) { cnt = -1; break; }
                         L.b.weights[cnt++] = (uint8_t)cell_sym(L.b.wtab[s2]);
-                        s2 = cell_base(L.b.wtab[s2]) + b.read((int)cell_nbits(L.b.wtab[s2]));
+                        s2 = cell_base(L.b.wtab[s2], al) + b.read((int)cell_nbits(L.b.wtab[s2], al));
                         if (b.bitpos < 0) { L.b.weights[cnt++] = (uint8_t)cell_sym(L.b.wtab[s1]); break; }
                     }
                 }
@@ -386,7 +387,7 @@ __device__ bool huf_decode_stream(const Lds &L, int max_bits, const uint8_t *src
 
 // (Re)build one sequence table according to its mode.  Uniform entry; the work runs on lane 0.
 // Returns bytes consumed from src, or -1.
-__device__ int seq_table(Lds &L, uint32_t *tab, int ctrl_al, int ctrl_ok, int mode, const uint8_t *src, uint32_t len,
+__device__ int seq_table(Lds &L, uint16_t *tab, int ctrl_al, int ctrl_ok, int mode, const uint8_t *src, uint32_t len,
                          const int8_t *def, int def_n, int def_al, int max_al, int max_sym, int lane)
 {
     if (lane == 0) {
@@ -395,7 +396,7 @@ __device__ int seq_table(Lds &L, uint32_t *tab, int ctrl_al, int ctrl_ok, int mo
             for (int i = 0; i < def_n; i++) L.b.norm[i] = def[i];
             if (fse_build_dtable(tab, L.b.norm, def_n, def_al, L.b.next)) { L.ctrl[ctrl_al] = def_al; L.ctrl[ctrl_ok] = 1; res = 0; }
         } else if (mode == 1) {
-            if (len >= 1 && src[0] <= max_sym) { tab[0] = src[0]; L.ctrl[ctrl_al] = 0; L.ctrl[ctrl_ok] = 1; res = 1; }
+            if (len >= 1 && src[0] <= max_sym) { tab[0] = (uint16_t)(src[0] | (1u << 6)); L.ctrl[ctrl_al] = 0; L.ctrl[ctrl_ok] = 1; res = 1; }
         } else if (mode == 2) {
             int nsym = 0, al = 0;
             int used = fse_read_desc(src, len, max_al, max_sym, L.b.norm, &nsym, &al);
@@ -414,7 +415,7 @@ __device__ int seq_table(Lds &L, uint32_t *tab, int ctrl_al, int ctrl_ok, int mo
 } // namespace
 
 // One wave (64-thread workgroup) per frame.  order[] lists frame indices, largest first.
-__global__ void __launch_bounds__(64) zarc_zstd_decode(const uint8_t *__restrict__ frames_base, const uint64_t *__restrict__ frame_off,
+__global__ void __launch_bounds__(64, 5) zarc_zstd_decode(const uint8_t *__restrict__ frames_base, const uint64_t *__restrict__ frame_off,
                                                        const uint64_t *__restrict__ frame_len, uint8_t *__restrict__ dst_base,
                                                        const uint64_t *__restrict__ dst_off, const uint64_t *__restrict__ raw_len,
                                                        const uint32_t *__restrict__ order, uint32_t n_frames,
@@ -639,9 +640,9 @@ __global__ void __launch_bounds__(64) zarc_zstd_decode(const uint8_t *__restrict
                         }
                         L.seq[i * 3] = ll; L.seq[i * 3 + 1] = ml; L.seq[i * 3 + 2] = offset;
                         if (base + i + 1 < nseq) {
-                            sl = cell_base(cl) + b.read((int)cell_nbits(cl));
-                            sm = cell_base(cm) + b.read((int)cell_nbits(cm));
-                            so = cell_base(co) + b.read((int)cell_nbits(co));
+                            sl = cell_base(cl, al_l) + b.read((int)cell_nbits(cl, al_l));
+                            sm = cell_base(cm, al_m) + b.read((int)cell_nbits(cm, al_m));
+                            so = cell_base(co, al_o) + b.read((int)cell_nbits(co, al_o));
                         }
                         if (b.bitpos < 0) { okb = false; break; }
                     }
