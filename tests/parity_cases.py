@@ -144,3 +144,47 @@ def check_params(engine):
     with pytest.raises(ZarcGpuError):
         engine.set_parameter(31337, 1)    # unknown id
     assert engine.params().checksum_flag == 1
+
+
+def check_unpack_fuzz(engine, oracle, corpus, golden_frames, n_mut, seed, max_raw=140000):
+    """Mutated frames (bit flips, byte smashes, truncations, header edits): the HIP decoder and the oracle decoder
+    must agree on whether the frame is decodable, and on every output byte when it is.  Nothing may hang or fault."""
+    import random
+    d, m = golden_frames
+    rnd = random.Random(seed)
+    pool = [f for f in m["frames"] if 0 < f["raw_len"] <= max_raw]
+    frames, raw_lens, want = [], [], []
+    while len(frames) < n_mut:
+        fr = rnd.choice(pool)
+        data = bytearray(open(os.path.join(d, fr["file"]), "rb").read())
+        if fr["checksum"] and rnd.randrange(2):     # half of the time without the XXH64 trailer, so that damage is not
+            data[4] &= ~0x04                        # simply caught by the checksum and the decoders must agree on
+            del data[-4:]                           # structure (or on the garbage they both produce)
+        kind = rnd.randrange(6)
+        if kind == 0 and len(data) > 12:            # flip one bit somewhere after the magic
+            i = rnd.randrange(4, len(data)); data[i] ^= 1 << rnd.randrange(8)
+        elif kind == 1 and len(data) > 12:          # smash a byte
+            data[rnd.randrange(4, len(data))] = rnd.randrange(256)
+        elif kind == 2 and len(data) > 12:          # truncate
+            data = data[:rnd.randrange(5, len(data))]
+        elif kind == 3:                             # extend with garbage
+            data += bytes(rnd.randrange(256) for _ in range(rnd.randrange(1, 9)))
+        elif kind == 4 and len(data) > 12:          # damage a block header / section header region
+            i = rnd.randrange(5, min(len(data), 40)); data[i] ^= rnd.randrange(1, 256)
+        else:                                       # several random flips
+            for _ in range(rnd.randrange(2, 6)):
+                i = rnd.randrange(4, len(data)); data[i] ^= 1 << rnd.randrange(8)
+        raw_len = fr["raw_len"] if rnd.randrange(8) else max(0, fr["raw_len"] + rnd.choice((-1, 1, 100)))
+        frames.append(bytes(data)); raw_lens.append(raw_len)
+        rc, out, used = oracle.zstd_decode(bytes(data), raw_len)
+        want.append(out if (rc == 0 and used == len(data) and len(out) == raw_len) else None)
+    res = engine.unpack(frames, raw_lens)
+    agree_ok = agree_bad = 0
+    for i, ((out, dig, st), w) in enumerate(zip(res, want)):
+        if w is None:
+            assert st != _lib.FRAME_OK, ("engine accepted a frame the oracle rejects", i, len(frames[i]), raw_lens[i])
+            agree_bad += 1
+        else:
+            assert st == _lib.FRAME_OK and out == w, ("engine rejected/garbled a frame the oracle decodes", i, st)
+            agree_ok += 1
+    return agree_ok, agree_bad

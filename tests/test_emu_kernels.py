@@ -26,3 +26,8 @@ def test_emu_unpack_error_statuses(emu_engine, oracle, corpus, golden_frames):
 
 def test_emu_params(emu_engine):
     pc.check_params(emu_engine)
+
+
+def test_emu_unpack_fuzz_agrees_with_oracle(emu_engine, oracle, corpus, golden_frames):
+    ok, bad = pc.check_unpack_fuzz(emu_engine, oracle, corpus, golden_frames, n_mut=160, seed=1, max_raw=70000)
+    assert bad > 40 and ok >= 0

@@ -131,3 +131,11 @@ def test_gpu_level9_parameter_config4_shape(engine, oracle, corpus, libzstds):
         for z in libzstds:
             assert z.decompress(frame, len(raw))[0] == raw
     e9.close()
+
+
+def test_gpu_unpack_fuzz_agrees_with_oracle(engine, oracle, corpus, golden_frames):
+    tot_ok = tot_bad = 0
+    for seed in range(4):
+        ok, bad = pc.check_unpack_fuzz(engine, oracle, corpus, golden_frames, n_mut=1500, seed=100 + seed, max_raw=310000)
+        tot_ok += ok; tot_bad += bad
+    assert tot_bad > 1000
