@@ -93,6 +93,7 @@ static inline hipError_t hipPeekAtLastError() { return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
 static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+static inline hipError_t hipMemGetInfo(size_t *f, size_t *t) { *f = (size_t)2 << 30; *t = (size_t)8 << 30; return hipSuccess; }
 static inline const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "hipemu error"; }
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int)
 {

@@ -351,7 +351,11 @@ int zarc_gpu_pack_batch_device(zarc_gpu_t *h, size_t n, const void *d_src_base, 
     const size_t per_block = (size_t)ZARC_MAX_SEQ * 8 + (ZARC_BLOCK + 64) + (ZARC_BLOCK + 1024) + sizeof(ZgeBlock);
     size_t budget = h->scratch_budget;
     if (!budget) {
-        budget = (size_t)24 << 30;
+        // up to 64 GiB of scratch (BASELINE configs[1] needs 46 GiB to run as ONE launch per kernel), at most 45 % of what is free
+        size_t free_b = 0, total_b = 0;
+        budget = (size_t)64 << 30;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / 100 * 45 < budget) budget = free_b / 100 * 45;
+        if (budget < ((size_t)1 << 30)) budget = (size_t)1 << 30;
     }
     size_t max_blocks = std::max<size_t>(budget / per_block, 1);
     float ms_match = 0, ms_ent = 0, ms_asm = 0;

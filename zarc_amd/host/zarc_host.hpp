@@ -14,7 +14,7 @@
 // = call order, first occurrence of a digest wins, later duplicates write nothing (content_frame.rs:30-33),
 // offsets are running sums starting at 12 (encode.rs:65,75).  Unlike the reference, writes use write-all
 // semantics (the reference's `writer.write` can short-write, lowlevel_frames.rs:38 -- SURVEY quirk 1).
-// The archive directory / trailer (`finalise`) stay host plumbing outside this path.
+// The archive directory / trailer (`add_file_entry`, `finalise`, `open`) live in zarc_container.hpp.
 #pragma once
 #include "../../include/zarc_gpu.h"
 #include <array>
@@ -147,7 +147,7 @@ class Encoder {
     const std::vector<Digest> &frame_order() const { return order_; } // insertion order (the reference uses a HashMap)
     uint64_t offset() const { return offset_; }
 
-  private:
+  protected: // ArchiveWriter (zarc_container.hpp) adds add_file_entry / finalise on top
     std::ostream &writer_;
     Engine engine_;
     uint16_t edition_ = 1;
