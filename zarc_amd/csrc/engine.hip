@@ -47,6 +47,8 @@ struct zarc_gpu {
     DevBuf d_blocks, d_seq, d_lit, d_out;
     // decoder
     DevBuf d_declit, d_status, d_stored_ck;
+    DevBuf d_queue; // frame queues of the persistent kernels (one u32 each)
+    int num_cus = 1;
     // staging arenas for the host-pointer entry points
     DevBuf d_arena_in, d_arena_out;
     hipEvent_t ev[16] = {};
@@ -178,6 +180,8 @@ int zarc_gpu_create(zarc_gpu_t **out, int device)
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) { delete h; return ZARC_GPU_E_DEVICE; }
     for (auto &e : h->ev)
         if (hipEventCreate(&e) != hipSuccess) { delete h; return ZARC_GPU_E_DEVICE; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) h->num_cus = prop.multiProcessorCount;
     h->params.level = 0;          // CCtx::init(0): default level (crates/zarc/src/encode.rs:62)
     h->params.checksum_flag = 0;  // libzstd default; the zarc CLI switches it on (pack.rs:227)
     h->params.content_size_flag = 1;
@@ -194,7 +198,7 @@ void zarc_gpu_destroy(zarc_gpu_t *h)
     (void)hipStreamSynchronize(h->stream);
     DevBuf *all[] = {&h->d_off, &h->d_len, &h->d_chunk_prefix, &h->d_block_prefix, &h->d_order, &h->d_dst_off, &h->d_dst_len, &h->d_raw_len,
                      &h->d_frame_off, &h->d_frame_len, &h->d_cvs, &h->d_cvs_tmp, &h->d_digests, &h->d_xxh, &h->d_expect, &h->d_blocks, &h->d_seq,
-                     &h->d_lit, &h->d_out, &h->d_declit, &h->d_status, &h->d_stored_ck, &h->d_arena_in, &h->d_arena_out};
+                     &h->d_lit, &h->d_out, &h->d_declit, &h->d_status, &h->d_stored_ck, &h->d_arena_in, &h->d_arena_out, &h->d_queue};
     for (DevBuf *b : all) b->release();
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -378,10 +382,14 @@ int zarc_gpu_pack_batch_device(zarc_gpu_t *h, size_t n, const void *d_src_base, 
         ZHIP(h->d_seq.reserve(nb * (size_t)ZARC_MAX_SEQ * 8));
         ZHIP(h->d_lit.reserve(nb * (size_t)(ZARC_BLOCK + 64)));
         ZHIP(h->d_out.reserve(nb * (size_t)(ZARC_BLOCK + 1024)));
+        ZHIP(h->d_queue.reserve(64));
         int a, b, c, d;
         ZHIP(t.mark(&a));
-        hipLaunchKernelGGL(zarc_zge_match, dim3((unsigned)m), dim3(512), 0, h->stream, P, base, d_off, d_len, h->d_order.as<uint32_t>(), (uint32_t)m,
-                           h->d_block_prefix.as<uint64_t>(), h->d_blocks.as<ZgeBlock>(), h->d_seq.as<uint64_t>(), h->d_lit.as<uint8_t>());
+        ZHIP(hipMemsetAsync(h->d_queue.p, 0, 4, h->stream));
+        const size_t match_grid = std::min<size_t>(m, (size_t)h->num_cus * 2); // two 80 KiB workgroups fit a CU
+        hipLaunchKernelGGL(zarc_zge_match, dim3((unsigned)match_grid), dim3(512), 0, h->stream, P, base, d_off, d_len, h->d_order.as<uint32_t>(), (uint32_t)m,
+                           h->d_block_prefix.as<uint64_t>(), h->d_blocks.as<ZgeBlock>(), h->d_seq.as<uint64_t>(), h->d_lit.as<uint8_t>(),
+                           h->d_queue.as<uint32_t>());
         ZHIP(hipGetLastError());
         ZHIP(t.mark(&b));
         hipLaunchKernelGGL(zarc_zge_entropy, dim3((unsigned)nb), dim3(64), 0, h->stream, (uint32_t)nb, h->d_blocks.as<ZgeBlock>(),
@@ -433,7 +441,9 @@ int zarc_gpu_unpack_batch_device(zarc_gpu_t *h, size_t n, const void *d_frames_b
     std::iota(order.begin(), order.end(), 0u);
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return raw_len[a] > raw_len[b]; });
     if ((rc = upload_u32(h, h->d_order, order.data(), n))) return rc;
-    ZHIP(h->d_declit.reserve(n * (size_t)(ZARC_BLOCK + 64)));
+    const size_t dec_grid = std::min<size_t>(n, (size_t)h->num_cus * 20); // 5 waves per SIMD (launch bounds of the decoder)
+    ZHIP(h->d_declit.reserve(dec_grid * (size_t)(ZARC_BLOCK + 64)));
+    ZHIP(h->d_queue.reserve(64));
     ZHIP(h->d_status.reserve(n * 4));
     ZHIP(h->d_stored_ck.reserve(n * 8));
     if (expect) {
@@ -443,10 +453,11 @@ int zarc_gpu_unpack_batch_device(zarc_gpu_t *h, size_t n, const void *d_frames_b
     Timer t{h};
     int e0, e1, e2, e3;
     ZHIP(t.mark(&e0));
-    hipLaunchKernelGGL(zarc_zstd_decode, dim3((unsigned)n), dim3(64), getenv("ZARC_GPU_DEC_PADLDS") ? atoi(getenv("ZARC_GPU_DEC_PADLDS")) : 0, h->stream, (const uint8_t *)d_frames_base, h->d_frame_off.as<uint64_t>(),
+    ZHIP(hipMemsetAsync(h->d_queue.p, 0, 4, h->stream));
+    hipLaunchKernelGGL(zarc_zstd_decode, dim3((unsigned)dec_grid), dim3(64), getenv("ZARC_GPU_DEC_PADLDS") ? atoi(getenv("ZARC_GPU_DEC_PADLDS")) : 0, h->stream, (const uint8_t *)d_frames_base, h->d_frame_off.as<uint64_t>(),
                        h->d_frame_len.as<uint64_t>(), (uint8_t *)d_dst_base, h->d_dst_off.as<uint64_t>(), h->d_raw_len.as<uint64_t>(),
                        h->d_order.as<uint32_t>(), (uint32_t)n, h->d_declit.as<uint8_t>(), h->d_status.as<int32_t>(), h->d_stored_ck.as<uint32_t>(),
-                       getenv("ZARC_GPU_DBG_DEC") ? atoi(getenv("ZARC_GPU_DBG_DEC")) : 0);
+                       getenv("ZARC_GPU_DBG_DEC") ? atoi(getenv("ZARC_GPU_DBG_DEC")) : 0, h->d_queue.as<uint32_t>());
     ZHIP(hipGetLastError());
     ZHIP(t.mark(&e1));
     // verification passes over the decoded bytes (K2 + XXH64 inside libzstd in the reference)

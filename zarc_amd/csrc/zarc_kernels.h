@@ -41,7 +41,7 @@ __global__ void zarc_blake3_tree(const uint64_t *chunk_prefix, uint32_t n_entrie
 __global__ void zarc_xxh64(const uint8_t *base, const uint64_t *off, const uint64_t *len, uint32_t n_entries, uint64_t *out);
 __global__ void zarc_zstd_decode(const uint8_t *frames_base, const uint64_t *frame_off, const uint64_t *frame_len, uint8_t *dst_base,
                                  const uint64_t *dst_off, const uint64_t *raw_len, const uint32_t *order, uint32_t n_frames,
-                                 uint8_t *lit_scratch, int32_t *status, uint32_t *stored_checksum, int dbg);
+                                 uint8_t *lit_scratch, int32_t *status, uint32_t *stored_checksum, int dbg, uint32_t *queue);
 // status[i]: keeps decode errors; else CHECKSUM if the stored XXH64 differs; else DIGEST if expect differs
 __global__ void zarc_unpack_verdict(uint32_t n, const uint64_t *xxh, const uint32_t *stored_checksum, const uint32_t *digests,
                                     const uint32_t *expect /* may be null */, int32_t *status);
@@ -50,7 +50,7 @@ __global__ void zarc_corpus_fill(uint8_t *base, const uint64_t *off, const uint6
 // encoder
 __global__ void zarc_zge_match(ZgeParams P, const uint8_t *src_base, const uint64_t *src_off, const uint64_t *src_len,
                                const uint32_t *order, uint32_t n_frames, const uint64_t *block_prefix, ZgeBlock *blocks,
-                               uint64_t *seq_scratch, uint8_t *lit_scratch);
+                               uint64_t *seq_scratch, uint8_t *lit_scratch, uint32_t *queue);
 __global__ void zarc_zge_entropy(uint32_t n_blocks, ZgeBlock *blocks, uint64_t *seq_scratch, const uint8_t *lit_scratch,
                                  uint8_t *out_scratch);
 __global__ void zarc_zge_assemble(ZgeParams P, const uint8_t *src_base, const uint64_t *src_off, const uint64_t *src_len,

@@ -49,7 +49,7 @@ struct MatchLds {
     uint32_t wsel[CHUNKS], wlit[CHUNKS];
     uint32_t ctrl[16];
 };
-enum { K_POS = 0, K_REP0 = 1, K_REP1 = 2, K_FLAG = 3, K_NEW0 = 4, K_NEW1 = 5 };
+enum { K_POS = 0, K_REP0 = 1, K_REP1 = 2, K_FLAG = 3, K_NEW0 = 4, K_NEW1 = 5, K_SLOT = 6 };
 
 // Hashes from 32-bit multiplies only (a 64-bit multiply is four quarter-rate VALU ops on gfx950).
 __device__ __forceinline__ uint32_t hash_long(uint64_t v, int bits)
@@ -109,22 +109,30 @@ __device__ __forceinline__ uint32_t match_more(const Win &w, uint32_t p, uint32_
 __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off,
                                                       const uint64_t *__restrict__ src_len, const uint32_t *__restrict__ order, uint32_t n_frames,
                                                       const uint64_t *__restrict__ block_prefix, ZgeBlock *__restrict__ blocks,
-                                                      uint64_t *__restrict__ seq_scratch, uint8_t *__restrict__ lit_scratch)
+                                                      uint64_t *__restrict__ seq_scratch, uint8_t *__restrict__ lit_scratch, uint32_t *__restrict__ queue)
 {
     __shared__ MatchLds L;
     const int tid = (int)threadIdx.x, lane = zd::lane_id();
     const int wave = (int)zd::uniform((uint32_t)zd::wave_id()); // scalar: chunk bounds and the parse walk stay on the SALU
-    const uint32_t f = order[blockIdx.x];
+    const uint64_t lt = (1ull << lane) - 1;
+    const uint32_t seg_mask = (1u << P.seg_log) - 1;
+    const uint32_t cap_max = (uint32_t)(P.cap < CAP_MAX ? P.cap : CAP_MAX);
+
+    // Persistent workgroups: the grid is what the chip holds at once (two per CU); every workgroup takes the next frame
+    // from a queue (largest first), so slow and fast frames balance across XCDs whatever their order in the batch.
+    for (;;) {
+    if (tid == 0) L.ctrl[K_SLOT] = atomicAdd(queue, 1u);
+    zd::lds_barrier();
+    const uint32_t slot = L.ctrl[K_SLOT];
+    if (slot >= n_frames) break; // uniform: every wave leaves once the queue is empty
+    const uint32_t f = order[slot];
     const uint8_t *src = src_base + src_off[f];
     const uint32_t n = (uint32_t)src_len[f]; // the engine rejects entries of 4 GiB or more: positions are 32-bit
     const uint32_t window = n <= (1u << P.window_log) ? (n ? n : 1u) : (1u << P.window_log);
     const uint32_t hash_end = n >= 8 ? n - 7 : 0;
-    // block records / scratch slots are numbered within the sub-batch: block_prefix is indexed by blockIdx
-    const uint64_t first_block = block_prefix[blockIdx.x];
-    const uint32_t nblocks = (uint32_t)(block_prefix[blockIdx.x + 1] - first_block);
-    const uint32_t cap_max = (uint32_t)(P.cap < CAP_MAX ? P.cap : CAP_MAX);
-    const uint64_t lt = (1ull << lane) - 1;
-    const uint32_t seg_mask = (1u << P.seg_log) - 1;
+    // block records / scratch slots are numbered within the sub-batch: block_prefix is indexed by queue slot
+    const uint64_t first_block = block_prefix[slot];
+    const uint32_t nblocks = (uint32_t)(block_prefix[slot + 1] - first_block);
 
     for (int i = tid; i < (1 << TAB_LOG); i += THREADS) { L.tl[i] = 0; L.ts[i] = 0; }
     zd::lds_barrier();
@@ -261,7 +269,7 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                     if (offs[u][k] > p || offs[u][k] > window || idx >= tcount || (P.dbg & 1)) offs[u][k] = 0;
                 // (tried: compacting live candidates to the front so that fewer evaluation slots run -- no gain on hardware)
 #pragma unroll
-                for (int k = 0; k < 4; k++) q8[u][k] = offs[u][k] ? W.ld8(p - offs[u][k]) : 0;
+                for (int k = 0; k < 4; k++) q8[u][k] = offs[u][k] ? ((P.dbg & 256) ? p8[u] ^ (uint64_t)(offs[u][k] & 0xFF0000) : W.ld8(p - offs[u][k])) : 0;
             }
 #pragma unroll
             for (int u = 0; u < PER; u++) {
@@ -280,7 +288,7 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                     const uint64_t x = q8[u][k] ^ p8[u];
                     uint32_t len;
                     if (x) { len = (uint32_t)(zd::ctz64(x) >> 3); if (len > cap) len = cap; }
-                    else len = cap >= 8 ? match_more(W, p, p - off, 8, cap) : cap;
+                    else len = (cap >= 8 && !(P.dbg & 128)) ? match_more(W, p, p - off, 8, cap) : (cap < 8 ? cap : 8u);
                     if (len < (uint32_t)(is_rep ? P.min_rep : P.min_match)) continue;
                     const int32_t sc = score_of(P, len, off, is_rep);
                     if (sc > best_score) { best_score = sc; best_len = len; best_off = off; best_rep = is_rep; }
@@ -292,7 +300,7 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                     if (p - bs < maxb) maxb = (uint32_t)(p - bs);
                     if (q < maxb) maxb = (uint32_t)q;
                     uint32_t back = 0;
-                    if (maxb) {
+                    if (maxb && !(P.dbg & 512)) {
                         if (q >= 8) { // then p >= 8 too
                             const uint64_t x = W.ld8(p - 8) ^ W.ld8(q - 8);
                             back = x ? (uint32_t)(__clzll((long long)x) >> 3) : 8u;
@@ -458,4 +466,5 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
         if (tid == 0) { rec->nseq = nseq; rec->nlit = lp; }
         zd::lds_barrier();
     }
+    } // next frame from the queue
 }

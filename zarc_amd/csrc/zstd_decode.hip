@@ -415,22 +415,17 @@ __device__ int seq_table(Lds &L, uint16_t *tab, int ctrl_al, int ctrl_ok, int mo
 } // namespace
 
 // One wave (64-thread workgroup) per frame.  order[] lists frame indices, largest first.
-__global__ void __launch_bounds__(64, 5) zarc_zstd_decode(const uint8_t *__restrict__ frames_base, const uint64_t *__restrict__ frame_off,
-                                                       const uint64_t *__restrict__ frame_len, uint8_t *__restrict__ dst_base,
-                                                       const uint64_t *__restrict__ dst_off, const uint64_t *__restrict__ raw_len,
-                                                       const uint32_t *__restrict__ order, uint32_t n_frames,
-                                                       uint8_t *__restrict__ lit_scratch, int32_t *__restrict__ status,
-                                                       uint32_t *__restrict__ stored_checksum /* 2 words/frame: has, value */,
-                                                       int dbg /* timing-only ablations: 1 no copies, 2 no sequence decode, 4 no Huffman decode */)
+// one frame, one wave
+__device__ __forceinline__ void decode_frame(Lds &L, const int lane, const uint32_t f, uint8_t *__restrict__ lit_buf,
+                                             const uint8_t *__restrict__ frames_base, const uint64_t *__restrict__ frame_off,
+                                             const uint64_t *__restrict__ frame_len, uint8_t *__restrict__ dst_base,
+                                             const uint64_t *__restrict__ dst_off, const uint64_t *__restrict__ raw_len,
+                                             int32_t *__restrict__ status, uint32_t *__restrict__ stored_checksum, const int dbg)
 {
-    __shared__ Lds L;
-    const int lane = zd::lane_id();
-    const uint32_t f = order[blockIdx.x];
     const uint8_t *src = frames_base + frame_off[f];
     const uint32_t slen = (uint32_t)frame_len[f];
     uint8_t *out = dst_base + dst_off[f];
     const uint64_t cap = raw_len[f];
-    uint8_t *lit_buf = lit_scratch + (uint64_t)blockIdx.x * (BLOCK_MAX + 64);
     int err = ZARC_FRAME_OK;
 
     if (lane == 0) {
@@ -771,5 +766,30 @@ __global__ void __launch_bounds__(64, 5) zarc_zstd_decode(const uint8_t *__restr
         status[f] = err;
         stored_checksum[2 * f] = has_ck;
         stored_checksum[2 * f + 1] = ck;
+    }
+}
+
+// Persistent waves: the grid is sized to what the chip holds at once and every wave takes the next frame from a
+// queue (frames are ordered largest first), so slow and fast frames balance across XCDs whatever their order.
+// Every wave leaves as soon as the queue is empty.
+__global__ void __launch_bounds__(64, 5) zarc_zstd_decode(const uint8_t *__restrict__ frames_base, const uint64_t *__restrict__ frame_off,
+                                                       const uint64_t *__restrict__ frame_len, uint8_t *__restrict__ dst_base,
+                                                       const uint64_t *__restrict__ dst_off, const uint64_t *__restrict__ raw_len,
+                                                       const uint32_t *__restrict__ order, uint32_t n_frames,
+                                                       uint8_t *__restrict__ lit_scratch /* one block per resident wave */, int32_t *__restrict__ status,
+                                                       uint32_t *__restrict__ stored_checksum /* 2 words/frame: has, value */,
+                                                       int dbg /* timing-only ablations: 1 no copies, 2 no sequence decode, 4 no Huffman decode */,
+                                                       uint32_t *__restrict__ queue)
+{
+    __shared__ Lds L;
+    const int lane = zd::lane_id();
+    uint8_t *lit_buf = lit_scratch + (uint64_t)blockIdx.x * (BLOCK_MAX + 64);
+    for (;;) {
+        uint32_t slot = 0;
+        if (lane == 0) slot = atomicAdd(queue, 1u);
+        slot = zd::uniform(slot); // lane 0 is the first active lane
+        if (slot >= n_frames) break;
+        decode_frame(L, lane, order[slot], lit_buf, frames_base, frame_off, frame_len, dst_base, dst_off, raw_len, status, stored_checksum, dbg);
+        zd::wave_sync_global(); // LDS tables and the literal buffer are reused by the next frame
     }
 }
