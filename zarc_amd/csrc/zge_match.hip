@@ -74,36 +74,6 @@ __device__ __forceinline__ int32_t score_of(const ZgeParams &, uint32_t len, uin
     return is_rep ? lits - REP_COST : lits - MATCH_COST - zd::hb32(off);
 }
 
-// 8 bytes at frame position `pos`: from the staged window [lo, hi) in LDS when fully inside, else from HBM/L2
-struct Win {
-    const uint8_t *src;  // frame start in global memory
-    const uint8_t *lds;  // LDS byte that corresponds to frame position `lo`
-    uint32_t lo, hi;
-    __device__ __forceinline__ bool staged(uint32_t pos) const { return pos >= lo && pos + 8 <= hi; }
-    __device__ __forceinline__ uint64_t ld8(uint32_t pos) const
-    {
-        if (staged(pos)) return zd::load_u64(lds + (pos - lo));
-        return zd::load_u64(src + pos);
-    }
-};
-
-// continue a common-prefix count from `n` (a multiple of 8) matched bytes up to `limit`
-__device__ __forceinline__ uint32_t match_more(const Win &w, uint32_t p, uint32_t q, uint32_t n, uint32_t limit)
-{
-    while (n + 8 <= limit) {
-        const uint64_t x = w.ld8(p + n) ^ w.ld8(q + n);
-        if (x) return n + (uint32_t)(zd::ctz64(x) >> 3);
-        n += 8;
-    }
-    if (n < limit) {
-        const uint64_t x = w.ld8(p + n) ^ w.ld8(q + n);
-        uint32_t m = x ? (uint32_t)(zd::ctz64(x) >> 3) : 8u;
-        if (m > limit - n) m = limit - n;
-        n += m;
-    }
-    return n;
-}
-
 } // namespace
 
 __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off,
@@ -181,7 +151,9 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
             const uint32_t erep0 = L.ctrl[K_REP0], erep1 = L.ctrl[K_REP1];
 
             // ---- S0: tile bytes (8 before .. cap+16 after) -> LDS ----
-            Win W;
+            // frame position `pos` of the staged window [lo, hi) lives at LDS byte tbb[pos + wofs] (u32 arithmetic)
+            const uint8_t *const tbb = (const uint8_t *)L.tb;
+            uint32_t wofs;
             {
                 const uint32_t before = (uint32_t)(P.rep_back < REP_BACK_MAX ? P.rep_back : REP_BACK_MAX) + 8;
                 const uint32_t lo = tile >= before ? tile - before : 0;
@@ -192,7 +164,7 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                 const uint32_t *w = (const uint32_t *)(a - mis);
                 const int ndw = (int)((hi - lo + mis + 3) / 4);
                 for (int i = tid; i < ndw; i += THREADS) L.tb[i] = w[i];
-                W.src = src; W.lds = (const uint8_t *)L.tb + mis; W.lo = lo; W.hi = hi;
+                wofs = mis - lo;
             }
             zd::lds_barrier();
             // ---- S1: hashes (index << TAG_BITS | tag) ----
@@ -204,7 +176,7 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                 uint32_t hl = 0xFFFFFFFFu, hs = 0xFFFFFFFFu;
                 p8[u] = 0;
                 if (idx < tcount) {
-                    p8[u] = W.ld8(p);
+                    p8[u] = zd::load_u64(tbb + (uint32_t)(p + wofs));
                     if (p < hash_end && !(P.dbg & 64)) {
                         hl = hash_long(p8[u], TAB_LOG + TAG_BITS);
                         hs = hash_short(p8[u], TAB_LOG + TAG_BITS, 5); // short_bytes is fixed at 5 by the engine
@@ -245,9 +217,11 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                     hc[k * 64 + lane] = (e[k] && (e[k] & TAG_MASK) == (h[k] & TAG_MASK)) ? (uint32_t)segbase + (e[k] >> TAG_BITS) : 0u;
             }
             zd::lds_barrier();
-            // ---- S3: own candidates.  Phase A requests the first source word of every candidate of BOTH positions
-            // (measured: the stage is bound by the number of random L2/HBM requests and their latency, so nothing else is
-            // fetched speculatively); phase B scores them, loading more only for candidates that match 8 bytes. ----
+            // ---- S3: own candidates {long, short, 2 recent offsets}.  The kernel is bound by VALU issue, so the loads carry no
+            // address arithmetic: the tile side and the recent-offset sources (always inside the staged window, see the
+            // idx + rep_back rule) are LDS reads at a lane offset; hash candidates are global loads `frame base (SGPR) + position`.
+            // Phase A requests the first 8 source bytes of every candidate of BOTH positions, phase B scores them and loads more
+            // only for candidates that match 8 bytes. ----
             uint32_t mo[PER], mw[PER];
             uint32_t offs[PER][4];
             uint64_t q8[PER][4];
@@ -269,7 +243,9 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                     if (offs[u][k] > p || offs[u][k] > window || idx >= tcount || (P.dbg & 1)) offs[u][k] = 0;
                 // (tried: compacting live candidates to the front so that fewer evaluation slots run -- no gain on hardware)
 #pragma unroll
-                for (int k = 0; k < 4; k++) q8[u][k] = offs[u][k] ? ((P.dbg & 256) ? p8[u] ^ (uint64_t)(offs[u][k] & 0xFF0000) : W.ld8(p - offs[u][k])) : 0;
+                for (int k = 0; k < 2; k++) q8[u][k] = offs[u][k] ? zd::load_u64(src + (p - offs[u][k])) : 0;
+#pragma unroll
+                for (int k = 2; k < 4; k++) q8[u][k] = offs[u][k] ? zd::load_u64(tbb + (uint32_t)(p - offs[u][k] + wofs)) : 0;
             }
 #pragma unroll
             for (int u = 0; u < PER; u++) {
@@ -285,10 +261,17 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                     const uint32_t off = offs[u][k];
                     if (!off) continue;
                     const bool is_rep = off == erep0 || off == erep1;
-                    const uint64_t x = q8[u][k] ^ p8[u];
-                    uint32_t len;
-                    if (x) { len = (uint32_t)(zd::ctz64(x) >> 3); if (len > cap) len = cap; }
-                    else len = (cap >= 8 && !(P.dbg & 128)) ? match_more(W, p, p - off, 8, cap) : (cap < 8 ? cap : 8u);
+                    uint64_t x = q8[u][k] ^ p8[u];
+                    uint32_t len = 0;
+                    // common prefix, 8 bytes per step; reads past `cap` stay inside the staged window / the padded arena
+                    while (!x && len + 8 < cap) {
+                        len += 8;
+                        const uint64_t a = zd::load_u64(tbb + (uint32_t)(p + len + wofs));
+                        const uint64_t c = k < 2 ? zd::load_u64(src + (p - off + len)) : zd::load_u64(tbb + (uint32_t)(p - off + len + wofs));
+                        x = a ^ c;
+                    }
+                    len += x ? (uint32_t)(zd::ctz64(x) >> 3) : 8u;
+                    if (len > cap) len = cap;
                     if (len < (uint32_t)(is_rep ? P.min_rep : P.min_match)) continue;
                     const int32_t sc = score_of(P, len, off, is_rep);
                     if (sc > best_score) { best_score = sc; best_len = len; best_off = off; best_rep = is_rep; }
@@ -300,9 +283,9 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                     if (p - bs < maxb) maxb = (uint32_t)(p - bs);
                     if (q < maxb) maxb = (uint32_t)q;
                     uint32_t back = 0;
-                    if (maxb && !(P.dbg & 512)) {
-                        if (q >= 8) { // then p >= 8 too
-                            const uint64_t x = W.ld8(p - 8) ^ W.ld8(q - 8);
+                    if (maxb) {
+                        if (q >= 8) { // then p >= 8 too, and p - 8 is inside the staged window
+                            const uint64_t x = zd::load_u64(tbb + (uint32_t)(p - 8 + wofs)) ^ zd::load_u64(src + (q - 8));
                             back = x ? (uint32_t)(__clzll((long long)x) >> 3) : 8u;
                             if (back > maxb) back = maxb;
                         } else {
