@@ -46,7 +46,7 @@ struct MatchLds {
     uint32_t a0[TILE], a1[TILE]; // S1: hashes -> S2: candidates (pos+1) -> S3: own match {offset ; len | back<<16 | rep<<24} -> S4: final match
     uint32_t ex[TILE];            // S4: best backward offer per position; S6: first position outside its chunk reached from each position
     uint32_t tb[(TB_BYTES + 3) / 4];
-    uint32_t wsel[CHUNKS], wlit[CHUNKS];
+    uint32_t wcnt[CHUNKS];       // S6: selected matches << 16 | literals of each chunk
     uint32_t ctrl[16];
 };
 enum { K_POS = 0, K_REP0 = 1, K_REP1 = 2, K_FLAG = 3, K_NEW0 = 4, K_NEW1 = 5, K_SLOT = 6 };
@@ -72,6 +72,25 @@ __device__ __forceinline__ int32_t score_of(const ZgeParams &, uint32_t len, uin
 {
     const int32_t lits = (int32_t)((len << 2) + len);
     return is_rep ? lits - REP_COST : lits - MATCH_COST - zd::hb32(off);
+}
+
+// The window of a tile staged in LDS: frame bytes [lo, hi) = rep_back + 8 bytes before the tile .. cap + 16 after it,
+// fetched as whole dwords starting at the aligned address `w` (one dword per thread: TB_BYTES / 4 <= THREADS).
+struct StageWin { const uint32_t *w; int ndw; uint32_t wofs; };
+static_assert((TB_BYTES + 3) / 4 <= THREADS, "one staged dword per thread");
+__device__ __forceinline__ StageWin stage_window(const ZgeParams &P, const uint8_t *src, uint32_t n, uint32_t tile, uint32_t tend, uint32_t cap_max)
+{
+    const uint32_t before = (uint32_t)(P.rep_back < REP_BACK_MAX ? P.rep_back : REP_BACK_MAX) + 8;
+    const uint32_t lo = tile >= before ? tile - before : 0;
+    uint32_t hi = tend + cap_max + 16;
+    if (hi > n + 16) hi = n + 16; // the arena is padded by ZARC_GPU_PAD
+    const uintptr_t a = (uintptr_t)(src + lo);
+    const uint32_t mis = (uint32_t)(a & 3);
+    StageWin s;
+    s.w = (const uint32_t *)(a - mis);
+    s.ndw = (int)((hi - lo + mis + 3) / 4);
+    s.wofs = mis - lo;
+    return s;
 }
 
 } // namespace
@@ -140,6 +159,7 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
         if (all_same && blen >= 2) { zd::lds_barrier(); continue; } // nothing is inserted for RLE blocks (same rule as the model)
 
         uint32_t nseq = 0, lp = 0; // replicated in every thread
+        uint32_t pf_word = 0, pf_tile = 0xFFFFFFFFu; // S0 prefetch: this thread's dword of the window of tile `pf_tile`
 
         for (uint32_t tile = bs; tile < be; tile += TILE) {
             const uint32_t tend = be - tile > TILE ? tile + TILE : be;
@@ -153,18 +173,19 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
             // ---- S0: tile bytes (8 before .. cap+16 after) -> LDS ----
             // frame position `pos` of the staged window [lo, hi) lives at LDS byte tbb[pos + wofs] (u32 arithmetic)
             const uint8_t *const tbb = (const uint8_t *)L.tb;
-            uint32_t wofs;
+            const StageWin sw = stage_window(P, src, n, tile, tend, cap_max);
+            const uint32_t wofs = sw.wofs;
             {
-                const uint32_t before = (uint32_t)(P.rep_back < REP_BACK_MAX ? P.rep_back : REP_BACK_MAX) + 8;
-                const uint32_t lo = tile >= before ? tile - before : 0;
-                uint32_t hi = tend + cap_max + 16;
-                if (hi > n + 16) hi = n + 16;             // the arena is padded by ZARC_GPU_PAD
-                const uintptr_t a = (uintptr_t)(src + lo);
-                const uint32_t mis = (uint32_t)(a & 3);
-                const uint32_t *w = (const uint32_t *)(a - mis);
-                const int ndw = (int)((hi - lo + mis + 3) / 4);
-                for (int i = tid; i < ndw; i += THREADS) L.tb[i] = w[i];
-                wofs = mis - lo;
+                uint32_t v = pf_word;
+                if (pf_tile != tile && tid < sw.ndw) v = sw.w[tid]; // not prefetched (first tile of a block, or after skipped tiles)
+                if (tid < sw.ndw) L.tb[tid] = v;
+                // request the next tile's window now: it arrives while this tile is being worked on
+                const uint32_t ntile = tile + TILE;
+                if (ntile < be) {
+                    const StageWin nw = stage_window(P, src, n, ntile, be - ntile > TILE ? ntile + TILE : be, cap_max);
+                    if (tid < nw.ndw) pf_word = nw.w[tid];
+                    pf_tile = ntile;
+                }
             }
             zd::lds_barrier();
             // ---- S1: hashes (index << TAG_BITS | tag) ----
@@ -407,23 +428,30 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                     c = mychunk + 1;
                     msel[u] = sel;
                     mlit[u] = lits;
-                    if (lane == 0) { L.wsel[mychunk] = (uint32_t)__popcll(msel[u]); L.wlit[mychunk] = (uint32_t)__popcll(mlit[u]); }
+                    if (lane == 0) L.wcnt[mychunk] = ((uint32_t)__popcll(msel[u]) << 16) | (uint32_t)__popcll(mlit[u]);
                 }
                 // the wave that owns the last chunk knows where the path leaves the tile
                 if (wave == WAVES - 1 && lane == 0) L.ctrl[K_POS] = (uint32_t)(tile - bs) + cur;
             }
             zd::lds_barrier();
-            uint32_t sel_total = 0, lit_total = 0, sel_before[PER], lit_before[PER];
+            // counts of the chunks before mine: a 16-lane scan of the packed per-chunk counts (every wave repeats it)
+            uint32_t sel_total, lit_total, sel_before[PER], lit_before[PER];
+            {
+                uint32_t cv = lane < CHUNKS ? L.wcnt[lane] : 0u;
 #pragma unroll
-            for (int u = 0; u < PER; u++) { sel_before[u] = 0; lit_before[u] = 0; }
+                for (int d = 1; d < CHUNKS; d <<= 1) {
+                    const uint32_t t = zd::shfl_up(cv, (unsigned)d);
+                    if (lane >= d) cv += t;
+                }
+                const uint32_t tot = zd::readlane(cv, CHUNKS - 1);
+                sel_total = tot >> 16;
+                lit_total = tot & 0xFFFFu;
 #pragma unroll
-            for (int cc = 0; cc < CHUNKS; cc++) {
-                const uint32_t s_ = L.wsel[cc], l_ = L.wlit[cc];
-#pragma unroll
-                for (int u = 0; u < PER; u++)
-                    if (cc < wave + u * WAVES) { sel_before[u] += s_; lit_before[u] += l_; }
-                sel_total += s_;
-                lit_total += l_;
+                for (int u = 0; u < PER; u++) {
+                    const uint32_t incl = zd::readlane(cv, (uint32_t)(wave + u * WAVES));
+                    sel_before[u] = (incl >> 16) - (uint32_t)__popcll(msel[u]);
+                    lit_before[u] = (incl & 0xFFFFu) - (uint32_t)__popcll(mlit[u]);
+                }
             }
 #pragma unroll
             for (int u = 0; u < PER; u++) {
