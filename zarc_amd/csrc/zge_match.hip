@@ -43,13 +43,13 @@ constexpr int TB_BYTES = 12 + REP_BACK_MAX + TILE + CAP_MAX + 24; // rep window 
 struct MatchLds {
     uint32_t tl[1 << TAB_LOG];
     uint32_t ts[1 << TAB_LOG];
-    uint32_t a0[TILE], a1[TILE]; // S1: hashes -> S2: candidates (pos+1) -> S3: own match {offset ; len | back<<16 | rep<<24} -> S4: final match
+    uint32_t a0[TILE], a1[TILE]; // S1: hashes -> S2: candidates (pos+1) -> S3: a0 = own match (match_pack) -> S4: a1 = final match
     uint32_t ex[TILE];            // S4: best backward offer per position; S6: first position outside its chunk reached from each position
     uint32_t tb[(TB_BYTES + 3) / 4];
     uint32_t wcnt[CHUNKS];       // S6: selected matches << 16 | literals of each chunk
     uint32_t ctrl[16];
 };
-enum { K_POS = 0, K_REP0 = 1, K_REP1 = 2, K_FLAG = 3, K_NEW0 = 4, K_NEW1 = 5, K_SLOT = 6 };
+enum { K_POS = 0, K_REP0 = 1, K_REP1 = 2, K_FLAG = 3, K_SLOT = 4 };
 
 // Hashes from 32-bit multiplies only (a 64-bit multiply is four quarter-rate VALU ops on gfx950).
 __device__ __forceinline__ uint32_t hash_long(uint64_t v, int bits)
@@ -73,6 +73,12 @@ __device__ __forceinline__ int32_t score_of(const ZgeParams &, uint32_t len, uin
     const int32_t lits = (int32_t)((len << 2) + len);
     return is_rep ? lits - REP_COST : lits - MATCH_COST - zd::hb32(off);
 }
+
+// a match in one LDS word: offset (21 bits) | length (9 bits) << 21 | recent-offset flag << 30
+__device__ __forceinline__ uint32_t match_pack(uint32_t off, uint32_t len, bool rep) { return off | (len << 21) | ((rep ? 1u : 0u) << 30); }
+__device__ __forceinline__ uint32_t match_off(uint32_t m) { return m & 0x1FFFFFu; }
+__device__ __forceinline__ uint32_t match_len(uint32_t m) { return (m >> 21) & 0x1FFu; }
+__device__ __forceinline__ bool match_rep(uint32_t m) { return (m >> 30) & 1u; }
 
 // The window of a tile staged in LDS: frame bytes [lo, hi) = rep_back + 8 bytes before the tile .. cap + 16 after it,
 // fetched as whole dwords starting at the aligned address `w` (one dword per thread: TB_BYTES / 4 <= THREADS).
@@ -205,6 +211,7 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                 }
                 L.a0[idx] = hl;
                 L.a1[idx] = hs;
+                L.ex[idx] = 0; // S4 offers start empty (the previous tile's walk is over)
             }
             zd::lds_barrier();
             // ---- S2: ordered lookup + insert (wave 0); no waits between the steps on hardware ----
@@ -317,10 +324,11 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                     mw[u] = best_len | (back << 16) | ((best_rep ? 1u : 0u) << 24);
                 }
             }
-            zd::lds_barrier(); // every thread has read its candidates from a0/a1
+            // own match -> a0 (each thread overwrites only the candidate slots it has just read itself: no barrier).  A match
+            // fits one word: offsets stay below 2^21 (table positions restart every 2^seg_log <= 2^21 bytes, recent-offset
+            // guesses are shorter still) and lengths below 2^9 (cap 256 + 8 bytes of backward extension).
 #pragma unroll
-            for (int u = 0; u < PER; u++) { L.a0[u * THREADS + tid] = mo[u]; L.a1[u * THREADS + tid] = mw[u]; L.ex[u * THREADS + tid] = 0; }
-            zd::lds_barrier();
+            for (int u = 0; u < PER; u++) L.a0[u * THREADS + tid] = match_pack(mo[u], mw[u] & 0xFFFF, (mw[u] >> 24) & 1);
             // ---- S4: backward propagation.  A position whose match extends b bytes backwards offers it to the b
             // positions before it (ds_max of score << 4 | 8-k: best score wins, then the nearest source); every position
             // then adopts the best offer if it beats its own match.  Same result as scanning the 8 following positions.
@@ -336,7 +344,7 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                     }
                 }
             }
-            zd::lds_barrier();
+            zd::lds_barrier(); // own matches (a0) and offers (ex) are complete
 #pragma unroll
             for (int u = 0; u < PER; u++) {
                 const uint32_t idx = (uint32_t)(u * THREADS + tid);
@@ -347,18 +355,16 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                     const int32_t own = blen_ ? score_of(P, blen_, boff, brep) : 0;
                     if ((int32_t)(offer >> 4) > own) {
                         const uint32_t k = 8u - (offer & 15u);
-                        const uint32_t nw = L.a1[idx + k];
-                        boff = L.a0[idx + k];
-                        blen_ = (nw & 0xFFFF) + k;
-                        brep = (nw >> 24) & 1;
+                        const uint32_t nm = L.a0[idx + k];
+                        boff = match_off(nm);
+                        blen_ = match_len(nm) + k;
+                        brep = match_rep(nm);
                     }
                 }
                 mo[u] = boff;
                 mw[u] = blen_ | ((brep ? 1u : 0u) << 24);
+                L.a1[idx] = match_pack(boff, blen_, brep); // final match (a1 held this thread's short candidate until S3)
             }
-            zd::lds_barrier();
-#pragma unroll
-            for (int u = 0; u < PER; u++) { L.a0[u * THREADS + tid] = mo[u]; L.a1[u * THREADS + tid] = mw[u]; }
             zd::lds_barrier();
             // ---- S5: take flag (one-byte lazy lookahead inside the tile) and successor ----
             bool take[PER];
@@ -369,9 +375,9 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                 const uint32_t my_len = mw[u] & 0xFFFF;
                 take[u] = idx < tcount && my_len != 0;
                 if (take[u] && P.lazy && idx + 1 < tcount) {
-                    const uint32_t w2 = L.a1[idx + 1];
-                    const uint32_t l2 = w2 & 0xFFFF;
-                    if (l2 && score_of(P, l2, L.a0[idx + 1], (w2 >> 24) & 1) > score_of(P, my_len, mo[u], (mw[u] >> 24) & 1) + P.lazy_delta) take[u] = false;
+                    const uint32_t m2 = L.a1[idx + 1];
+                    const uint32_t l2 = match_len(m2);
+                    if (l2 && score_of(P, l2, match_off(m2), match_rep(m2)) > score_of(P, my_len, mo[u], (mw[u] >> 24) & 1) + P.lazy_delta) take[u] = false;
                 }
                 nx[u] = take[u] ? idx + my_len : idx + 1;
             }
@@ -461,18 +467,15 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                 if ((msel[u] >> lane) & 1) {
                     // the literal position stands in for the literal length (difference of neighbours, taken in stage 2)
                     seq_out[nseq + my_sel_idx] = zge_pack_seq(lp + my_lit_idx, mw[u] & 0xFFFF, mo[u]);
-                    if (my_sel_idx + 1 == sel_total) L.ctrl[K_NEW0] = mo[u];
-                    if (my_sel_idx + 2 == sel_total) L.ctrl[K_NEW1] = mo[u];
+                    // offset guesses for the next tile: the offsets of the last two matches selected so far (every thread
+                    // took its copy of the old ones at the top of the tile, so they can be replaced in place)
+                    if (my_sel_idx + 1 == sel_total) { L.ctrl[K_REP0] = mo[u]; if (sel_total == 1) L.ctrl[K_REP1] = erep0; }
+                    if (my_sel_idx + 2 == sel_total) L.ctrl[K_REP1] = mo[u];
                 }
                 if ((mlit[u] >> lane) & 1) lit_out[lp + my_lit_idx] = (uint8_t)p8[u];
             }
             nseq += sel_total;
             lp += lit_total;
-            zd::lds_barrier();
-            if (tid == 0) { // offset guesses for the next tile: offsets of the last two matches selected so far
-                if (sel_total >= 2) { L.ctrl[K_REP0] = L.ctrl[K_NEW0]; L.ctrl[K_REP1] = L.ctrl[K_NEW1]; }
-                else if (sel_total == 1) { L.ctrl[K_REP1] = L.ctrl[K_REP0]; L.ctrl[K_REP0] = L.ctrl[K_NEW0]; }
-            }
         }
         if (tid == 0) { rec->nseq = nseq; rec->nlit = lp; }
         zd::lds_barrier();
