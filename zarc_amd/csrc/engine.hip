@@ -382,10 +382,10 @@ int zarc_gpu_pack_batch_device(zarc_gpu_t *h, size_t n, const void *d_src_base, 
         ZHIP(h->d_seq.reserve(nb * (size_t)ZARC_MAX_SEQ * 8));
         ZHIP(h->d_lit.reserve(nb * (size_t)(ZARC_BLOCK + 64)));
         ZHIP(h->d_out.reserve(nb * (size_t)(ZARC_BLOCK + 1024)));
-        ZHIP(h->d_queue.reserve(64));
+        ZHIP(h->d_queue.reserve(256));
         int a, b, c, d;
         ZHIP(t.mark(&a));
-        ZHIP(hipMemsetAsync(h->d_queue.p, 0, 4, h->stream));
+        ZHIP(hipMemsetAsync(h->d_queue.p, 0, 256, h->stream));
         const size_t match_grid = std::min<size_t>(m, (size_t)h->num_cus * 2); // two 80 KiB workgroups fit a CU
         hipLaunchKernelGGL(zarc_zge_match, dim3((unsigned)match_grid), dim3(512), 0, h->stream, P, base, d_off, d_len, h->d_order.as<uint32_t>(), (uint32_t)m,
                            h->d_block_prefix.as<uint64_t>(), h->d_blocks.as<ZgeBlock>(), h->d_seq.as<uint64_t>(), h->d_lit.as<uint8_t>(),
@@ -402,6 +402,15 @@ int zarc_gpu_pack_batch_device(zarc_gpu_t *h, size_t n, const void *d_src_base, 
         ZHIP(hipGetLastError());
         ZHIP(t.mark(&d));
         ZHIP(hipStreamSynchronize(h->stream)); // the scratch is reused by the next sub-batch; also bounds the event pool
+        if (P.dbg & 1024) { // stage timing of the match finder (diagnostics)
+            unsigned long long prof[12];
+            ZHIP(hipMemcpy(prof, (const char *)h->d_queue.p + 8, sizeof prof, hipMemcpyDeviceToHost));
+            unsigned long long tot = 0;
+            for (int i = 0; i < 9; i++) tot += prof[i];
+            fprintf(stderr, "zge_match stage ticks (%% of %llu):", tot);
+            for (int i = 0; i < 9; i++) fprintf(stderr, " %d:%.1f", i, tot ? 100.0 * (double)prof[i] / (double)tot : 0.0);
+            fprintf(stderr, "\n");
+        }
         ms_match += elapsed(h, a, b);
         ms_ent += elapsed(h, b, c);
         ms_asm += elapsed(h, c, d);
@@ -443,7 +452,7 @@ int zarc_gpu_unpack_batch_device(zarc_gpu_t *h, size_t n, const void *d_frames_b
     if ((rc = upload_u32(h, h->d_order, order.data(), n))) return rc;
     const size_t dec_grid = std::min<size_t>(n, (size_t)h->num_cus * 20); // 5 waves per SIMD (launch bounds of the decoder)
     ZHIP(h->d_declit.reserve(dec_grid * (size_t)(ZARC_BLOCK + 64)));
-    ZHIP(h->d_queue.reserve(64));
+    ZHIP(h->d_queue.reserve(256));
     ZHIP(h->d_status.reserve(n * 4));
     ZHIP(h->d_stored_ck.reserve(n * 8));
     if (expect) {

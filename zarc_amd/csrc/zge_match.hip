@@ -28,6 +28,14 @@
 
 namespace {
 
+#ifdef ZARC_HIPEMU
+#define ZGE_CLOCK() 0ull
+#else
+#define ZGE_CLOCK() ((unsigned long long)__builtin_readcyclecounter())
+#endif
+// stage timing (diagnostics): ticks since the previous mark, accumulated per stage; each mark sits after a barrier
+#define ZGE_PROF(i) do { if ((P.dbg & 1024) && tid == 0) { const unsigned long long now_ = ZGE_CLOCK(); L.prof[i] += now_ - tprev; tprev = now_; } } while (0)
+
 constexpr int TILE = 1024;
 constexpr int THREADS = 512;
 constexpr int WAVES = THREADS / 64;
@@ -48,6 +56,7 @@ struct MatchLds {
     uint32_t tb[(TB_BYTES + 3) / 4];
     uint32_t wcnt[CHUNKS];       // S6: selected matches << 16 | literals of each chunk
     uint32_t ctrl[16];
+    unsigned long long prof[12]; // ZARC_GPU_DBG & 1024: shader-clock ticks per stage, workgroup view from thread 0
 };
 enum { K_POS = 0, K_REP0 = 1, K_REP1 = 2, K_FLAG = 3, K_SLOT = 4 };
 
@@ -112,6 +121,8 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
     const uint64_t lt = (1ull << lane) - 1;
     const uint32_t seg_mask = (1u << P.seg_log) - 1;
     const uint32_t cap_max = (uint32_t)(P.cap < CAP_MAX ? P.cap : CAP_MAX);
+    unsigned long long tprev = ZGE_CLOCK();
+    if (tid < 12) L.prof[tid] = 0;
 
     // Persistent workgroups: the grid is what the chip holds at once (two per CU); every workgroup takes the next frame
     // from a queue (largest first), so slow and fast frames balance across XCDs whatever their order in the batch.
@@ -172,6 +183,7 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
             const uint32_t tcount = (uint32_t)(tend - tile);
             const uint32_t segbase = tile & ~seg_mask;
             zd::lds_barrier(); // K_POS / K_REP* of the previous tile are final; LDS work arrays are free again
+            ZGE_PROF(0);
             const uint32_t pos = bs + L.ctrl[K_POS];
             if (pos >= tend) continue; // whole tile already covered by a match: skip it (nothing is inserted)
             const uint32_t erep0 = L.ctrl[K_REP0], erep1 = L.ctrl[K_REP1];
@@ -194,6 +206,7 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                 }
             }
             zd::lds_barrier();
+            ZGE_PROF(1);
             // ---- S1: hashes (index << TAG_BITS | tag) ----
             uint64_t p8[PER]; // first 8 bytes at each of this thread's positions
 #pragma unroll
@@ -214,6 +227,7 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                 L.ex[idx] = 0; // S4 offers start empty (the previous tile's walk is over)
             }
             zd::lds_barrier();
+            ZGE_PROF(2);
             // ---- S2: ordered lookup + insert (wave 0); no waits between the steps on hardware ----
             // The two tables are independent: wave 0 owns the long table, wave 1 the short one.
             if (wave < 2 && !(P.dbg & 4)) {
@@ -245,6 +259,7 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                     hc[k * 64 + lane] = (e[k] && (e[k] & TAG_MASK) == (h[k] & TAG_MASK)) ? (uint32_t)segbase + (e[k] >> TAG_BITS) : 0u;
             }
             zd::lds_barrier();
+            ZGE_PROF(3);
             // ---- S3: own candidates {long, short, 2 recent offsets}.  The kernel is bound by VALU issue, so the loads carry no
             // address arithmetic: the tile side and the recent-offset sources (always inside the staged window, see the
             // idx + rep_back rule) are LDS reads at a lane offset; hash candidates are global loads `frame base (SGPR) + position`.
@@ -345,6 +360,7 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                 }
             }
             zd::lds_barrier(); // own matches (a0) and offers (ex) are complete
+            ZGE_PROF(4);
 #pragma unroll
             for (int u = 0; u < PER; u++) {
                 const uint32_t idx = (uint32_t)(u * THREADS + tid);
@@ -366,6 +382,7 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                 L.a1[idx] = match_pack(boff, blen_, brep); // final match (a1 held this thread's short candidate until S3)
             }
             zd::lds_barrier();
+            ZGE_PROF(5);
             // ---- S5: take flag (one-byte lazy lookahead inside the tile) and successor ----
             bool take[PER];
             uint32_t nx[PER]; // true successor in tile coordinates (may leave the tile)
@@ -396,6 +413,7 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                 L.ex[idx] = val;
             }
             zd::lds_barrier();
+            ZGE_PROF(6);
             // ---- S6b/c + S7: chunk entries by a chain through ex[], path marks per chunk, emission ----
             uint64_t msel[PER], mlit[PER];
             {
@@ -440,6 +458,7 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                 if (wave == WAVES - 1 && lane == 0) L.ctrl[K_POS] = (uint32_t)(tile - bs) + cur;
             }
             zd::lds_barrier();
+            ZGE_PROF(7);
             // counts of the chunks before mine: a 16-lane scan of the packed per-chunk counts (every wave repeats it)
             uint32_t sel_total, lit_total, sel_before[PER], lit_before[PER];
             {
@@ -476,9 +495,11 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
             }
             nseq += sel_total;
             lp += lit_total;
+            ZGE_PROF(8);
         }
         if (tid == 0) { rec->nseq = nseq; rec->nlit = lp; }
         zd::lds_barrier();
     }
     } // next frame from the queue
+    if ((P.dbg & 1024) && tid < 12) atomicAdd((unsigned long long *)(queue + 2) + tid, L.prof[tid]);
 }
