@@ -255,8 +255,8 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                     zd::wave_lds_order(); // inserts precede the next group's lookups
                 }
 #pragma unroll
-                for (int k = 0; k < CHUNKS; k++) // candidate position (+1), 0 = none or check bits differ
-                    hc[k * 64 + lane] = (e[k] && (e[k] & TAG_MASK) == (h[k] & TAG_MASK)) ? (uint32_t)segbase + (e[k] >> TAG_BITS) : 0u;
+                for (int k = 0; k < CHUNKS; k++) // table entry with its check bits cancelled: a hit has zero low bits and is non-zero
+                    hc[k * 64 + lane] = e[k] ^ (h[k] & TAG_MASK);
             }
             zd::lds_barrier();
             ZGE_PROF(3);
@@ -266,29 +266,56 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
             // Phase A requests the first 8 source bytes of every candidate of BOTH positions, phase B scores them and loads more
             // only for candidates that match 8 bytes. ----
             uint32_t mo[PER], mw[PER];
-            uint32_t offs[PER][4];
-            uint64_t q8[PER][4];
+            uint32_t offs[PER][2];
+            uint64_t q8[PER][2];
 #pragma unroll
             for (int u = 0; u < PER; u++) {
                 const uint32_t idx = (uint32_t)(u * THREADS + tid);
                 const uint32_t p = tile + idx;
                 uint32_t c0 = 0, c1 = 0;
-                if (idx < tcount && !(P.dbg & 5)) { c0 = L.a0[idx]; c1 = L.a1[idx]; }
+                if (idx < tcount && !(P.dbg & 5)) {
+                    const uint32_t w0 = L.a0[idx], w1 = L.a1[idx]; // candidate position (+1): a table hit whose check bits agreed
+                    c0 = (w0 && !(w0 & TAG_MASK)) ? segbase + (w0 >> TAG_BITS) : 0u;
+                    c1 = (w1 && !(w1 & TAG_MASK)) ? segbase + (w1 >> TAG_BITS) : 0u;
+                }
                 offs[u][0] = c0 ? p - (c0 - 1) : 0u;
                 offs[u][1] = (c1 && c1 != c0) ? p - (c1 - 1) : 0u;
                 if (P.short_window_log < 32 && offs[u][1] > (1u << P.short_window_log)) offs[u][1] = 0;
-                offs[u][2] = P.rep_search > 0 ? erep0 : 0u;
-                offs[u][3] = (P.rep_search > 1 && erep1 != erep0) ? erep1 : 0u;
-                if (offs[u][2] > idx + (uint32_t)P.rep_back) offs[u][2] = 0; // recent-offset guesses only from the LDS window
-                if (offs[u][3] > idx + (uint32_t)P.rep_back) offs[u][3] = 0;
 #pragma unroll
-                for (int k = 0; k < 4; k++)
+                for (int k = 0; k < 2; k++)
                     if (offs[u][k] > p || offs[u][k] > window || idx >= tcount || (P.dbg & 1)) offs[u][k] = 0;
-                // (tried: compacting live candidates to the front so that fewer evaluation slots run -- no gain on hardware)
 #pragma unroll
                 for (int k = 0; k < 2; k++) q8[u][k] = offs[u][k] ? zd::load_u64(src + (p - offs[u][k])) : 0;
+            }
+            // while those loads are in flight: the two recent-offset guesses of both positions.  Both sides are inside the staged
+            // window (guesses are limited to idx + rep_back), so this is LDS-only work.  rres = length | (1 << 9 if the second
+            // guess won), 0 = none; equal lengths keep the first.
+            uint32_t rres[PER];
+            {
+                const bool use0 = P.rep_search > 0 && erep0 != 0 && erep0 <= window;
+                const bool use1 = P.rep_search > 1 && erep1 != 0 && erep1 != erep0 && erep1 <= window;
 #pragma unroll
-                for (int k = 2; k < 4; k++) q8[u][k] = offs[u][k] ? zd::load_u64(tbb + (uint32_t)(p - offs[u][k] + wofs)) : 0;
+                for (int u = 0; u < PER; u++) {
+                    const uint32_t idx = (uint32_t)(u * THREADS + tid);
+                    const uint32_t p = tile + idx;
+                    const uint32_t limit = idx < tcount ? (uint32_t)(be - p) : 0u, cap = limit < cap_max ? limit : cap_max;
+                    uint32_t res = 0;
+#pragma unroll
+                    for (int k = 0; k < 2; k++) {
+                        const uint32_t off = k == 0 ? erep0 : erep1;
+                        if (!(k == 0 ? use0 : use1) || off > idx + (uint32_t)P.rep_back || off > p || idx >= tcount || (P.dbg & 1)) continue;
+                        uint64_t x = zd::load_u64(tbb + (uint32_t)(p - off + wofs)) ^ p8[u];
+                        uint32_t len = 0;
+                        while (!x && len + 8 < cap) {
+                            len += 8;
+                            x = zd::load_u64(tbb + (uint32_t)(p + len + wofs)) ^ zd::load_u64(tbb + (uint32_t)(p - off + len + wofs));
+                        }
+                        len += x ? (uint32_t)(zd::ctz64(x) >> 3) : 8u;
+                        if (len > cap) len = cap;
+                        if (len >= (uint32_t)P.min_rep && len > (res & 0x1FFu)) res = len | ((uint32_t)k << 9);
+                    }
+                    rres[u] = res;
+                }
             }
 #pragma unroll
             for (int u = 0; u < PER; u++) {
@@ -300,7 +327,7 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                 bool best_rep = false;
                 int32_t best_score = -1000000;
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
+                for (int k = 0; k < 2; k++) {
                     const uint32_t off = offs[u][k];
                     if (!off) continue;
                     const bool is_rep = off == erep0 || off == erep1;
@@ -309,15 +336,21 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                     // common prefix, 8 bytes per step; reads past `cap` stay inside the staged window / the padded arena
                     while (!x && len + 8 < cap) {
                         len += 8;
-                        const uint64_t a = zd::load_u64(tbb + (uint32_t)(p + len + wofs));
-                        const uint64_t c = k < 2 ? zd::load_u64(src + (p - off + len)) : zd::load_u64(tbb + (uint32_t)(p - off + len + wofs));
-                        x = a ^ c;
+                        x = zd::load_u64(tbb + (uint32_t)(p + len + wofs)) ^ zd::load_u64(src + (p - off + len));
                     }
                     len += x ? (uint32_t)(zd::ctz64(x) >> 3) : 8u;
                     if (len > cap) len = cap;
                     if (len < (uint32_t)(is_rep ? P.min_rep : P.min_match)) continue;
                     const int32_t sc = score_of(P, len, off, is_rep);
                     if (sc > best_score) { best_score = sc; best_len = len; best_off = off; best_rep = is_rep; }
+                }
+                { // the recent-offset guesses rank after the table candidates (ties keep the earlier candidate)
+                    const uint32_t r = rres[u];
+                    if (r) {
+                        const uint32_t len = r & 0x1FFu;
+                        const int32_t sc = score_of(P, len, 1, true);
+                        if (sc > best_score) { best_score = sc; best_len = len; best_off = (r >> 9) ? erep1 : erep0; best_rep = true; }
+                    }
                 }
                 if (best_len && best_score > 0) {
                     // backward-extension potential: equal bytes just before the match and its source
