@@ -694,6 +694,10 @@ static uint32_t matchfind_block(mf_ctx *c, size_t bs, size_t be, zge_seq *seq, u
              * (rep_back bytes before the tile): far guesses almost never match and would cost an HBM access each */
             if (offs[2] > (uint32_t)(p - tile) + (uint32_t)P->rep_back) offs[2] = 0;
             if (offs[3] > (uint32_t)(p - tile) + (uint32_t)P->rep_back) offs[3] = 0;
+            /* table candidates need 8 bytes in front of their source: the kernel fetches source[-8 .. 8) in one load (the
+             * first half feeds the backward extension); sources in the first 8 bytes of a frame are skipped */
+            if (offs[0] + 8 > p) offs[0] = 0;
+            if (offs[1] + 8 > p) offs[1] = 0;
             m->len = 0; m->off = 0;
             for (k = 0; k < 4; k++) {
                 uint32_t off = offs[k], len; int is_rep; int32_t sc;
@@ -708,8 +712,9 @@ static uint32_t matchfind_block(mf_ctx *c, size_t bs, size_t be, zge_seq *seq, u
                 uint32_t back = 0;
                 m->len = best_len; m->off = best_off; m->is_rep = (uint8_t)best_rep;
                 /* backward extension potential: equal bytes just before the match and its source */
-                while (back < (uint32_t)P->back_cap && p - back > bs && p - back > best_off &&
-                       src[p - back - 1] == src[p - back - 1 - best_off]) back++;
+                if (p - best_off >= 8) /* same rule for recent-offset guesses: no extension next to the frame start */
+                    while (back < (uint32_t)P->back_cap && p - back > bs && p - back > best_off &&
+                           src[p - back - 1] == src[p - back - 1 - best_off]) back++;
                 m->back = (uint8_t)back;
             }
         }

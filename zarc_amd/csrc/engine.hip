@@ -406,9 +406,9 @@ int zarc_gpu_pack_batch_device(zarc_gpu_t *h, size_t n, const void *d_src_base, 
             unsigned long long prof[12];
             ZHIP(hipMemcpy(prof, (const char *)h->d_queue.p + 8, sizeof prof, hipMemcpyDeviceToHost));
             unsigned long long tot = 0;
-            for (int i = 0; i < 9; i++) tot += prof[i];
+            for (int i = 0; i < 12; i++) tot += prof[i];
             fprintf(stderr, "zge_match stage ticks (%% of %llu):", tot);
-            for (int i = 0; i < 9; i++) fprintf(stderr, " %d:%.1f", i, tot ? 100.0 * (double)prof[i] / (double)tot : 0.0);
+            for (int i = 0; i < 12; i++) fprintf(stderr, " %d:%.1f", i, tot ? 100.0 * (double)prof[i] / (double)tot : 0.0);
             fprintf(stderr, "\n");
         }
         ms_match += elapsed(h, a, b);

@@ -83,6 +83,8 @@ __device__ __forceinline__ int32_t score_of(const ZgeParams &, uint32_t len, uin
     return is_rep ? lits - REP_COST : lits - MATCH_COST - zd::hb32(off);
 }
 
+struct U128 { uint64_t lo, hi; };
+
 // a match in one LDS word: offset (21 bits) | length (9 bits) << 21 | recent-offset flag << 30
 __device__ __forceinline__ uint32_t match_pack(uint32_t off, uint32_t len, bool rep) { return off | (len << 21) | ((rep ? 1u : 0u) << 30); }
 __device__ __forceinline__ uint32_t match_off(uint32_t m) { return m & 0x1FFFFFu; }
@@ -267,7 +269,7 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
             // only for candidates that match 8 bytes. ----
             uint32_t mo[PER], mw[PER];
             uint32_t offs[PER][2];
-            uint64_t q8[PER][2];
+            U128 q16[PER][2];
 #pragma unroll
             for (int u = 0; u < PER; u++) {
                 const uint32_t idx = (uint32_t)(u * THREADS + tid);
@@ -282,11 +284,15 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                 offs[u][1] = (c1 && c1 != c0) ? p - (c1 - 1) : 0u;
                 if (P.short_window_log < 32 && offs[u][1] > (1u << P.short_window_log)) offs[u][1] = 0;
 #pragma unroll
-                for (int k = 0; k < 2; k++)
-                    if (offs[u][k] > p || offs[u][k] > window || idx >= tcount || (P.dbg & 1)) offs[u][k] = 0;
+                for (int k = 0; k < 2; k++) // the source needs 8 bytes in front of it (frame positions 0..7 are not used as sources)
+                    if (offs[u][k] + 8 > p || offs[u][k] > window || idx >= tcount || (P.dbg & 1)) offs[u][k] = 0;
 #pragma unroll
-                for (int k = 0; k < 2; k++) q8[u][k] = offs[u][k] ? zd::load_u64(src + (p - offs[u][k])) : 0;
+                for (int k = 0; k < 2; k++) { // one 16-byte request: source[-8 .. 0) for the backward extension, source[0 .. 8)
+                    q16[u][k] = U128{0, 0};
+                    if (offs[u][k]) __builtin_memcpy(&q16[u][k], src + (p - offs[u][k] - 8), 16);
+                }
             }
+            ZGE_PROF(9);
             // while those loads are in flight: the two recent-offset guesses of both positions.  Both sides are inside the staged
             // window (guesses are limited to idx + rep_back), so this is LDS-only work.  rres = length | (1 << 9 if the second
             // guess won), 0 = none; equal lengths keep the first.
@@ -317,6 +323,7 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                     rres[u] = res;
                 }
             }
+            ZGE_PROF(10);
 #pragma unroll
             for (int u = 0; u < PER; u++) {
                 const uint32_t idx = (uint32_t)(u * THREADS + tid);
@@ -326,12 +333,13 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                 uint32_t best_len = 0, best_off = 0;
                 bool best_rep = false;
                 int32_t best_score = -1000000;
+                uint64_t best_before = 0; // the 8 bytes in front of the best candidate's source
 #pragma unroll
                 for (int k = 0; k < 2; k++) {
                     const uint32_t off = offs[u][k];
                     if (!off) continue;
                     const bool is_rep = off == erep0 || off == erep1;
-                    uint64_t x = q8[u][k] ^ p8[u];
+                    uint64_t x = q16[u][k].hi ^ p8[u];
                     uint32_t len = 0;
                     // common prefix, 8 bytes per step; reads past `cap` stay inside the staged window / the padded arena
                     while (!x && len + 8 < cap) {
@@ -342,36 +350,34 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                     if (len > cap) len = cap;
                     if (len < (uint32_t)(is_rep ? P.min_rep : P.min_match)) continue;
                     const int32_t sc = score_of(P, len, off, is_rep);
-                    if (sc > best_score) { best_score = sc; best_len = len; best_off = off; best_rep = is_rep; }
+                    if (sc > best_score) { best_score = sc; best_len = len; best_off = off; best_rep = is_rep; best_before = q16[u][k].lo; }
                 }
+                bool from_guess = false;
                 { // the recent-offset guesses rank after the table candidates (ties keep the earlier candidate)
                     const uint32_t r = rres[u];
                     if (r) {
                         const uint32_t len = r & 0x1FFu;
                         const int32_t sc = score_of(P, len, 1, true);
-                        if (sc > best_score) { best_score = sc; best_len = len; best_off = (r >> 9) ? erep1 : erep0; best_rep = true; }
+                        if (sc > best_score) { best_score = sc; best_len = len; best_off = (r >> 9) ? erep1 : erep0; best_rep = true; from_guess = true; }
                     }
                 }
                 if (best_len && best_score > 0) {
-                    // backward-extension potential: equal bytes just before the match and its source
+                    // backward-extension potential: equal bytes just before the match and its source (none next to the frame start)
                     const uint32_t q = p - best_off;
                     uint32_t maxb = (uint32_t)P.back_cap;
                     if (p - bs < maxb) maxb = (uint32_t)(p - bs);
-                    if (q < maxb) maxb = (uint32_t)q;
                     uint32_t back = 0;
-                    if (maxb) {
-                        if (q >= 8) { // then p >= 8 too, and p - 8 is inside the staged window
-                            const uint64_t x = zd::load_u64(tbb + (uint32_t)(p - 8 + wofs)) ^ zd::load_u64(src + (q - 8));
-                            back = x ? (uint32_t)(__clzll((long long)x) >> 3) : 8u;
-                            if (back > maxb) back = maxb;
-                        } else {
-                            while (back < maxb && src[p - back - 1] == src[q - back - 1]) back++;
-                        }
+                    if (maxb && q >= 8) { // then p - 8 and (for a guess) q - 8 are inside the staged window
+                        if (from_guess) best_before = zd::load_u64(tbb + (uint32_t)(q - 8 + wofs));
+                        const uint64_t x = zd::load_u64(tbb + (uint32_t)(p - 8 + wofs)) ^ best_before;
+                        back = x ? (uint32_t)(__clzll((long long)x) >> 3) : 8u;
+                        if (back > maxb) back = maxb;
                     }
                     mo[u] = best_off;
                     mw[u] = best_len | (back << 16) | ((best_rep ? 1u : 0u) << 24);
                 }
             }
+            ZGE_PROF(11);
             // own match -> a0 (each thread overwrites only the candidate slots it has just read itself: no barrier).  A match
             // fits one word: offsets stay below 2^21 (table positions restart every 2^seg_log <= 2^21 bytes, recent-offset
             // guesses are shorter still) and lengths below 2^9 (cap 256 + 8 bytes of backward extension).
