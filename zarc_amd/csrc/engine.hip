@@ -393,7 +393,8 @@ int zarc_gpu_pack_batch_device(zarc_gpu_t *h, size_t n, const void *d_src_base, 
         ZHIP(hipGetLastError());
         ZHIP(t.mark(&b));
         hipLaunchKernelGGL(zarc_zge_entropy, dim3((unsigned)nb), dim3(64), 0, h->stream, (uint32_t)nb, h->d_blocks.as<ZgeBlock>(),
-                           h->d_seq.as<uint64_t>(), h->d_lit.as<uint8_t>(), h->d_out.as<uint8_t>());
+                           h->d_seq.as<uint64_t>(), h->d_lit.as<uint8_t>(), h->d_out.as<uint8_t>(),
+                           (P.dbg & 1024) ? (unsigned long long *)((char *)h->d_queue.p + 128) : (unsigned long long *)nullptr);
         ZHIP(hipGetLastError());
         ZHIP(t.mark(&c));
         hipLaunchKernelGGL(zarc_zge_assemble, dim3((unsigned)m), dim3(256), 0, h->stream, P, base, d_off, d_len, h->d_order.as<uint32_t>(), (uint32_t)m,
@@ -410,6 +411,11 @@ int zarc_gpu_pack_batch_device(zarc_gpu_t *h, size_t n, const void *d_src_base, 
             fprintf(stderr, "zge_match stage ticks (%% of %llu):", tot);
             for (int i = 0; i < 12; i++) fprintf(stderr, " %d:%.1f", i, tot ? 100.0 * (double)prof[i] / (double)tot : 0.0);
             fprintf(stderr, "\n");
+            ZHIP(hipMemcpy(prof, (const char *)h->d_queue.p + 128, 6 * 8, hipMemcpyDeviceToHost));
+            tot = 0;
+            for (int i = 0; i < 6; i++) tot += prof[i];
+            fprintf(stderr, "zge_entropy stage ticks (%% of %llu): hist %.1f huf-build %.1f lit-encode %.1f seq-prepass %.1f seq-tables %.1f seq-encode %.1f\n", tot,
+                    100.0 * prof[0] / tot, 100.0 * prof[1] / tot, 100.0 * prof[2] / tot, 100.0 * prof[3] / tot, 100.0 * prof[4] / tot, 100.0 * prof[5] / tot);
         }
         ms_match += elapsed(h, a, b);
         ms_ent += elapsed(h, b, c);

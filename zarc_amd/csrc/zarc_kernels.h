@@ -52,7 +52,7 @@ __global__ void zarc_zge_match(ZgeParams P, const uint8_t *src_base, const uint6
                                const uint32_t *order, uint32_t n_frames, const uint64_t *block_prefix, ZgeBlock *blocks,
                                uint64_t *seq_scratch, uint8_t *lit_scratch, uint32_t *queue);
 __global__ void zarc_zge_entropy(uint32_t n_blocks, ZgeBlock *blocks, uint64_t *seq_scratch, const uint8_t *lit_scratch,
-                                 uint8_t *out_scratch);
+                                 uint8_t *out_scratch, unsigned long long *prof);
 __global__ void zarc_zge_assemble(ZgeParams P, const uint8_t *src_base, const uint64_t *src_off, const uint64_t *src_len,
                                   const uint32_t *order, uint32_t n_frames, const uint64_t *block_prefix, const ZgeBlock *blocks, const uint8_t *out_scratch,
                                   const uint64_t *xxh, uint8_t *dst_base, const uint64_t *dst_off, uint64_t *dst_len);

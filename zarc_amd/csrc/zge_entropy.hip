@@ -17,6 +17,13 @@
 
 namespace {
 
+#ifdef ZARC_HIPEMU
+#define ZGE_CLOCK() 0ull
+#else
+#define ZGE_CLOCK() ((unsigned long long)__builtin_readcyclecounter())
+#endif
+#define ENT_PROF(i) do { if (prof && lane == 0) { const unsigned long long now_ = ZGE_CLOCK(); atomicAdd(prof + (i), now_ - tprev); tprev = now_; } } while (0)
+
 constexpr int HUF_MAXBITS = 11;
 constexpr uint32_t MIN_HUF_LITERALS = 64;
 
@@ -105,8 +112,7 @@ struct EntLds {
             uint32_t cl[36], co[32], cm[53];
             int16_t norm[3][64];
             uint8_t desc[3][80];
-            uint32_t chain[3][64]; // value | nb << 16 for LL / OF / ML transitions of the current 64 sequences
-            uint8_t symc[3][64];   // LL / OF / ML codes of the current 64 sequences
+            uint64_t pre[3][64];   // LL / OF / ML of the current 64 sequences: in {dnb, dfs} of the symbol, out value | nb << 16
         } s;
     };
 };
@@ -445,10 +451,12 @@ struct WavePacker {
 } // namespace
 
 __global__ void __launch_bounds__(64) zarc_zge_entropy(uint32_t n_blocks, ZgeBlock *__restrict__ blocks, uint64_t *__restrict__ seq_scratch,
-                                                       const uint8_t *__restrict__ lit_scratch, uint8_t *__restrict__ out_scratch)
+                                                       const uint8_t *__restrict__ lit_scratch, uint8_t *__restrict__ out_scratch,
+                                                       unsigned long long *__restrict__ prof /* stage ticks (diagnostics) or null */)
 {
     __shared__ EntLds L;
     const int lane = zd::lane_id();
+    unsigned long long tprev = ZGE_CLOCK();
     const uint32_t bi = blockIdx.x;
     if (bi >= n_blocks) return;
     ZgeBlock *rec = blocks + bi;
@@ -469,6 +477,7 @@ __global__ void __launch_bounds__(64) zarc_zge_entropy(uint32_t n_blocks, ZgeBlo
         zd::wave_sync();
         for (uint32_t i = (uint32_t)lane; i < n; i += 64) atomicAdd(&L.h.count[lit[i]], 1u);
         zd::wave_sync();
+        ENT_PROF(0);
         uint32_t distinct = 0;
 #pragma unroll
         for (int r = 0; r < 4; r++) distinct += (uint32_t)__popcll(zd::ballot(L.h.count[r * 64 + lane] != 0));
@@ -485,6 +494,7 @@ __global__ void __launch_bounds__(64) zarc_zge_entropy(uint32_t n_blocks, ZgeBlo
                 L.ctrl[X_DLEN] = (dlen && est + 3 < n) ? (int)dlen : 0;
             }
             zd::wave_sync();
+            ENT_PROF(1);
             const uint32_t dlen = (uint32_t)L.ctrl[X_DLEN];
             zd::wave_sync();
             if (dlen) {
@@ -546,50 +556,58 @@ __global__ void __launch_bounds__(64) zarc_zge_entropy(uint32_t n_blocks, ZgeBlo
         }
     }
     zd::wave_sync_global();
+    ENT_PROF(2);
 
     // ================= sequences pre-pass =================
     // The match finder stores (literal position, match length, offset); here the literal length becomes the
     // difference of neighbouring literal positions and the offset is resolved against the repcode history
-    // (RFC 8878 3.1.1.5).  The history is a serial chain: lane 0 walks 64 sequences per round out of LDS.  It
-    // starts UNKNOWN (0) in every block because blocks are coded independently of their predecessors' type.
+    // (RFC 8878 3.1.1.5).  It starts UNKNOWN (0) in every block because blocks are coded independently of their
+    // predecessors' type.
+    // The history after sequence i is a function of few neighbours, so 64 sequences resolve at once:
+    //   r0_i = o_i                                   (every rule leaves the coded offset in front)
+    //   r1_i = keep1_i ? r1_{i-1} : o_{i-1}          keep1 = literals present and o_i == r0
+    //   r2_i = keep2_i ? r2_{i-1} : r1_{i-1}         keep2 = o_i hits r0/r1 (with literals) or r1 (without)
+    // "the value at the last position that did not keep" is a ballot + count-leading-zeros per lane.
     {
-        uint32_t r0 = 0, r1 = 0, r2 = 0, carry = 0;
+        uint32_t r0 = 0, r1 = 0, r2 = 0, carry = 0; // wave-uniform history / literal position carried between rounds
         for (uint32_t base = 0; base < nseq; base += 64) {
             const uint32_t cnt = nseq - base < 64 ? nseq - base : 64;
             const bool valid = (uint32_t)lane < cnt;
             const uint64_t s = valid ? seq[base + (uint32_t)lane] : 0;
-            const uint32_t litpos = zge_seq_ll(s), ml = zge_seq_ml(s), off = zge_seq_ofv(s);
+            const uint32_t litpos = zge_seq_ll(s), ml = zge_seq_ml(s), o = zge_seq_ofv(s);
             uint32_t prev = zd::shfl_up(litpos, 1);
             if (lane == 0) prev = carry;
             const uint32_t ll = litpos - prev;
             carry = zd::uniform(zd::shfl(litpos, (int)cnt - 1));
-            L.s.chain[0][lane] = off;
-            L.s.chain[1][lane] = ll;
-            zd::wave_sync();
-            if (lane == 0) {
-                for (uint32_t e = 0; e < cnt; e++) {
-                    const uint32_t o = L.s.chain[0][e];
-                    uint32_t ofv;
-                    if (L.s.chain[1][e] > 0) {
-                        if (o == r0) ofv = 1;
-                        else if (o == r1) { ofv = 2; r1 = r0; r0 = o; }
-                        else if (o == r2) { ofv = 3; r2 = r1; r1 = r0; r0 = o; }
-                        else { ofv = o + 3; r2 = r1; r1 = r0; r0 = o; }
-                    } else {
-                        if (o == r1) { ofv = 1; r1 = r0; r0 = o; }
-                        else if (o == r2) { ofv = 2; r2 = r1; r1 = r0; r0 = o; }
-                        else if (r0 > 1 && o == r0 - 1) { ofv = 3; r2 = r1; r1 = r0; r0 = o; }
-                        else { ofv = o + 3; r2 = r1; r1 = r0; r0 = o; }
-                    }
-                    L.s.chain[2][e] = ofv;
-                }
-            }
-            zd::wave_sync();
-            if (valid) seq[base + (uint32_t)lane] = zge_pack_seq(ll, ml, L.s.chain[2][lane]);
-            zd::wave_sync();
+            const bool z = ll == 0;
+            uint32_t a = zd::shfl_up(o, 1);            // r0 before this sequence
+            if (lane == 0) a = r0;
+            const uint64_t upto = lane == 63 ? ~0ull : ((2ull << lane) - 1); // lanes <= mine
+            // r1 after each sequence
+            const bool keep1 = !valid || (!z && o == a);
+            const uint64_t nk1 = zd::ballot(!keep1) & upto;
+            const uint32_t src1 = zd::shfl(a, nk1 ? 63 - __clzll((long long)nk1) : 0);
+            const uint32_t r1_after = nk1 ? src1 : r1;
+            uint32_t bb = zd::shfl_up(r1_after, 1);   // r1 before this sequence
+            if (lane == 0) bb = r1;
+            // r2 after each sequence
+            const bool keep2 = !valid || (z ? o == bb : (o == a || o == bb));
+            const uint64_t nk2 = zd::ballot(!keep2) & upto;
+            const uint32_t src2 = zd::shfl(bb, nk2 ? 63 - __clzll((long long)nk2) : 0);
+            const uint32_t r2_after = nk2 ? src2 : r2;
+            uint32_t c = zd::shfl_up(r2_after, 1);    // r2 before this sequence
+            if (lane == 0) c = r2;
+            uint32_t ofv;
+            if (!z) ofv = o == a ? 1u : (o == bb ? 2u : (o == c ? 3u : o + 3));
+            else ofv = o == bb ? 1u : (o == c ? 2u : ((a > 1 && o == a - 1) ? 3u : o + 3));
+            if (valid) seq[base + (uint32_t)lane] = zge_pack_seq(ll, ml, ofv);
+            r0 = zd::uniform(zd::shfl(o, (int)cnt - 1));
+            r1 = zd::uniform(zd::shfl(r1_after, (int)cnt - 1));
+            r2 = zd::uniform(zd::shfl(r2_after, (int)cnt - 1));
         }
         zd::wave_sync_global(); // the coding passes below read seq[] with a different lane mapping
     }
+    ENT_PROF(3);
 
     // ================= sequences section =================
     uint32_t ssz = 0;
@@ -626,6 +644,7 @@ __global__ void __launch_bounds__(64) zarc_zge_entropy(uint32_t n_blocks, ZgeBlo
                 if (L.ctrl[X_MODE_M] != 1) fse_build_ctab(tm_, L.s.norm[2], L.ctrl[X_NSYM_M], L.ctrl[X_AL_M], L.cellsym);
             }
             zd::wave_sync();
+            ENT_PROF(4);
             const int mode_l = L.ctrl[X_MODE_L], mode_o = L.ctrl[X_MODE_O], mode_m = L.ctrl[X_MODE_M];
             const uint32_t dl_l = (uint32_t)L.ctrl[X_DL_L], dl_o = (uint32_t)L.ctrl[X_DL_O], dl_m = (uint32_t)L.ctrl[X_DL_M];
             const int al_l = L.ctrl[X_AL_L], al_o = L.ctrl[X_AL_O], al_m = L.ctrl[X_AL_M];
@@ -656,25 +675,39 @@ __global__ void __launch_bounds__(64) zarc_zge_entropy(uint32_t n_blocks, ZgeBlo
                         const uint64_t s = seq[nseq - 1 - done - (uint32_t)lane];
                         ll = zge_seq_ll(s); ml = zge_seq_ml(s); ofv = zge_seq_ofv(s);
                         llc = ll_code(ll); mlc = ml_code(ml); ofc = (uint32_t)zd::hb32(ofv);
-                        L.s.symc[0][lane] = (uint8_t)llc; L.s.symc[1][lane] = (uint8_t)ofc; L.s.symc[2][lane] = (uint8_t)mlc;
+                        // per-symbol transition constants fetched by all lanes at once: the serial loop below then has a
+                        // single dependent LDS access per step (the state table)
+                        L.s.pre[0][lane] = (uint32_t)L.s.dnb_ll[llc] | ((uint64_t)(uint32_t)L.s.dfs_ll[llc] << 32);
+                        L.s.pre[1][lane] = (uint32_t)L.s.dnb_of[ofc] | ((uint64_t)(uint32_t)L.s.dfs_of[ofc] << 32);
+                        L.s.pre[2][lane] = (uint32_t)L.s.dnb_ml[mlc] | ((uint64_t)(uint32_t)L.s.dfs_ml[mlc] << 32);
                     }
                     zd::wave_sync();
                     if (lane < 3) {
+                        uint64_t nxt = L.s.pre[lane][0];
                         for (uint32_t e = 0; e < cnt; e++) {
-                            const int sym = L.s.symc[lane][e];
+                            const uint64_t cur = nxt;
+                            if (e + 1 < cnt) nxt = L.s.pre[lane][e + 1]; // independent of the state: in flight during the step
+                            const int32_t d = (int32_t)(uint32_t)cur, f = (int32_t)(uint32_t)(cur >> 32);
                             uint32_t bits = 0;
                             if (my_mode != 1) {
-                                if (done + e == 0) state = fse_init_state(ct, sym);
-                                else state = fse_step(ct, state, sym, &bits);
+                                if (done + e == 0) { // first symbol coded: the state that needs no bits (fse_init_state)
+                                    const int nb0 = (d + (1 << 15)) >> 16;
+                                    const int value = (nb0 << 16) - d;
+                                    state = ct.state_tab[(value >> nb0) + f];
+                                } else {
+                                    const int nb_ = (int)((state + (uint32_t)d) >> 16);
+                                    bits = (state & ((1u << nb_) - 1)) | ((uint32_t)nb_ << 16);
+                                    state = ct.state_tab[(int)(state >> nb_) + f];
+                                }
                             }
-                            L.s.chain[lane][e] = bits;
+                            ((uint32_t *)&L.s.pre[lane][e])[0] = bits; // value | nb << 16, read back by lane e
                         }
                     }
                     zd::wave_sync();
                     uint64_t lo = 0;
                     uint32_t hi = 0, nb = 0;
                     if ((uint32_t)lane < cnt) {
-                        const uint32_t bo = L.s.chain[1][lane], bm = L.s.chain[2][lane], bl = L.s.chain[0][lane];
+                        const uint32_t bo = (uint32_t)L.s.pre[1][lane], bm = (uint32_t)L.s.pre[2][lane], bl = (uint32_t)L.s.pre[0][lane];
                         // order: OF state bits, ML state bits, LL state bits, LL extra, ML extra, OF extra
                         uint64_t acc = bo & 0xFFFF; uint32_t sh = bo >> 16;
                         acc |= (uint64_t)(bm & 0xFFFF) << sh; sh += bm >> 16;
@@ -706,6 +739,7 @@ __global__ void __launch_bounds__(64) zarc_zge_entropy(uint32_t n_blocks, ZgeBlo
             }
         }
     }
+    ENT_PROF(5);
     const uint32_t csz = fail ? 0u : lsz + ssz;
     if (lane == 0) {
         if (csz && csz < src_len) { rec->type = 2; rec->out_len = csz; }
