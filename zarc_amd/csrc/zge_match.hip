@@ -40,6 +40,7 @@ constexpr int TILE = 1024;
 constexpr int THREADS = 512;
 constexpr int WAVES = THREADS / 64;
 constexpr int PER = TILE / THREADS; // positions per thread
+static_assert(PER == 2, "the kernel is written for two positions per thread");
 constexpr int CHUNKS = TILE / 64;
 constexpr int TAB_LOG = 13;
 constexpr int TAG_BITS = 10;
@@ -58,7 +59,7 @@ struct MatchLds {
     uint32_t ctrl[16];
     unsigned long long prof[12]; // ZARC_GPU_DBG & 1024: shader-clock ticks per stage, workgroup view from thread 0
 };
-enum { K_POS = 0, K_REP0 = 1, K_REP1 = 2, K_FLAG = 3, K_SLOT = 4 };
+enum { K_POS = 0, K_REP0 = 1, K_REP1 = 2, K_FLAG = 3, K_SLOT = 4, K_ANY = 5 };
 
 // Hashes from 32-bit multiplies only (a 64-bit multiply is four quarter-rate VALU ops on gfx950).
 __device__ __forceinline__ uint32_t hash_long(uint64_t v, int bits)
@@ -189,6 +190,7 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
             const uint32_t pos = bs + L.ctrl[K_POS];
             if (pos >= tend) continue; // whole tile already covered by a match: skip it (nothing is inserted)
             const uint32_t erep0 = L.ctrl[K_REP0], erep1 = L.ctrl[K_REP1];
+            if (tid == 0) L.ctrl[K_ANY] = 0; // set by any position of this tile that finds a match
 
             // ---- S0: tile bytes (8 before .. cap+16 after) -> LDS ----
             // frame position `pos` of the staged window [lo, hi) lives at LDS byte tbb[pos + wofs] (u32 arithmetic)
@@ -383,6 +385,7 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
             // guesses are shorter still) and lengths below 2^9 (cap 256 + 8 bytes of backward extension).
 #pragma unroll
             for (int u = 0; u < PER; u++) L.a0[u * THREADS + tid] = match_pack(mo[u], mw[u] & 0xFFFF, (mw[u] >> 24) & 1);
+            if (mo[0] | mo[1]) L.ctrl[K_ANY] = 1; // benign race: every writer stores 1
             // ---- S4: backward propagation.  A position whose match extends b bytes backwards offers it to the b
             // positions before it (ds_max of score << 4 | 8-k: best score wins, then the nearest source); every position
             // then adopts the best offer if it beats its own match.  Same result as scanning the 8 following positions.
@@ -400,6 +403,18 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
             }
             zd::lds_barrier(); // own matches (a0) and offers (ex) are complete
             ZGE_PROF(4);
+            if (L.ctrl[K_ANY] == 0) {
+                // no match anywhere in the tile (incompressible data): the path is all literals, nothing to parse
+                const uint32_t start = (uint32_t)((pos > tile ? pos : tile) - tile);
+#pragma unroll
+                for (int u = 0; u < PER; u++) {
+                    const uint32_t idx = (uint32_t)(u * THREADS + tid);
+                    if (idx >= start && idx < tcount && !(P.dbg & 32)) lit_out[lp + (idx - start)] = (uint8_t)p8[u];
+                }
+                lp += tcount - start;
+                if (tid == 0) L.ctrl[K_POS] = (uint32_t)(tend - bs);
+                continue;
+            }
 #pragma unroll
             for (int u = 0; u < PER; u++) {
                 const uint32_t idx = (uint32_t)(u * THREADS + tid);
