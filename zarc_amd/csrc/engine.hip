@@ -47,6 +47,7 @@ struct zarc_gpu {
     DevBuf d_blocks, d_seq, d_lit, d_out;
     // decoder
     DevBuf d_declit, d_status, d_stored_ck;
+    DevBuf d_slot_prefix, d_zblocks, d_nseq, d_fast, d_seqidx, d_seqs, d_ztables; // decoder fast path (sequences decoded ahead)
     DevBuf d_queue; // frame queues of the persistent kernels (one u32 each)
     int num_cus = 1;
     // staging arenas for the host-pointer entry points
@@ -198,7 +199,8 @@ void zarc_gpu_destroy(zarc_gpu_t *h)
     (void)hipStreamSynchronize(h->stream);
     DevBuf *all[] = {&h->d_off, &h->d_len, &h->d_chunk_prefix, &h->d_block_prefix, &h->d_order, &h->d_dst_off, &h->d_dst_len, &h->d_raw_len,
                      &h->d_frame_off, &h->d_frame_len, &h->d_cvs, &h->d_cvs_tmp, &h->d_digests, &h->d_xxh, &h->d_expect, &h->d_blocks, &h->d_seq,
-                     &h->d_lit, &h->d_out, &h->d_declit, &h->d_status, &h->d_stored_ck, &h->d_arena_in, &h->d_arena_out, &h->d_queue};
+                     &h->d_lit, &h->d_out, &h->d_declit, &h->d_status, &h->d_stored_ck, &h->d_arena_in, &h->d_arena_out, &h->d_queue,
+                     &h->d_slot_prefix, &h->d_zblocks, &h->d_nseq, &h->d_fast, &h->d_seqidx, &h->d_seqs, &h->d_ztables};
     for (DevBuf *b : all) b->release();
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -468,11 +470,47 @@ int zarc_gpu_unpack_batch_device(zarc_gpu_t *h, size_t n, const void *d_frames_b
     Timer t{h};
     int e0, e1, e2, e3;
     ZHIP(t.mark(&e0));
+    // ---- fast path: block scan (lane per frame), then sequence entropy decoding with one lane per block ----
+    bool fastpath = !(getenv("ZARC_GPU_DEC_FAST") && atoi(getenv("ZARC_GPU_DEC_FAST")) == 0);
+    std::vector<uint64_t> slot_prefix(n + 1, 0);
+    for (size_t i = 0; i < n; i++) slot_prefix[i + 1] = slot_prefix[i] + raw_len[i] / ZARC_BLOCK + 2; // blocks a well-formed frame needs, plus slack
+    const size_t nslots = (size_t)slot_prefix[n];
+    if (nslots * (size_t)ZDEC_TABLE_CELLS * 2 > ((size_t)8 << 30)) fastpath = false; // table scratch would be out of proportion (millions of tiny frames)
+    if (fastpath) {
+        if ((rc = upload_u64(h, h->d_slot_prefix, slot_prefix.data(), n + 1))) return rc;
+        ZHIP(h->d_zblocks.reserve(nslots * sizeof(ZdecBlock)));
+        ZHIP(h->d_nseq.reserve(nslots * 4));
+        ZHIP(h->d_fast.reserve(n * 4));
+        ZHIP(h->d_seqidx.reserve(nslots * 8));
+        ZHIP(h->d_ztables.reserve(nslots * (size_t)ZDEC_TABLE_CELLS * 2));
+        ZHIP(hipMemsetAsync(h->d_zblocks.p, 0xFF, nslots * sizeof(ZdecBlock), h->stream));
+        ZHIP(hipMemsetAsync(h->d_nseq.p, 0, nslots * 4, h->stream));
+        hipLaunchKernelGGL(zarc_zdec_scan, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, h->stream, (const uint8_t *)d_frames_base, h->d_frame_off.as<uint64_t>(),
+                           h->d_frame_len.as<uint64_t>(), h->d_raw_len.as<uint64_t>(), (uint32_t)n, h->d_slot_prefix.as<uint64_t>(), h->d_zblocks.as<ZdecBlock>(),
+                           h->d_nseq.as<uint32_t>(), h->d_fast.as<uint32_t>());
+        ZHIP(hipGetLastError());
+        std::vector<uint32_t> nseq(nslots);
+        ZHIP(hipMemcpyAsync(nseq.data(), h->d_nseq.p, nslots * 4, hipMemcpyDeviceToHost, h->stream));
+        ZHIP(hipStreamSynchronize(h->stream)); // the sequence scratch is sized exactly: sum of the blocks' sequence counts
+        std::vector<uint64_t> seqidx(nslots);
+        uint64_t total = 0;
+        for (size_t i = 0; i < nslots; i++) { seqidx[i] = total; total += nseq[i]; }
+        if ((rc = upload_u64(h, h->d_seqidx, seqidx.data(), nslots))) return rc;
+        ZHIP(h->d_seqs.reserve(std::max<uint64_t>(total, 1) * 8));
+        if (total) {
+            hipLaunchKernelGGL(zarc_zdec_seqs, dim3((unsigned)((nslots + 63) / 64)), dim3(64), 0, h->stream, (const uint8_t *)d_frames_base, h->d_frame_off.as<uint64_t>(),
+                               (uint64_t)nslots, h->d_slot_prefix.as<uint64_t>(), h->d_zblocks.as<ZdecBlock>(), h->d_seqidx.as<uint64_t>(), h->d_seqs.as<uint64_t>(),
+                               h->d_ztables.as<uint16_t>(), h->d_fast.as<uint32_t>());
+            ZHIP(hipGetLastError());
+        }
+    }
     ZHIP(hipMemsetAsync(h->d_queue.p, 0, 4, h->stream));
     hipLaunchKernelGGL(zarc_zstd_decode, dim3((unsigned)dec_grid), dim3(64), getenv("ZARC_GPU_DEC_PADLDS") ? atoi(getenv("ZARC_GPU_DEC_PADLDS")) : 0, h->stream, (const uint8_t *)d_frames_base, h->d_frame_off.as<uint64_t>(),
                        h->d_frame_len.as<uint64_t>(), (uint8_t *)d_dst_base, h->d_dst_off.as<uint64_t>(), h->d_raw_len.as<uint64_t>(),
                        h->d_order.as<uint32_t>(), (uint32_t)n, h->d_declit.as<uint8_t>(), h->d_status.as<int32_t>(), h->d_stored_ck.as<uint32_t>(),
-                       getenv("ZARC_GPU_DBG_DEC") ? atoi(getenv("ZARC_GPU_DBG_DEC")) : 0, h->d_queue.as<uint32_t>());
+                       getenv("ZARC_GPU_DBG_DEC") ? atoi(getenv("ZARC_GPU_DBG_DEC")) : 0, h->d_queue.as<uint32_t>(),
+                       fastpath ? h->d_fast.as<uint32_t>() : (const uint32_t *)nullptr, h->d_slot_prefix.as<uint64_t>(), h->d_zblocks.as<ZdecBlock>(),
+                       h->d_seqidx.as<uint64_t>(), h->d_seqs.as<uint64_t>());
     ZHIP(hipGetLastError());
     ZHIP(t.mark(&e1));
     // verification passes over the decoded bytes (K2 + XXH64 inside libzstd in the reference)
@@ -487,6 +525,13 @@ int zarc_gpu_unpack_batch_device(zarc_gpu_t *h, size_t n, const void *d_frames_b
     ZHIP(hipMemcpyAsync(status, h->d_status.p, n * 4, hipMemcpyDeviceToHost, h->stream));
     ZHIP(hipMemcpyAsync(digest, h->d_digests.p, n * 32, hipMemcpyDeviceToHost, h->stream));
     ZHIP(hipStreamSynchronize(h->stream));
+    if (fastpath && getenv("ZARC_GPU_DEC_STATS")) { // diagnostics: how many frames had their sequences decoded ahead
+        std::vector<uint32_t> fl(n);
+        ZHIP(hipMemcpy(fl.data(), h->d_fast.p, n * 4, hipMemcpyDeviceToHost));
+        size_t nf = 0;
+        for (uint32_t v : fl) nf += v != 0;
+        fprintf(stderr, "zstd_decode: %zu of %zu frames on the fast path\n", nf, n);
+    }
     h->ms[ZARC_GPU_T_DECODE] = elapsed(h, e0, e1);
     h->ms[ZARC_GPU_T_XXH64] = elapsed(h, e1, e2);
     h->ms[ZARC_GPU_T_BLAKE3] = elapsed(h, e2, e3);

@@ -34,6 +34,19 @@ __host__ __device__ inline uint32_t zge_seq_ofv(uint64_t s) { return (uint32_t)(
 __host__ __device__ inline uint32_t zge_seq_ll(uint64_t s) { return (uint32_t)((s >> 28) & 0x3FFFFu); }
 __host__ __device__ inline uint32_t zge_seq_ml(uint64_t s) { return (uint32_t)((s >> 46) & 0x3FFFFu); }
 
+// Decoder: one slot per block of a frame (the slots of frame f start at slot_prefix[f]); filled by zarc_zdec_scan.
+struct ZdecBlock {
+    uint32_t frame;    // frame index
+    uint32_t type;     // 0 raw, 1 RLE, 2 compressed; 0xFFFFFFFF = slot not used
+    uint32_t payload;  // frame offset of the block content (after the 3-byte block header)
+    uint32_t size;     // Block_Size field
+    uint32_t nseq;     // compressed blocks: Number_of_Sequences
+    uint32_t seq_hdr;  // compressed blocks with sequences: frame offset of the Symbol_Compression_Modes byte
+    uint32_t state;    // set to 1 by zarc_zdec_seqs once the block's sequences are in the sequence scratch
+    uint32_t pad;
+};
+constexpr int ZDEC_TABLE_CELLS = 1280; // per block slot: LL 512 + ML 512 + OF 256 FSE decode cells (u16)
+
 // ---- kernels -----------------------------------------------------------------------------------
 __global__ void zarc_blake3_chunks(const uint8_t *base, const uint64_t *off, const uint64_t *len, const uint64_t *chunk_prefix,
                                    uint32_t n_entries, uint64_t total_chunks, uint32_t *cvs, uint32_t *digests);
@@ -41,7 +54,15 @@ __global__ void zarc_blake3_tree(const uint64_t *chunk_prefix, uint32_t n_entrie
 __global__ void zarc_xxh64(const uint8_t *base, const uint64_t *off, const uint64_t *len, uint32_t n_entries, uint64_t *out);
 __global__ void zarc_zstd_decode(const uint8_t *frames_base, const uint64_t *frame_off, const uint64_t *frame_len, uint8_t *dst_base,
                                  const uint64_t *dst_off, const uint64_t *raw_len, const uint32_t *order, uint32_t n_frames,
-                                 uint8_t *lit_scratch, int32_t *status, uint32_t *stored_checksum, int dbg, uint32_t *queue);
+                                 uint8_t *lit_scratch, int32_t *status, uint32_t *stored_checksum, int dbg, uint32_t *queue,
+                                 const uint32_t *fast /* per frame: sequences are pre-decoded; may be null */, const uint64_t *slot_prefix,
+                                 const ZdecBlock *zblocks, const uint64_t *seq_index, const uint64_t *seqs);
+// decoder fast path, stage 1: one LANE per frame walks the block headers (no payload is touched) -> block slots, nseq[], fast[]
+__global__ void zarc_zdec_scan(const uint8_t *frames_base, const uint64_t *frame_off, const uint64_t *frame_len, const uint64_t *raw_len,
+                               uint32_t n_frames, const uint64_t *slot_prefix, ZdecBlock *zblocks, uint32_t *nseq_out, uint32_t *fast);
+// stage 2: one LANE per block slot entropy-decodes the block's sequences (FSE tables in HBM scratch) into seqs[]
+__global__ void zarc_zdec_seqs(const uint8_t *frames_base, const uint64_t *frame_off, uint64_t n_slots, const uint64_t *slot_prefix,
+                               ZdecBlock *zblocks, const uint64_t *seq_index, uint64_t *seqs, uint16_t *tables, uint32_t *fast);
 // status[i]: keeps decode errors; else CHECKSUM if the stored XXH64 differs; else DIGEST if expect differs
 __global__ void zarc_unpack_verdict(uint32_t n, const uint64_t *xxh, const uint32_t *stored_checksum, const uint32_t *digests,
                                     const uint32_t *expect /* may be null */, int32_t *status);

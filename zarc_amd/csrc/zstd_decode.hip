@@ -412,6 +412,96 @@ __device__ int seq_table(Lds &L, uint16_t *tab, int ctrl_al, int ctrl_ok, int mo
     return r;
 }
 
+// ---- decoder fast path: sequences entropy-decoded ahead of the frame pass ---------------------------------------
+// The frame pass (one wave per frame) spends most of its time in the lane-0 FSE loop, where a whole wave issues
+// instructions for one lane.  Sequence decoding of a block needs nothing from other blocks except (for Repeat mode)
+// the table description of an earlier block, so it runs here with one LANE per block: 64 serial decoders per wave,
+// each written as plain serial code, tables in HBM scratch (L2-resident).  Anything unusual (odd block structure,
+// invalid descriptions, offsets beyond the format's window) clears fast[frame]: the frame pass then decodes that
+// frame inline exactly as before, so error statuses are decided in one place.
+
+// literals section of a compressed block: bytes it occupies (same checks as the frame pass)
+__device__ bool lit_section_used(const uint8_t *bp, uint32_t blen, uint32_t *lused)
+{
+    if (blen < 2) return false;
+    const uint32_t b0 = bp[0], ltype = b0 & 3, sf = (b0 >> 2) & 3;
+    uint32_t lit_len, hdr;
+    if (ltype < 2) {
+        if (sf == 0 || sf == 2) { lit_len = b0 >> 3; hdr = 1; }
+        else if (sf == 1) { lit_len = (b0 >> 4) | ((uint32_t)bp[1] << 4); hdr = 2; }
+        else { if (blen < 3) return false; lit_len = (b0 >> 4) | ((uint32_t)bp[1] << 4) | ((uint32_t)bp[2] << 12); hdr = 3; }
+        if (lit_len > BLOCK_MAX) return false;
+        if (ltype == 0) { if (hdr + lit_len > blen) return false; *lused = hdr + lit_len; }
+        else { if (hdr + 1 > blen) return false; *lused = hdr + 1; }
+    } else {
+        uint32_t comp;
+        if (blen < 5 && !(sf <= 1 && blen >= 3)) return false;
+        if (sf <= 1) {
+            const uint32_t v = b0 | ((uint32_t)bp[1] << 8) | ((uint32_t)bp[2] << 16);
+            lit_len = (v >> 4) & 0x3FF; comp = (v >> 14) & 0x3FF; hdr = 3;
+        } else if (sf == 2) {
+            const uint32_t v = b0 | ((uint32_t)bp[1] << 8) | ((uint32_t)bp[2] << 16) | ((uint32_t)bp[3] << 24);
+            lit_len = (v >> 4) & 0x3FFF; comp = (v >> 18) & 0x3FFF; hdr = 4;
+        } else {
+            const uint64_t v = (uint64_t)b0 | ((uint64_t)bp[1] << 8) | ((uint64_t)bp[2] << 16) | ((uint64_t)bp[3] << 24) | ((uint64_t)bp[4] << 32);
+            lit_len = (uint32_t)(v >> 4) & 0x3FFFF; comp = (uint32_t)(v >> 22) & 0x3FFFF; hdr = 5;
+        }
+        if (lit_len > BLOCK_MAX || hdr + comp > blen) return false;
+        *lused = hdr + comp;
+    }
+    return true;
+}
+
+// where the three table descriptions of a block's sequences section sit (types 0 LL, 1 OF, 2 ML, in stream order)
+struct SeqHeader { uint32_t mode[3], off[3], len[3], bits_off; };
+__device__ bool scan_seq_header(const uint8_t *src, uint32_t hdr_off, uint32_t end, SeqHeader *h)
+{
+    if (hdr_off + 1 > end) return false;
+    const uint32_t modes = src[hdr_off];
+    if (modes & 3) return false;
+    uint32_t q = hdr_off + 1;
+    int16_t norm[64];
+    for (int t = 0; t < 3; t++) {
+        const uint32_t m = (modes >> (6 - 2 * t)) & 3;
+        uint32_t len = 0;
+        if (m == 1) len = 1;
+        else if (m == 2) {
+            int nsym = 0, al = 0;
+            const int used = fse_read_desc(src + q, end - q, t == 1 ? 8 : 9, t == 0 ? 35 : (t == 1 ? 31 : 52), norm, &nsym, &al);
+            if (used <= 0) return false;
+            len = (uint32_t)used;
+        }
+        if (q + len > end) return false;
+        h->mode[t] = m; h->off[t] = q; h->len[t] = len;
+        q += len;
+    }
+    h->bits_off = q;
+    return true;
+}
+
+// build the decode table of type t from a description found by scan_seq_header (mode 0, 1 or 2); returns the accuracy or -1
+__device__ int build_seq_table(uint16_t *tab, int t, uint32_t mode, const uint8_t *desc, uint32_t len)
+{
+    int16_t norm[64];
+    uint16_t next[64];
+    const int max_sym = t == 0 ? 35 : (t == 1 ? 31 : 52);
+    if (mode == 0) {
+        const int8_t *def = t == 0 ? D_LL_DEFAULT : (t == 1 ? D_OF_DEFAULT : D_ML_DEFAULT);
+        const int def_n = t == 0 ? 36 : (t == 1 ? 29 : 53), def_al = t == 1 ? 5 : 6;
+        for (int i = 0; i < def_n; i++) norm[i] = def[i];
+        return fse_build_dtable(tab, norm, def_n, def_al, next) ? def_al : -1;
+    }
+    if (mode == 1) {
+        if (len < 1 || desc[0] > max_sym) return -1;
+        tab[0] = (uint16_t)(desc[0] | (1u << 6));
+        return 0;
+    }
+    int nsym = 0, al = 0;
+    const int used = fse_read_desc(desc, len, t == 1 ? 8 : 9, max_sym, norm, &nsym, &al);
+    if (used <= 0 || !fse_build_dtable(tab, norm, nsym, al, next)) return -1;
+    return al;
+}
+
 } // namespace
 
 // One wave (64-thread workgroup) per frame.  order[] lists frame indices, largest first.
@@ -420,7 +510,10 @@ __device__ __forceinline__ void decode_frame(Lds &L, const int lane, const uint3
                                              const uint8_t *__restrict__ frames_base, const uint64_t *__restrict__ frame_off,
                                              const uint64_t *__restrict__ frame_len, uint8_t *__restrict__ dst_base,
                                              const uint64_t *__restrict__ dst_off, const uint64_t *__restrict__ raw_len,
-                                             int32_t *__restrict__ status, uint32_t *__restrict__ stored_checksum, const int dbg)
+                                             int32_t *__restrict__ status, uint32_t *__restrict__ stored_checksum, const int dbg,
+                                             const bool use_pre /* sequences of every block are in seqs[] (fast path) */,
+                                             const ZdecBlock *__restrict__ fblocks, const uint64_t *__restrict__ fseq_index,
+                                             const uint64_t *__restrict__ seqs)
 {
     const uint8_t *src = frames_base + frame_off[f];
     const uint32_t slen = (uint32_t)frame_len[f];
@@ -472,7 +565,9 @@ __device__ __forceinline__ void decode_frame(Lds &L, const int lane, const uint3
     uint64_t opos = 0;          // bytes produced
     uint32_t rep0 = 1, rep1 = 4, rep2 = 8;
     bool last = false;
+    uint32_t bidx = 0; // block ordinal inside the frame (slot index of the fast path)
     while (!err && !last) {
+        const uint32_t my_b = bidx++;
         if (pos + 3 > slen) { err = ZARC_FRAME_SRCSIZE; break; }
         const uint32_t bh = zd::uniform((uint32_t)src[pos] | ((uint32_t)src[pos + 1] << 8) | ((uint32_t)src[pos + 2] << 16));
         pos += 3;
@@ -583,33 +678,67 @@ __device__ __forceinline__ void decode_frame(Lds &L, const int lane, const uint3
         const uint64_t block_start = opos;
         uint32_t lp = 0; // literals consumed
         if (nseq > 0) {
-            if (srem < 1) { err = ZARC_FRAME_CORRUPT; break; }
-            const uint32_t modes = sp[0];
-            sp++; srem--;
-            if (modes & 3) { err = ZARC_FRAME_CORRUPT; break; }
-            int r = seq_table(L, L.ll, C_LL_AL, C_LL_OK, (int)(modes >> 6), sp, srem, D_LL_DEFAULT, 36, 6, 9, 35, lane);
-            if (r < 0) { err = ZARC_FRAME_CORRUPT; break; }
-            sp += r; srem -= (uint32_t)r;
-            r = seq_table(L, L.of, C_OF_AL, C_OF_OK, (int)((modes >> 4) & 3), sp, srem, D_OF_DEFAULT, 29, 5, 8, 31, lane);
-            if (r < 0) { err = ZARC_FRAME_CORRUPT; break; }
-            sp += r; srem -= (uint32_t)r;
-            r = seq_table(L, L.ml, C_ML_AL, C_ML_OK, (int)((modes >> 2) & 3), sp, srem, D_ML_DEFAULT, 53, 6, 9, 52, lane);
-            if (r < 0) { err = ZARC_FRAME_CORRUPT; break; }
-            sp += r; srem -= (uint32_t)r;
-            const int al_l = L.ctrl[C_LL_AL], al_o = L.ctrl[C_OF_AL], al_m = L.ctrl[C_ML_AL];
-            // lane 0 owns the bitstream and the FSE states
+            int al_l = 0, al_o = 0, al_m = 0;
             SeqBits b;
             uint32_t sl = 0, so = 0, sm = 0;
             bool okb = true;
-            if (lane == 0) {
-                okb = b.init(sp, srem);
-                if (okb) { sl = b.read(al_l); so = b.read(al_o); sm = b.read(al_m); okb = b.bitpos >= 0; }
+            const uint64_t *pre = nullptr; // this block's sequences (literal length, match length, offset value), already decoded
+            if (use_pre) {
+                const ZdecBlock zb = fblocks[my_b];
+                if (zb.state != 1 || zb.nseq != nseq) { err = ZARC_FRAME_CORRUPT; break; } // not reachable: stage 2 covers every block of a fast frame
+                pre = seqs + fseq_index[my_b];
+            } else {
+                if (srem < 1) { err = ZARC_FRAME_CORRUPT; break; }
+                const uint32_t modes = sp[0];
+                sp++; srem--;
+                if (modes & 3) { err = ZARC_FRAME_CORRUPT; break; }
+                int r = seq_table(L, L.ll, C_LL_AL, C_LL_OK, (int)(modes >> 6), sp, srem, D_LL_DEFAULT, 36, 6, 9, 35, lane);
+                if (r < 0) { err = ZARC_FRAME_CORRUPT; break; }
+                sp += r; srem -= (uint32_t)r;
+                r = seq_table(L, L.of, C_OF_AL, C_OF_OK, (int)((modes >> 4) & 3), sp, srem, D_OF_DEFAULT, 29, 5, 8, 31, lane);
+                if (r < 0) { err = ZARC_FRAME_CORRUPT; break; }
+                sp += r; srem -= (uint32_t)r;
+                r = seq_table(L, L.ml, C_ML_AL, C_ML_OK, (int)((modes >> 2) & 3), sp, srem, D_ML_DEFAULT, 53, 6, 9, 52, lane);
+                if (r < 0) { err = ZARC_FRAME_CORRUPT; break; }
+                sp += r; srem -= (uint32_t)r;
+                al_l = L.ctrl[C_LL_AL]; al_o = L.ctrl[C_OF_AL]; al_m = L.ctrl[C_ML_AL];
+                // lane 0 owns the bitstream and the FSE states
+                if (lane == 0) {
+                    okb = b.init(sp, srem);
+                    if (okb) { sl = b.read(al_l); so = b.read(al_o); sm = b.read(al_m); okb = b.bitpos >= 0; }
+                }
+                if (zd::ballot(!okb) != 0) { err = ZARC_FRAME_CORRUPT; break; }
             }
-            if (zd::ballot(!okb) != 0) { err = ZARC_FRAME_CORRUPT; break; }
             for (uint32_t base = 0; base < nseq && !err; base += SEQ_BATCH) {
                 const uint32_t cnt = nseq - base < SEQ_BATCH ? nseq - base : SEQ_BATCH;
                 if (dbg & 2) continue;
-                if (lane == 0) {
+                if (pre) {
+                    // all lanes fetch their sequence; only the repeat-offset history is a chain (lane 0, out of LDS)
+                    if ((uint32_t)lane < cnt) {
+                        const uint64_t q = pre[base + (uint32_t)lane];
+                        L.seq[lane * 3] = zge_seq_ll(q); L.seq[lane * 3 + 1] = zge_seq_ml(q); L.seq[lane * 3 + 2] = zge_seq_ofv(q);
+                    }
+                    zd::wave_sync();
+                    if (lane == 0) {
+                        for (uint32_t i = 0; i < cnt; i++) {
+                            const uint32_t ofv = L.seq[i * 3 + 2];
+                            uint32_t offset;
+                            if (ofv > 3) { offset = ofv - 3; rep2 = rep1; rep1 = rep0; rep0 = offset; }
+                            else {
+                                const uint32_t idx = ofv - 1 + (L.seq[i * 3] == 0 ? 1u : 0u);
+                                if (idx == 0) offset = rep0;
+                                else {
+                                    offset = idx == 3 ? rep0 - 1 : (idx == 1 ? rep1 : rep2);
+                                    if (offset == 0) { okb = false; break; }
+                                    if (idx > 1) rep2 = rep1;
+                                    rep1 = rep0;
+                                    rep0 = offset;
+                                }
+                            }
+                            L.seq[i * 3 + 2] = offset;
+                        }
+                    }
+                } else if (lane == 0) {
                     for (uint32_t i = 0; i < cnt; i++) {
                         const uint32_t cl = L.ll[sl], co = L.of[so], cm = L.ml[sm];
                         const uint32_t ofc = cell_sym(co), mlc = cell_sym(cm), llc = cell_sym(cl);
@@ -741,7 +870,7 @@ __device__ __forceinline__ void decode_frame(Lds &L, const int lane, const uint3
             }
             if (err) break;
             bool endok = true;
-            if (lane == 0) endok = b.bitpos == 0;
+            if (lane == 0 && !pre) endok = b.bitpos == 0;
             if (zd::ballot(!endok) != 0) { err = ZARC_FRAME_CORRUPT; break; }
         } else if (srem != 0) { err = ZARC_FRAME_CORRUPT; break; }
         // trailing literals
@@ -779,7 +908,9 @@ __global__ void __launch_bounds__(64, 5) zarc_zstd_decode(const uint8_t *__restr
                                                        uint8_t *__restrict__ lit_scratch /* one block per resident wave */, int32_t *__restrict__ status,
                                                        uint32_t *__restrict__ stored_checksum /* 2 words/frame: has, value */,
                                                        int dbg /* timing-only ablations: 1 no copies, 2 no sequence decode, 4 no Huffman decode */,
-                                                       uint32_t *__restrict__ queue)
+                                                       uint32_t *__restrict__ queue, const uint32_t *__restrict__ fast,
+                                                       const uint64_t *__restrict__ slot_prefix, const ZdecBlock *__restrict__ zblocks,
+                                                       const uint64_t *__restrict__ seq_index, const uint64_t *__restrict__ seqs)
 {
     __shared__ Lds L;
     const int lane = zd::lane_id();
@@ -789,7 +920,139 @@ __global__ void __launch_bounds__(64, 5) zarc_zstd_decode(const uint8_t *__restr
         if (lane == 0) slot = atomicAdd(queue, 1u);
         slot = zd::uniform(slot); // lane 0 is the first active lane
         if (slot >= n_frames) break;
-        decode_frame(L, lane, order[slot], lit_buf, frames_base, frame_off, frame_len, dst_base, dst_off, raw_len, status, stored_checksum, dbg);
+        const uint32_t f = order[slot];
+        const bool use_pre = fast != nullptr && zd::uniform(fast[f]) != 0;
+        const uint64_t first = use_pre ? slot_prefix[f] : 0;
+        decode_frame(L, lane, f, lit_buf, frames_base, frame_off, frame_len, dst_base, dst_off, raw_len, status, stored_checksum, dbg, use_pre,
+                     zblocks + first, seq_index + first, seqs);
         zd::wave_sync_global(); // LDS tables and the literal buffer are reused by the next frame
     }
+}
+
+// Stage 1 of the fast path: one lane per frame reads the frame header and walks the block headers.
+__global__ void __launch_bounds__(64) zarc_zdec_scan(const uint8_t *__restrict__ frames_base, const uint64_t *__restrict__ frame_off,
+                                                     const uint64_t *__restrict__ frame_len, const uint64_t *__restrict__ raw_len, uint32_t n_frames,
+                                                     const uint64_t *__restrict__ slot_prefix, ZdecBlock *__restrict__ zblocks,
+                                                     uint32_t *__restrict__ nseq_out, uint32_t *__restrict__ fast)
+{
+    const uint32_t f = blockIdx.x * 64u + threadIdx.x;
+    if (f >= n_frames) return;
+    fast[f] = 0;
+    const uint8_t *src = frames_base + frame_off[f];
+    const uint32_t slen = (uint32_t)frame_len[f];
+    const uint64_t first = slot_prefix[f], maxb = slot_prefix[f + 1] - first;
+    if (slen < 6 || !(src[0] == 0x28 && src[1] == 0xB5 && src[2] == 0x2F && src[3] == 0xFD)) return;
+    const uint32_t desc = src[4];
+    const uint32_t fcs_flag = desc >> 6, ss = (desc >> 5) & 1, did_flag = desc & 3;
+    if (desc & 8) return;
+    const uint32_t did_bytes = did_flag == 3 ? 4u : did_flag, fcs_bytes = fcs_flag == 0 ? ss : (1u << fcs_flag);
+    uint32_t pos = 5 + (ss ? 0u : 1u) + did_bytes + fcs_bytes;
+    if (pos > slen) return;
+    (void)raw_len; // content-size and checksum checks stay with the frame pass
+    bool last = false;
+    uint64_t bi = 0;
+    while (!last) {
+        if (pos + 3 > slen || bi >= maxb) return;
+        const uint32_t bh = (uint32_t)src[pos] | ((uint32_t)src[pos + 1] << 8) | ((uint32_t)src[pos + 2] << 16);
+        pos += 3;
+        last = bh & 1;
+        const uint32_t btype = (bh >> 1) & 3, bsize = bh >> 3;
+        if (btype == 3 || bsize > BLOCK_MAX) return;
+        ZdecBlock zb;
+        zb.frame = f; zb.type = btype; zb.payload = pos; zb.size = bsize; zb.nseq = 0; zb.seq_hdr = 0; zb.state = 0; zb.pad = 0;
+        if (btype == 0) { if (pos + bsize > slen) return; pos += bsize; }
+        else if (btype == 1) { if (pos + 1 > slen) return; pos += 1; }
+        else {
+            if (pos + bsize > slen) return;
+            const uint8_t *bp = src + pos;
+            uint32_t lused = 0;
+            if (!lit_section_used(bp, bsize, &lused)) return;
+            const uint8_t *sp = bp + lused;
+            const uint32_t srem = bsize - lused;
+            if (srem < 1) return;
+            uint32_t nseq, adv;
+            if (sp[0] < 128) { nseq = sp[0]; adv = 1; }
+            else if (sp[0] < 255) { if (srem < 2) return; nseq = ((uint32_t)(sp[0] - 128) << 8) + sp[1]; adv = 2; }
+            else { if (srem < 3) return; nseq = (uint32_t)sp[1] + ((uint32_t)sp[2] << 8) + 0x7F00; adv = 3; }
+            if (nseq == 0 && srem != adv) return;
+            if (nseq > BLOCK_MAX / 3 + 1) return; // more sequences than a block can hold output for
+            zb.nseq = nseq;
+            zb.seq_hdr = pos + lused + adv;
+            pos += bsize;
+        }
+        zblocks[first + bi] = zb;
+        nseq_out[first + bi] = zb.nseq;
+        bi++;
+    }
+    fast[f] = 1;
+}
+
+// Stage 2: one lane per block slot.
+__global__ void __launch_bounds__(64) zarc_zdec_seqs(const uint8_t *__restrict__ frames_base, const uint64_t *__restrict__ frame_off, uint64_t n_slots,
+                                                     const uint64_t *__restrict__ slot_prefix, ZdecBlock *__restrict__ zblocks,
+                                                     const uint64_t *__restrict__ seq_index, uint64_t *__restrict__ seqs, uint16_t *__restrict__ tables,
+                                                     uint32_t *__restrict__ fast)
+{
+    const uint64_t s = (uint64_t)blockIdx.x * 64u + threadIdx.x;
+    if (s >= n_slots) return;
+    const ZdecBlock zb = zblocks[s];
+    if (zb.type != 2 || zb.nseq == 0) return;
+    const uint32_t f = zb.frame;
+    if (!fast[f]) return;
+    const uint8_t *src = frames_base + frame_off[f];
+    const uint32_t end = zb.payload + zb.size;
+    uint16_t *tab = tables + s * (uint64_t)ZDEC_TABLE_CELLS;
+    uint16_t *const tabs[3] = {tab, tab + 1024, tab + 512}; // LL, OF, ML
+    SeqHeader own;
+    bool ok = scan_seq_header(src, zb.seq_hdr, end, &own);
+    int al[3] = {0, 0, 0};
+    for (int t = 0; t < 3 && ok; t++) {
+        uint32_t mode = own.mode[t], off = own.off[t], len = own.len[t];
+        if (mode == 3) { // Repeat: the description lives in the nearest earlier block with sequences that set this table
+            ok = false;
+            const uint64_t first = slot_prefix[f];
+            for (uint64_t j = s; j > first;) {
+                j--;
+                const ZdecBlock pb = zblocks[j];
+                if (pb.type != 2 || pb.nseq == 0) continue;
+                SeqHeader ph;
+                if (!scan_seq_header(src, pb.seq_hdr, pb.payload + pb.size, &ph)) break;
+                if (ph.mode[t] == 3) continue;
+                mode = ph.mode[t]; off = ph.off[t]; len = ph.len[t];
+                ok = true;
+                break;
+            }
+            if (!ok) break;
+        }
+        al[t] = build_seq_table(tabs[t], t, mode, src + off, mode == 2 ? len : (mode == 1 ? 1u : 0u));
+        if (al[t] < 0) ok = false;
+    }
+    if (ok) {
+        SeqBits b;
+        ok = b.init(src + own.bits_off, end - own.bits_off);
+        uint32_t sl = 0, so = 0, sm = 0;
+        if (ok) { sl = b.read(al[0]); so = b.read(al[1]); sm = b.read(al[2]); ok = b.bitpos >= 0; }
+        uint64_t *outp = seqs + seq_index[s];
+        for (uint32_t i = 0; i < zb.nseq && ok; i++) {
+            const uint32_t cl = tabs[0][sl], co = tabs[1][so], cm = tabs[2][sm];
+            const uint32_t ofc = cell_sym(co), mlc = cell_sym(cm), llc = cell_sym(cl);
+            if (ofc > 27 || mlc > 52 || llc > 35) { ok = false; break; } // offsets past the format's largest window: left to the frame pass
+            const uint32_t ofv = (1u << ofc) + b.read((int)ofc);
+            uint32_t mbase, mbits, lbase, lbits;
+            ml_code_info(mlc, mbase, mbits);
+            ll_code_info(llc, lbase, lbits);
+            const uint32_t ml = mbase + b.read((int)mbits);
+            const uint32_t ll = lbase + b.read((int)lbits);
+            outp[i] = zge_pack_seq(ll, ml, ofv);
+            if (i + 1 < zb.nseq) {
+                sl = cell_base(cl, al[0]) + b.read((int)cell_nbits(cl, al[0]));
+                sm = cell_base(cm, al[2]) + b.read((int)cell_nbits(cm, al[2]));
+                so = cell_base(co, al[1]) + b.read((int)cell_nbits(co, al[1]));
+            }
+            if (b.bitpos < 0) ok = false;
+        }
+        if (ok && b.bitpos != 0) ok = false;
+    }
+    if (ok) zblocks[s].state = 1;
+    else fast[f] = 0; // the frame pass decodes this frame inline and reports whatever is wrong with it
 }
