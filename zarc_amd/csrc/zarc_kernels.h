@@ -43,8 +43,14 @@ struct ZdecBlock {
     uint32_t nseq;     // compressed blocks: Number_of_Sequences
     uint32_t seq_hdr;  // compressed blocks with sequences: frame offset of the Symbol_Compression_Modes byte
     uint32_t state;    // set to 1 by zarc_zdec_seqs once the block's sequences are in the sequence scratch
-    uint32_t pad;
+    uint32_t rep[3];   // repeat-offset history after the block, symbolic (see zdec_ref): absolute, or "history slot at block start minus delta"
+    uint32_t pad[3];
 };
+// Fast-path sequences are stored with zge_pack_seq(); the offset field is already resolved against the repeat-offset history
+// as far as the block alone allows: bit 17 of the literal-length field set = the offset is (history slot at block start) - delta,
+// the offset field then holds slot | delta << 2; otherwise the offset field is the absolute offset.
+constexpr uint32_t ZDEC_LL_REF = 1u << 17;
+constexpr uint32_t ZDEC_REP_REF = 0x80000000u; // same idea for ZdecBlock::rep[]: REF | slot | delta << 2
 constexpr int ZDEC_TABLE_CELLS = 1280; // per block slot: LL 512 + ML 512 + OF 256 FSE decode cells (u16)
 
 // ---- kernels -----------------------------------------------------------------------------------

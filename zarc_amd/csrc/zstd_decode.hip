@@ -712,32 +712,22 @@ __device__ __forceinline__ void decode_frame(Lds &L, const int lane, const uint3
             for (uint32_t base = 0; base < nseq && !err; base += SEQ_BATCH) {
                 const uint32_t cnt = nseq - base < SEQ_BATCH ? nseq - base : SEQ_BATCH;
                 if (dbg & 2) continue;
+                uint32_t p_ll = 0, p_ml = 0, p_off = 1;
                 if (pre) {
-                    // all lanes fetch their sequence; only the repeat-offset history is a chain (lane 0, out of LDS)
+                    // every lane fetches its sequence; stage 2 already resolved the offset as far as the block alone allows, what is
+                    // left refers to the history at the start of the block (rep0..2 stay fixed during a pre-decoded block)
+                    bool pbad = false;
                     if ((uint32_t)lane < cnt) {
                         const uint64_t q = pre[base + (uint32_t)lane];
-                        L.seq[lane * 3] = zge_seq_ll(q); L.seq[lane * 3 + 1] = zge_seq_ml(q); L.seq[lane * 3 + 2] = zge_seq_ofv(q);
+                        const uint32_t llr = zge_seq_ll(q), v = zge_seq_ofv(q);
+                        p_ll = llr & (ZDEC_LL_REF - 1);
+                        p_ml = zge_seq_ml(q);
+                        if (llr & ZDEC_LL_REF) {
+                            const uint32_t slot = v & 3, delta = v >> 2, hist = slot == 0 ? rep0 : (slot == 1 ? rep1 : rep2);
+                            if (hist <= delta) pbad = true; else p_off = hist - delta;
+                        } else p_off = v;
                     }
-                    zd::wave_sync();
-                    if (lane == 0) {
-                        for (uint32_t i = 0; i < cnt; i++) {
-                            const uint32_t ofv = L.seq[i * 3 + 2];
-                            uint32_t offset;
-                            if (ofv > 3) { offset = ofv - 3; rep2 = rep1; rep1 = rep0; rep0 = offset; }
-                            else {
-                                const uint32_t idx = ofv - 1 + (L.seq[i * 3] == 0 ? 1u : 0u);
-                                if (idx == 0) offset = rep0;
-                                else {
-                                    offset = idx == 3 ? rep0 - 1 : (idx == 1 ? rep1 : rep2);
-                                    if (offset == 0) { okb = false; break; }
-                                    if (idx > 1) rep2 = rep1;
-                                    rep1 = rep0;
-                                    rep0 = offset;
-                                }
-                            }
-                            L.seq[i * 3 + 2] = offset;
-                        }
-                    }
+                    if (zd::ballot(pbad) != 0) okb = false;
                 } else if (lane == 0) {
                     for (uint32_t i = 0; i < cnt; i++) {
                         const uint32_t cl = L.ll[sl], co = L.of[so], cm = L.ml[sm];
@@ -777,8 +767,8 @@ __device__ __forceinline__ void decode_frame(Lds &L, const int lane, const uint3
                 // are independent unless a match source reaches into this batch's own output ("near" matches) ----
                 {
                     const bool have = (uint32_t)lane < cnt;
-                    const uint32_t ll = have ? L.seq[lane * 3] : 0u, ml = have ? L.seq[lane * 3 + 1] : 0u;
-                    const uint32_t offset = have ? L.seq[lane * 3 + 2] : 1u;
+                    const uint32_t ll = !have ? 0u : (pre ? p_ll : L.seq[lane * 3]), ml = !have ? 0u : (pre ? p_ml : L.seq[lane * 3 + 1]);
+                    const uint32_t offset = !have ? 1u : (pre ? p_off : L.seq[lane * 3 + 2]);
                     const uint32_t incl_ll = zd::wave_scan_incl(ll), incl_all = zd::wave_scan_incl(ll + ml);
                     const uint32_t tot_ll = zd::uniform(zd::shfl(incl_ll, 63)), tot_all = zd::uniform(zd::shfl(incl_all, 63));
                     if (lp + tot_ll > lit_len) { err = ZARC_FRAME_CORRUPT; break; }
@@ -869,6 +859,17 @@ __device__ __forceinline__ void decode_frame(Lds &L, const int lane, const uint3
                 zd::wave_sync(); // L.seq is rewritten by lane 0 in the next batch
             }
             if (err) break;
+            if (pre) { // history after the block, from stage 2's symbolic summary
+                const ZdecBlock zb = fblocks[my_b];
+                uint32_t nr[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const uint32_t e = zb.rep[k];
+                    if (e & ZDEC_REP_REF) { const uint32_t slot = e & 3, delta = (e & ~ZDEC_REP_REF) >> 2; nr[k] = (slot == 0 ? rep0 : (slot == 1 ? rep1 : rep2)) - delta; }
+                    else nr[k] = e;
+                }
+                rep0 = nr[0]; rep1 = nr[1]; rep2 = nr[2];
+            }
             bool endok = true;
             if (lane == 0 && !pre) endok = b.bitpos == 0;
             if (zd::ballot(!endok) != 0) { err = ZARC_FRAME_CORRUPT; break; }
@@ -959,7 +960,8 @@ __global__ void __launch_bounds__(64) zarc_zdec_scan(const uint8_t *__restrict__
         const uint32_t btype = (bh >> 1) & 3, bsize = bh >> 3;
         if (btype == 3 || bsize > BLOCK_MAX) return;
         ZdecBlock zb;
-        zb.frame = f; zb.type = btype; zb.payload = pos; zb.size = bsize; zb.nseq = 0; zb.seq_hdr = 0; zb.state = 0; zb.pad = 0;
+        zb.frame = f; zb.type = btype; zb.payload = pos; zb.size = bsize; zb.nseq = 0; zb.seq_hdr = 0; zb.state = 0;
+        for (int k = 0; k < 3; k++) { zb.rep[k] = ZDEC_REP_REF | (uint32_t)k; zb.pad[k] = 0; }
         if (btype == 0) { if (pos + bsize > slen) return; pos += bsize; }
         else if (btype == 1) { if (pos + 1 > slen) return; pos += 1; }
         else {
@@ -1006,6 +1008,8 @@ __global__ void __launch_bounds__(64) zarc_zdec_seqs(const uint8_t *__restrict__
     SeqHeader own;
     bool ok = scan_seq_header(src, zb.seq_hdr, end, &own);
     int al[3] = {0, 0, 0};
+    // repeat-offset history, symbolic: hv = offset (hr = 0) or hv = slot | delta << 2 of the history at block start (hr = 1)
+    uint32_t hv0 = 0, hv1 = 1, hv2 = 2, hr0 = 1, hr1 = 1, hr2 = 1;
     for (int t = 0; t < 3 && ok; t++) {
         uint32_t mode = own.mode[t], off = own.off[t], len = own.len[t];
         if (mode == 3) { // Repeat: the description lives in the nearest earlier block with sequences that set this table
@@ -1043,7 +1047,25 @@ __global__ void __launch_bounds__(64) zarc_zdec_seqs(const uint8_t *__restrict__
             ll_code_info(llc, lbase, lbits);
             const uint32_t ml = mbase + b.read((int)mbits);
             const uint32_t ll = lbase + b.read((int)lbits);
-            outp[i] = zge_pack_seq(ll, ml, ofv);
+            uint32_t ov, orf; // this sequence's offset, same symbolic form
+            if (ofv > 3) { ov = ofv - 3; orf = 0; hv2 = hv1; hr2 = hr1; hv1 = hv0; hr1 = hr0; hv0 = ov; hr0 = orf; }
+            else {
+                const uint32_t idx = ofv - 1 + (ll == 0 ? 1u : 0u);
+                if (idx == 0) { ov = hv0; orf = hr0; }
+                else {
+                    if (idx == 1) { ov = hv1; orf = hr1; }
+                    else if (idx == 2) { ov = hv2; orf = hr2; }
+                    else { // first history entry minus one
+                        ov = hv0; orf = hr0;
+                        if (orf) { if ((ov >> 2) >= 3) { ok = false; break; } ov += 4; } // delta + 1 (deeper chains: left to the frame pass)
+                        else { if (ov <= 1) { ok = false; break; } ov -= 1; }
+                    }
+                    if (idx > 1) { hv2 = hv1; hr2 = hr1; }
+                    hv1 = hv0; hr1 = hr0;
+                    hv0 = ov; hr0 = orf;
+                }
+            }
+            outp[i] = zge_pack_seq(ll | (orf ? ZDEC_LL_REF : 0u), ml, ov);
             if (i + 1 < zb.nseq) {
                 sl = cell_base(cl, al[0]) + b.read((int)cell_nbits(cl, al[0]));
                 sm = cell_base(cm, al[2]) + b.read((int)cell_nbits(cm, al[2]));
@@ -1053,6 +1075,11 @@ __global__ void __launch_bounds__(64) zarc_zdec_seqs(const uint8_t *__restrict__
         }
         if (ok && b.bitpos != 0) ok = false;
     }
-    if (ok) zblocks[s].state = 1;
+    if (ok) {
+        zblocks[s].rep[0] = hr0 ? (ZDEC_REP_REF | hv0) : hv0;
+        zblocks[s].rep[1] = hr1 ? (ZDEC_REP_REF | hv1) : hv1;
+        zblocks[s].rep[2] = hr2 ? (ZDEC_REP_REF | hv2) : hv2;
+        zblocks[s].state = 1;
+    }
     else fast[f] = 0; // the frame pass decodes this frame inline and reports whatever is wrong with it
 }
