@@ -373,12 +373,12 @@ __device__ bool huf_build_table(Lds &L, int n, int lane)
 }
 
 // One Huffman stream on the calling lane.  Returns false on corruption.
-__device__ bool huf_decode_stream(const Lds &L, int max_bits, const uint8_t *src, uint32_t len, uint8_t *out, uint32_t nout)
+__device__ bool huf_decode_stream(const uint16_t *tab, int max_bits, const uint8_t *src, uint32_t len, uint8_t *out, uint32_t nout)
 {
     BackBits b;
     if (!b.init(src, len)) return false;
     for (uint32_t i = 0; i < nout; i++) {
-        const uint32_t e = L.huf[b.peek(max_bits)];
+        const uint32_t e = tab[b.peek(max_bits)];
         b.skip((int)(e >> 8));
         out[i] = (uint8_t)e;
     }
@@ -420,35 +420,36 @@ __device__ int seq_table(Lds &L, uint16_t *tab, int ctrl_al, int ctrl_ok, int mo
 // invalid descriptions, offsets beyond the format's window) clears fast[frame]: the frame pass then decodes that
 // frame inline exactly as before, so error statuses are decided in one place.
 
-// literals section of a compressed block: bytes it occupies (same checks as the frame pass)
-__device__ bool lit_section_used(const uint8_t *bp, uint32_t blen, uint32_t *lused)
+// literals section header of a compressed block (same checks as the frame pass)
+struct LitInfo { uint32_t ltype, lit_len, hdr, comp, streams, lused; };
+__device__ bool parse_lit_section(const uint8_t *bp, uint32_t blen, LitInfo *o)
 {
     if (blen < 2) return false;
     const uint32_t b0 = bp[0], ltype = b0 & 3, sf = (b0 >> 2) & 3;
-    uint32_t lit_len, hdr;
+    uint32_t lit_len, hdr, comp = 0, streams = 0, lused;
     if (ltype < 2) {
         if (sf == 0 || sf == 2) { lit_len = b0 >> 3; hdr = 1; }
         else if (sf == 1) { lit_len = (b0 >> 4) | ((uint32_t)bp[1] << 4); hdr = 2; }
         else { if (blen < 3) return false; lit_len = (b0 >> 4) | ((uint32_t)bp[1] << 4) | ((uint32_t)bp[2] << 12); hdr = 3; }
         if (lit_len > BLOCK_MAX) return false;
-        if (ltype == 0) { if (hdr + lit_len > blen) return false; *lused = hdr + lit_len; }
-        else { if (hdr + 1 > blen) return false; *lused = hdr + 1; }
+        if (ltype == 0) { if (hdr + lit_len > blen) return false; lused = hdr + lit_len; }
+        else { if (hdr + 1 > blen) return false; lused = hdr + 1; }
     } else {
-        uint32_t comp;
         if (blen < 5 && !(sf <= 1 && blen >= 3)) return false;
         if (sf <= 1) {
             const uint32_t v = b0 | ((uint32_t)bp[1] << 8) | ((uint32_t)bp[2] << 16);
-            lit_len = (v >> 4) & 0x3FF; comp = (v >> 14) & 0x3FF; hdr = 3;
+            lit_len = (v >> 4) & 0x3FF; comp = (v >> 14) & 0x3FF; hdr = 3; streams = sf == 0 ? 1 : 4;
         } else if (sf == 2) {
             const uint32_t v = b0 | ((uint32_t)bp[1] << 8) | ((uint32_t)bp[2] << 16) | ((uint32_t)bp[3] << 24);
-            lit_len = (v >> 4) & 0x3FFF; comp = (v >> 18) & 0x3FFF; hdr = 4;
+            lit_len = (v >> 4) & 0x3FFF; comp = (v >> 18) & 0x3FFF; hdr = 4; streams = 4;
         } else {
             const uint64_t v = (uint64_t)b0 | ((uint64_t)bp[1] << 8) | ((uint64_t)bp[2] << 16) | ((uint64_t)bp[3] << 24) | ((uint64_t)bp[4] << 32);
-            lit_len = (uint32_t)(v >> 4) & 0x3FFFF; comp = (uint32_t)(v >> 22) & 0x3FFFF; hdr = 5;
+            lit_len = (uint32_t)(v >> 4) & 0x3FFFF; comp = (uint32_t)(v >> 22) & 0x3FFFF; hdr = 5; streams = 4;
         }
         if (lit_len > BLOCK_MAX || hdr + comp > blen) return false;
-        *lused = hdr + comp;
+        lused = hdr + comp;
     }
+    o->ltype = ltype; o->lit_len = lit_len; o->hdr = hdr; o->comp = comp; o->streams = streams; o->lused = lused;
     return true;
 }
 
@@ -513,7 +514,7 @@ __device__ __forceinline__ void decode_frame(Lds &L, const int lane, const uint3
                                              int32_t *__restrict__ status, uint32_t *__restrict__ stored_checksum, const int dbg,
                                              const bool use_pre /* sequences of every block are in seqs[] (fast path) */,
                                              const ZdecBlock *__restrict__ fblocks, const uint64_t *__restrict__ fseq_index,
-                                             const uint64_t *__restrict__ seqs)
+                                             const uint64_t *__restrict__ seqs, const uint64_t *__restrict__ flit_index, const uint8_t *__restrict__ lits)
 {
     const uint8_t *src = frames_base + frame_off[f];
     const uint32_t slen = (uint32_t)frame_len[f];
@@ -636,6 +637,11 @@ __device__ __forceinline__ void decode_frame(Lds &L, const int lane, const uint3
                 lit_len = (uint32_t)(v >> 4) & 0x3FFFF; comp = (uint32_t)(v >> 22) & 0x3FFFF; hdr = 5; streams = 4;
             }
             if (lit_len > BLOCK_MAX || hdr + comp > blen) { err = ZARC_FRAME_CORRUPT; break; }
+            if (use_pre) { // fast path: stage 2 has regenerated these literals
+                if (fblocks[my_b].lit_len != lit_len) { err = ZARC_FRAME_CORRUPT; break; } // not reachable
+                lit = lits + flit_index[my_b];
+                lused = hdr + comp;
+            } else {
             const uint8_t *hp = bp + hdr;
             uint32_t rem = comp;
             if (ltype == 2) {
@@ -648,7 +654,7 @@ __device__ __forceinline__ void decode_frame(Lds &L, const int lane, const uint3
             const int max_bits = L.ctrl[C_HUF_BITS];
             bool ok = true;
             if (streams == 1) {
-                if (lane == 0 && !(dbg & 4)) ok = huf_decode_stream(L, max_bits, hp, rem, lit_buf, lit_len);
+                if (lane == 0 && !(dbg & 4)) ok = huf_decode_stream(L.huf, max_bits, hp, rem, lit_buf, lit_len);
             } else {
                 if (rem < 6) { err = ZARC_FRAME_CORRUPT; break; }
                 const uint32_t s1 = hp[0] | ((uint32_t)hp[1] << 8), s2 = hp[2] | ((uint32_t)hp[3] << 8), s3 = hp[4] | ((uint32_t)hp[5] << 8);
@@ -659,12 +665,13 @@ __device__ __forceinline__ void decode_frame(Lds &L, const int lane, const uint3
                     const uint32_t so = lane == 0 ? 0 : (lane == 1 ? s1 : (lane == 2 ? s1 + s2 : s1 + s2 + s3));
                     const uint32_t sl = lane == 0 ? s1 : (lane == 1 ? s2 : (lane == 2 ? s3 : s4));
                     const uint32_t cntl = lane < 3 ? per : lit_len - 3 * per;
-                    ok = huf_decode_stream(L, max_bits, hp + 6 + so, sl, lit_buf + (uint32_t)lane * per, cntl);
+                    ok = huf_decode_stream(L.huf, max_bits, hp + 6 + so, sl, lit_buf + (uint32_t)lane * per, cntl);
                 }
             }
             if (zd::ballot(!ok) != 0) { err = ZARC_FRAME_CORRUPT; break; }
             zd::wave_sync_global(); // literal bytes written by lanes 0..3 are read by every lane below
             lused = hdr + comp;
+            }
         }
         // sequences section
         const uint8_t *sp = bp + lused;
@@ -911,7 +918,8 @@ __global__ void __launch_bounds__(64, 5) zarc_zstd_decode(const uint8_t *__restr
                                                        int dbg /* timing-only ablations: 1 no copies, 2 no sequence decode, 4 no Huffman decode */,
                                                        uint32_t *__restrict__ queue, const uint32_t *__restrict__ fast,
                                                        const uint64_t *__restrict__ slot_prefix, const ZdecBlock *__restrict__ zblocks,
-                                                       const uint64_t *__restrict__ seq_index, const uint64_t *__restrict__ seqs)
+                                                       const uint64_t *__restrict__ seq_index, const uint64_t *__restrict__ seqs,
+                                                       const uint64_t *__restrict__ lit_index, const uint8_t *__restrict__ lits)
 {
     __shared__ Lds L;
     const int lane = zd::lane_id();
@@ -925,7 +933,7 @@ __global__ void __launch_bounds__(64, 5) zarc_zstd_decode(const uint8_t *__restr
         const bool use_pre = fast != nullptr && zd::uniform(fast[f]) != 0;
         const uint64_t first = use_pre ? slot_prefix[f] : 0;
         decode_frame(L, lane, f, lit_buf, frames_base, frame_off, frame_len, dst_base, dst_off, raw_len, status, stored_checksum, dbg, use_pre,
-                     zblocks + first, seq_index + first, seqs);
+                     zblocks + first, seq_index + first, seqs, lit_index + first, lits);
         zd::wave_sync_global(); // LDS tables and the literal buffer are reused by the next frame
     }
 }
@@ -934,7 +942,7 @@ __global__ void __launch_bounds__(64, 5) zarc_zstd_decode(const uint8_t *__restr
 __global__ void __launch_bounds__(64) zarc_zdec_scan(const uint8_t *__restrict__ frames_base, const uint64_t *__restrict__ frame_off,
                                                      const uint64_t *__restrict__ frame_len, const uint64_t *__restrict__ raw_len, uint32_t n_frames,
                                                      const uint64_t *__restrict__ slot_prefix, ZdecBlock *__restrict__ zblocks,
-                                                     uint32_t *__restrict__ nseq_out, uint32_t *__restrict__ fast)
+                                                     uint32_t *__restrict__ counts, uint32_t *__restrict__ fast)
 {
     const uint32_t f = blockIdx.x * 64u + threadIdx.x;
     if (f >= n_frames) return;
@@ -961,14 +969,17 @@ __global__ void __launch_bounds__(64) zarc_zdec_scan(const uint8_t *__restrict__
         if (btype == 3 || bsize > BLOCK_MAX) return;
         ZdecBlock zb;
         zb.frame = f; zb.type = btype; zb.payload = pos; zb.size = bsize; zb.nseq = 0; zb.seq_hdr = 0; zb.state = 0;
-        for (int k = 0; k < 3; k++) { zb.rep[k] = ZDEC_REP_REF | (uint32_t)k; zb.pad[k] = 0; }
+        for (int k = 0; k < 3; k++) zb.rep[k] = ZDEC_REP_REF | (uint32_t)k;
+        zb.lit_type = 0; zb.lit_len = 0; zb.lit_off = 0; zb.lit_comp = 0; zb.lit_streams = 0; zb.huf_used = 0; zb.huf_bits = 0; zb.pad = 0;
         if (btype == 0) { if (pos + bsize > slen) return; pos += bsize; }
         else if (btype == 1) { if (pos + 1 > slen) return; pos += 1; }
         else {
             if (pos + bsize > slen) return;
             const uint8_t *bp = src + pos;
-            uint32_t lused = 0;
-            if (!lit_section_used(bp, bsize, &lused)) return;
+            LitInfo li;
+            if (!parse_lit_section(bp, bsize, &li)) return;
+            const uint32_t lused = li.lused;
+            zb.lit_type = li.ltype; zb.lit_len = li.lit_len; zb.lit_off = pos + li.hdr; zb.lit_comp = li.comp; zb.lit_streams = li.streams;
             const uint8_t *sp = bp + lused;
             const uint32_t srem = bsize - lused;
             if (srem < 1) return;
@@ -983,7 +994,8 @@ __global__ void __launch_bounds__(64) zarc_zdec_scan(const uint8_t *__restrict__
             pos += bsize;
         }
         zblocks[first + bi] = zb;
-        nseq_out[first + bi] = zb.nseq;
+        counts[2 * (first + bi)] = zb.nseq;
+        counts[2 * (first + bi) + 1] = (btype == 2 && zb.lit_type >= 2) ? zb.lit_len : 0u;
         bi++;
     }
     fast[f] = 1;
@@ -993,9 +1005,44 @@ __global__ void __launch_bounds__(64) zarc_zdec_scan(const uint8_t *__restrict__
 __global__ void __launch_bounds__(64) zarc_zdec_seqs(const uint8_t *__restrict__ frames_base, const uint64_t *__restrict__ frame_off, uint64_t n_slots,
                                                      const uint64_t *__restrict__ slot_prefix, ZdecBlock *__restrict__ zblocks,
                                                      const uint64_t *__restrict__ seq_index, uint64_t *__restrict__ seqs, uint16_t *__restrict__ tables,
-                                                     uint32_t *__restrict__ fast)
+                                                     uint32_t *__restrict__ fast, const uint64_t *__restrict__ lit_index, uint8_t *__restrict__ lits,
+                                                     const uint16_t *__restrict__ huf_tables)
 {
-    const uint64_t s = (uint64_t)blockIdx.x * 64u + threadIdx.x;
+    const uint64_t job = (uint64_t)blockIdx.x * 64u + threadIdx.x;
+    const uint64_t seq_jobs = (n_slots + 63) / 64 * 64;
+    if (job >= seq_jobs) {
+        // ---- literal jobs: one Huffman stream per lane, table from zarc_zdec_huf_tables (L2-resident) ----
+        const uint64_t j = job - seq_jobs, slot = j >> 2;
+        const uint32_t k = (uint32_t)(j & 3);
+        if (slot >= n_slots) return;
+        const ZdecBlock zb = zblocks[slot];
+        if (zb.type != 2 || zb.lit_type < 2 || (zb.lit_streams == 1 && k != 0)) return;
+        const uint32_t f = zb.frame;
+        if (!fast[f]) return;
+        bool ok = zb.huf_bits != 0 && zb.huf_used <= zb.lit_comp;
+        if (ok) {
+            const uint8_t *hp = frames_base + frame_off[f] + zb.lit_off + zb.huf_used;
+            const uint32_t rem = zb.lit_comp - zb.huf_used;
+            const uint16_t *ht = huf_tables + slot * (uint64_t)ZDEC_HUF_CELLS;
+            uint8_t *dst = lits + lit_index[slot];
+            if (zb.lit_streams == 1) ok = huf_decode_stream(ht, (int)zb.huf_bits, hp, rem, dst, zb.lit_len);
+            else if (rem < 6) ok = false;
+            else {
+                const uint32_t s1 = hp[0] | ((uint32_t)hp[1] << 8), s2 = hp[2] | ((uint32_t)hp[3] << 8), s3 = hp[4] | ((uint32_t)hp[5] << 8);
+                const uint32_t per = (zb.lit_len + 3) / 4;
+                if (6 + s1 + s2 + s3 > rem || per * 3 > zb.lit_len) ok = false;
+                else {
+                    const uint32_t s4 = rem - 6 - s1 - s2 - s3;
+                    const uint32_t so = k == 0 ? 0 : (k == 1 ? s1 : (k == 2 ? s1 + s2 : s1 + s2 + s3));
+                    const uint32_t sl = k == 0 ? s1 : (k == 1 ? s2 : (k == 2 ? s3 : s4));
+                    ok = huf_decode_stream(ht, (int)zb.huf_bits, hp + 6 + so, sl, dst + k * per, k < 3 ? per : zb.lit_len - 3 * per);
+                }
+            }
+        }
+        if (!ok) fast[f] = 0;
+        return;
+    }
+    const uint64_t s = job;
     if (s >= n_slots) return;
     const ZdecBlock zb = zblocks[s];
     if (zb.type != 2 || zb.nseq == 0) return;
@@ -1082,4 +1129,47 @@ __global__ void __launch_bounds__(64) zarc_zdec_seqs(const uint8_t *__restrict__
         zblocks[s].state = 1;
     }
     else fast[f] = 0; // the frame pass decodes this frame inline and reports whatever is wrong with it
+}
+
+
+// Huffman tables of the fast path: one wave per block slot (the construction is wave-cooperative, as in the frame pass).
+__global__ void __launch_bounds__(64) zarc_zdec_huf_tables(const uint8_t *__restrict__ frames_base, const uint64_t *__restrict__ frame_off, uint64_t n_slots,
+                                                           const uint64_t *__restrict__ slot_prefix, ZdecBlock *__restrict__ zblocks,
+                                                           uint16_t *__restrict__ huf_tables, uint32_t *__restrict__ fast)
+{
+    __shared__ Lds L;
+    const int lane = zd::lane_id();
+    const uint64_t s = blockIdx.x;
+    if (s >= n_slots) return;
+    const ZdecBlock zb = zblocks[s];
+    if (zb.type != 2 || zb.lit_type < 2) return;
+    const uint32_t f = zb.frame;
+    if (!fast[f]) return;
+    if (lane == 0) for (int i = 0; i < 16; i++) L.ctrl[i] = 0;
+    zd::wave_sync();
+    // Treeless literals use the tree of the nearest earlier block of the frame that carries one
+    uint64_t from = s;
+    bool ok = true;
+    if (zb.lit_type == 3) {
+        ok = false;
+        const uint64_t first = slot_prefix[f];
+        for (uint64_t j = s; j > first;) {
+            j--;
+            const ZdecBlock pb = zblocks[j];
+            if (pb.type == 2 && pb.lit_type == 2) { from = j; ok = true; break; }
+        }
+    }
+    int used = 0;
+    if (ok) {
+        const ZdecBlock sb = zblocks[from];
+        int nw = 0;
+        used = huf_read_weights(L, frames_base + frame_off[f] + sb.lit_off, sb.lit_comp, lane, &nw);
+        ok = used >= 0 && huf_build_table(L, nw, lane);
+    }
+    if (ok) {
+        uint16_t *ht = huf_tables + s * (uint64_t)ZDEC_HUF_CELLS;
+        const int cells = 1 << L.ctrl[C_HUF_BITS];
+        for (int i = lane; i < cells; i += 64) ht[i] = L.huf[i];
+        if (lane == 0) { zblocks[s].huf_used = zb.lit_type == 2 ? (uint32_t)used : 0u; zblocks[s].huf_bits = (uint32_t)L.ctrl[C_HUF_BITS]; }
+    } else if (lane == 0) fast[f] = 0;
 }
