@@ -47,7 +47,7 @@ struct zarc_gpu {
     DevBuf d_blocks, d_seq, d_lit, d_out;
     // decoder
     DevBuf d_declit, d_status, d_stored_ck;
-    DevBuf d_slot_prefix, d_zblocks, d_nseq, d_fast, d_seqidx, d_seqs, d_ztables, d_litidx, d_lits, d_huftabs; // decoder fast path (sequences decoded ahead)
+    DevBuf d_slot_prefix, d_zblocks, d_nseq, d_fast, d_seqidx, d_seqs, d_ztables, d_litidx, d_lits; // decoder fast path (sequences decoded ahead)
     DevBuf d_queue; // frame queues of the persistent kernels (one u32 each)
     int num_cus = 1;
     // staging arenas for the host-pointer entry points
@@ -200,7 +200,7 @@ void zarc_gpu_destroy(zarc_gpu_t *h)
     DevBuf *all[] = {&h->d_off, &h->d_len, &h->d_chunk_prefix, &h->d_block_prefix, &h->d_order, &h->d_dst_off, &h->d_dst_len, &h->d_raw_len,
                      &h->d_frame_off, &h->d_frame_len, &h->d_cvs, &h->d_cvs_tmp, &h->d_digests, &h->d_xxh, &h->d_expect, &h->d_blocks, &h->d_seq,
                      &h->d_lit, &h->d_out, &h->d_declit, &h->d_status, &h->d_stored_ck, &h->d_arena_in, &h->d_arena_out, &h->d_queue,
-                     &h->d_slot_prefix, &h->d_zblocks, &h->d_nseq, &h->d_fast, &h->d_seqidx, &h->d_seqs, &h->d_ztables, &h->d_litidx, &h->d_lits, &h->d_huftabs};
+                     &h->d_slot_prefix, &h->d_zblocks, &h->d_nseq, &h->d_fast, &h->d_seqidx, &h->d_seqs, &h->d_ztables, &h->d_litidx, &h->d_lits};
     for (DevBuf *b : all) b->release();
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -475,7 +475,7 @@ int zarc_gpu_unpack_batch_device(zarc_gpu_t *h, size_t n, const void *d_frames_b
     std::vector<uint64_t> slot_prefix(n + 1, 0);
     for (size_t i = 0; i < n; i++) slot_prefix[i + 1] = slot_prefix[i] + raw_len[i] / ZARC_BLOCK + 2; // blocks a well-formed frame needs, plus slack
     const size_t nslots = (size_t)slot_prefix[n];
-    if (nslots * (size_t)(ZDEC_TABLE_CELLS + ZDEC_HUF_CELLS) * 2 > ((size_t)16 << 30)) fastpath = false; // table scratch out of proportion (millions of tiny frames)
+    if (nslots * (size_t)ZDEC_TABLE_CELLS * 2 > ((size_t)8 << 30)) fastpath = false; // table scratch out of proportion (millions of tiny frames)
     if (fastpath) {
         if ((rc = upload_u64(h, h->d_slot_prefix, slot_prefix.data(), n + 1))) return rc;
         ZHIP(h->d_zblocks.reserve(nslots * sizeof(ZdecBlock)));
@@ -484,7 +484,6 @@ int zarc_gpu_unpack_batch_device(zarc_gpu_t *h, size_t n, const void *d_frames_b
         ZHIP(h->d_seqidx.reserve(nslots * 8));
         ZHIP(h->d_litidx.reserve(nslots * 8));
         ZHIP(h->d_ztables.reserve(nslots * (size_t)ZDEC_TABLE_CELLS * 2));
-        ZHIP(h->d_huftabs.reserve(nslots * (size_t)ZDEC_HUF_CELLS * 2));
         ZHIP(hipMemsetAsync(h->d_zblocks.p, 0xFF, nslots * sizeof(ZdecBlock), h->stream));
         ZHIP(hipMemsetAsync(h->d_nseq.p, 0, nslots * 8, h->stream));
         hipLaunchKernelGGL(zarc_zdec_scan, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, h->stream, (const uint8_t *)d_frames_base, h->d_frame_off.as<uint64_t>(),
@@ -493,10 +492,6 @@ int zarc_gpu_unpack_batch_device(zarc_gpu_t *h, size_t n, const void *d_frames_b
         ZHIP(hipGetLastError());
         std::vector<uint32_t> counts(nslots * 2);
         ZHIP(hipMemcpyAsync(counts.data(), h->d_nseq.p, nslots * 8, hipMemcpyDeviceToHost, h->stream));
-        // the Huffman tables need nothing from the host: they are built while the counts travel
-        hipLaunchKernelGGL(zarc_zdec_huf_tables, dim3((unsigned)nslots), dim3(64), 0, h->stream, (const uint8_t *)d_frames_base, h->d_frame_off.as<uint64_t>(),
-                           (uint64_t)nslots, h->d_slot_prefix.as<uint64_t>(), h->d_zblocks.as<ZdecBlock>(), h->d_huftabs.as<uint16_t>(), h->d_fast.as<uint32_t>());
-        ZHIP(hipGetLastError());
         ZHIP(hipStreamSynchronize(h->stream)); // the sequence / literal scratch is sized exactly: sums of the blocks' counts
         std::vector<uint64_t> seqidx(nslots), litidx(nslots);
         uint64_t total = 0, lit_total = 0;
@@ -505,12 +500,16 @@ int zarc_gpu_unpack_batch_device(zarc_gpu_t *h, size_t n, const void *d_frames_b
         if ((rc = upload_u64(h, h->d_litidx, litidx.data(), nslots))) return rc;
         ZHIP(h->d_seqs.reserve(std::max<uint64_t>(total, 1) * 8));
         ZHIP(h->d_lits.reserve(std::max<uint64_t>(lit_total, 1) + 64));
-        if (total || lit_total) {
-            const size_t jobs = (nslots + 63) / 64 * 64 + nslots * 4;
-            hipLaunchKernelGGL(zarc_zdec_seqs, dim3((unsigned)((jobs + 63) / 64)), dim3(64), 0, h->stream, (const uint8_t *)d_frames_base, h->d_frame_off.as<uint64_t>(),
+        if (lit_total) {
+            hipLaunchKernelGGL(zarc_zdec_literals, dim3((unsigned)((nslots + ZDEC_LIT_GROUP - 1) / ZDEC_LIT_GROUP)), dim3(64), 0, h->stream, (const uint8_t *)d_frames_base,
+                               h->d_frame_off.as<uint64_t>(), (uint64_t)nslots, h->d_slot_prefix.as<uint64_t>(), h->d_zblocks.as<ZdecBlock>(), h->d_litidx.as<uint64_t>(),
+                               h->d_lits.as<uint8_t>(), h->d_fast.as<uint32_t>());
+            ZHIP(hipGetLastError());
+        }
+        if (total) {
+            hipLaunchKernelGGL(zarc_zdec_seqs, dim3((unsigned)((nslots + 63) / 64)), dim3(64), 0, h->stream, (const uint8_t *)d_frames_base, h->d_frame_off.as<uint64_t>(),
                                (uint64_t)nslots, h->d_slot_prefix.as<uint64_t>(), h->d_zblocks.as<ZdecBlock>(), h->d_seqidx.as<uint64_t>(), h->d_seqs.as<uint64_t>(),
-                               h->d_ztables.as<uint16_t>(), h->d_fast.as<uint32_t>(), h->d_litidx.as<uint64_t>(), h->d_lits.as<uint8_t>(),
-                               h->d_huftabs.as<uint16_t>());
+                               h->d_ztables.as<uint16_t>(), h->d_fast.as<uint32_t>());
             ZHIP(hipGetLastError());
         }
     }

@@ -49,12 +49,10 @@ struct ZdecBlock {
     uint32_t lit_off;  // Huffman literals: frame offset of the section body (tree description, then the streams)
     uint32_t lit_comp; // Huffman literals: bytes of that body
     uint32_t lit_streams; // 1 or 4
-    uint32_t huf_used; // set by zarc_zdec_huf_tables: bytes of the tree description (0 for treeless)
-    uint32_t huf_bits; // set by zarc_zdec_huf_tables: table log of the Huffman table in the table scratch (0 = none)
-    uint32_t pad;
+    uint32_t pad[3];
 };
 static_assert(sizeof(ZdecBlock) == 72, "block slot layout");
-constexpr int ZDEC_HUF_CELLS = 2048; // per block slot: Huffman decode cells (u16), table log <= 11
+constexpr int ZDEC_LIT_GROUP = 16;  // block slots per wave of zarc_zdec_literals (4 Huffman streams each)
 // Fast-path sequences are stored with zge_pack_seq(); the offset field is already resolved against the repeat-offset history
 // as far as the block alone allows: bit 17 of the literal-length field set = the offset is (history slot at block start) - delta,
 // the offset field then holds slot | delta << 2; otherwise the offset field is the absolute offset.
@@ -77,14 +75,12 @@ __global__ void zarc_zstd_decode(const uint8_t *frames_base, const uint64_t *fra
 __global__ void zarc_zdec_scan(const uint8_t *frames_base, const uint64_t *frame_off, const uint64_t *frame_len, const uint64_t *raw_len,
                                uint32_t n_frames, const uint64_t *slot_prefix, ZdecBlock *zblocks, uint32_t *counts /* per slot: nseq, Huffman literal bytes */,
                                uint32_t *fast);
-// Huffman tables of the fast path: one wave per block slot builds the block's literal decoding table into the table scratch
-__global__ void zarc_zdec_huf_tables(const uint8_t *frames_base, const uint64_t *frame_off, uint64_t n_slots, const uint64_t *slot_prefix,
-                                     ZdecBlock *zblocks, uint16_t *huf_tables, uint32_t *fast);
-// stage 2: one LANE per job.  Jobs [0, n_slots): entropy-decode a block's sequences (FSE tables in HBM scratch) into seqs[];
-// jobs [seq_jobs, seq_jobs + 4 n_slots) with seq_jobs = n_slots rounded up to 64: decode one Huffman literal stream into lits[]
+// Huffman literals of the fast path: one wave per ZDEC_LIT_GROUP block slots (tables in LDS, one stream per lane) -> lits[]
+__global__ void zarc_zdec_literals(const uint8_t *frames_base, const uint64_t *frame_off, uint64_t n_slots, const uint64_t *slot_prefix,
+                                   const ZdecBlock *zblocks, const uint64_t *lit_index, uint8_t *lits, uint32_t *fast);
+// stage 2: one LANE per block slot entropy-decodes the block's sequences (FSE tables in HBM scratch) into seqs[]
 __global__ void zarc_zdec_seqs(const uint8_t *frames_base, const uint64_t *frame_off, uint64_t n_slots, const uint64_t *slot_prefix,
-                               ZdecBlock *zblocks, const uint64_t *seq_index, uint64_t *seqs, uint16_t *tables, uint32_t *fast,
-                               const uint64_t *lit_index, uint8_t *lits, const uint16_t *huf_tables);
+                               ZdecBlock *zblocks, const uint64_t *seq_index, uint64_t *seqs, uint16_t *tables, uint32_t *fast);
 // status[i]: keeps decode errors; else CHECKSUM if the stored XXH64 differs; else DIGEST if expect differs
 __global__ void zarc_unpack_verdict(uint32_t n, const uint64_t *xxh, const uint32_t *stored_checksum, const uint32_t *digests,
                                     const uint32_t *expect /* may be null */, int32_t *status);

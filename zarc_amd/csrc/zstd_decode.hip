@@ -385,6 +385,31 @@ __device__ bool huf_decode_stream(const uint16_t *tab, int max_bits, const uint8
     return b.bitpos == 0;
 }
 
+// Same, for a lane of the fast path: symbols leave in 8-byte stores (64 lanes storing single bytes to 64 different places is
+// what bounds a lane-per-stream decoder otherwise).
+__device__ bool huf_decode_stream8(const uint16_t *tab, int max_bits, const uint8_t *src, uint32_t len, uint8_t *out, uint32_t nout)
+{
+    BackBits b;
+    if (!b.init(src, len)) return false;
+    uint32_t i = 0;
+    for (; i + 8 <= nout; i += 8) {
+        uint64_t w = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint32_t e = tab[b.peek(max_bits)];
+            b.skip((int)(e >> 8));
+            w |= (uint64_t)(e & 0xFF) << (8 * j);
+        }
+        __builtin_memcpy(out + i, &w, 8);
+    }
+    for (; i < nout; i++) {
+        const uint32_t e = tab[b.peek(max_bits)];
+        b.skip((int)(e >> 8));
+        out[i] = (uint8_t)e;
+    }
+    return b.bitpos == 0;
+}
+
 // (Re)build one sequence table according to its mode.  Uniform entry; the work runs on lane 0.
 // Returns bytes consumed from src, or -1.
 __device__ int seq_table(Lds &L, uint16_t *tab, int ctrl_al, int ctrl_ok, int mode, const uint8_t *src, uint32_t len,
@@ -970,7 +995,7 @@ __global__ void __launch_bounds__(64) zarc_zdec_scan(const uint8_t *__restrict__
         ZdecBlock zb;
         zb.frame = f; zb.type = btype; zb.payload = pos; zb.size = bsize; zb.nseq = 0; zb.seq_hdr = 0; zb.state = 0;
         for (int k = 0; k < 3; k++) zb.rep[k] = ZDEC_REP_REF | (uint32_t)k;
-        zb.lit_type = 0; zb.lit_len = 0; zb.lit_off = 0; zb.lit_comp = 0; zb.lit_streams = 0; zb.huf_used = 0; zb.huf_bits = 0; zb.pad = 0;
+        zb.lit_type = 0; zb.lit_len = 0; zb.lit_off = 0; zb.lit_comp = 0; zb.lit_streams = 0; zb.pad[0] = zb.pad[1] = zb.pad[2] = 0;
         if (btype == 0) { if (pos + bsize > slen) return; pos += bsize; }
         else if (btype == 1) { if (pos + 1 > slen) return; pos += 1; }
         else {
@@ -1005,44 +1030,9 @@ __global__ void __launch_bounds__(64) zarc_zdec_scan(const uint8_t *__restrict__
 __global__ void __launch_bounds__(64) zarc_zdec_seqs(const uint8_t *__restrict__ frames_base, const uint64_t *__restrict__ frame_off, uint64_t n_slots,
                                                      const uint64_t *__restrict__ slot_prefix, ZdecBlock *__restrict__ zblocks,
                                                      const uint64_t *__restrict__ seq_index, uint64_t *__restrict__ seqs, uint16_t *__restrict__ tables,
-                                                     uint32_t *__restrict__ fast, const uint64_t *__restrict__ lit_index, uint8_t *__restrict__ lits,
-                                                     const uint16_t *__restrict__ huf_tables)
+                                                     uint32_t *__restrict__ fast)
 {
-    const uint64_t job = (uint64_t)blockIdx.x * 64u + threadIdx.x;
-    const uint64_t seq_jobs = (n_slots + 63) / 64 * 64;
-    if (job >= seq_jobs) {
-        // ---- literal jobs: one Huffman stream per lane, table from zarc_zdec_huf_tables (L2-resident) ----
-        const uint64_t j = job - seq_jobs, slot = j >> 2;
-        const uint32_t k = (uint32_t)(j & 3);
-        if (slot >= n_slots) return;
-        const ZdecBlock zb = zblocks[slot];
-        if (zb.type != 2 || zb.lit_type < 2 || (zb.lit_streams == 1 && k != 0)) return;
-        const uint32_t f = zb.frame;
-        if (!fast[f]) return;
-        bool ok = zb.huf_bits != 0 && zb.huf_used <= zb.lit_comp;
-        if (ok) {
-            const uint8_t *hp = frames_base + frame_off[f] + zb.lit_off + zb.huf_used;
-            const uint32_t rem = zb.lit_comp - zb.huf_used;
-            const uint16_t *ht = huf_tables + slot * (uint64_t)ZDEC_HUF_CELLS;
-            uint8_t *dst = lits + lit_index[slot];
-            if (zb.lit_streams == 1) ok = huf_decode_stream(ht, (int)zb.huf_bits, hp, rem, dst, zb.lit_len);
-            else if (rem < 6) ok = false;
-            else {
-                const uint32_t s1 = hp[0] | ((uint32_t)hp[1] << 8), s2 = hp[2] | ((uint32_t)hp[3] << 8), s3 = hp[4] | ((uint32_t)hp[5] << 8);
-                const uint32_t per = (zb.lit_len + 3) / 4;
-                if (6 + s1 + s2 + s3 > rem || per * 3 > zb.lit_len) ok = false;
-                else {
-                    const uint32_t s4 = rem - 6 - s1 - s2 - s3;
-                    const uint32_t so = k == 0 ? 0 : (k == 1 ? s1 : (k == 2 ? s1 + s2 : s1 + s2 + s3));
-                    const uint32_t sl = k == 0 ? s1 : (k == 1 ? s2 : (k == 2 ? s3 : s4));
-                    ok = huf_decode_stream(ht, (int)zb.huf_bits, hp + 6 + so, sl, dst + k * per, k < 3 ? per : zb.lit_len - 3 * per);
-                }
-            }
-        }
-        if (!ok) fast[f] = 0;
-        return;
-    }
-    const uint64_t s = job;
+    const uint64_t s = (uint64_t)blockIdx.x * 64u + threadIdx.x;
     if (s >= n_slots) return;
     const ZdecBlock zb = zblocks[s];
     if (zb.type != 2 || zb.nseq == 0) return;
@@ -1132,44 +1122,89 @@ __global__ void __launch_bounds__(64) zarc_zdec_seqs(const uint8_t *__restrict__
 }
 
 
-// Huffman tables of the fast path: one wave per block slot (the construction is wave-cooperative, as in the frame pass).
-__global__ void __launch_bounds__(64) zarc_zdec_huf_tables(const uint8_t *__restrict__ frames_base, const uint64_t *__restrict__ frame_off, uint64_t n_slots,
-                                                           const uint64_t *__restrict__ slot_prefix, ZdecBlock *__restrict__ zblocks,
-                                                           uint16_t *__restrict__ huf_tables, uint32_t *__restrict__ fast)
+// Huffman literals of the fast path.  One wave per ZDEC_LIT_GROUP consecutive block slots: the wave builds the blocks' decode
+// tables in LDS one after the other (the construction is wave-cooperative, as in the frame pass), then every lane decodes one
+// stream (4 streams x 16 blocks) out of LDS -- the only global traffic left is the bitstream and 8-byte stores of the output.
+struct LitLds {
+    Lds build;                                   // construction scratch (weights, FSE table of the weights) and one table
+    uint16_t huf[ZDEC_LIT_GROUP][2048];
+    int32_t bits[ZDEC_LIT_GROUP];                // table log per block, 0 = no table
+    uint32_t used[ZDEC_LIT_GROUP];               // bytes of the tree description in front of the streams
+};
+
+__global__ void __launch_bounds__(64) zarc_zdec_literals(const uint8_t *__restrict__ frames_base, const uint64_t *__restrict__ frame_off, uint64_t n_slots,
+                                                         const uint64_t *__restrict__ slot_prefix, const ZdecBlock *__restrict__ zblocks,
+                                                         const uint64_t *__restrict__ lit_index, uint8_t *__restrict__ lits, uint32_t *__restrict__ fast)
 {
-    __shared__ Lds L;
+    __shared__ LitLds S;
     const int lane = zd::lane_id();
-    const uint64_t s = blockIdx.x;
-    if (s >= n_slots) return;
-    const ZdecBlock zb = zblocks[s];
-    if (zb.type != 2 || zb.lit_type < 2) return;
-    const uint32_t f = zb.frame;
-    if (!fast[f]) return;
-    if (lane == 0) for (int i = 0; i < 16; i++) L.ctrl[i] = 0;
+    const uint64_t s0 = (uint64_t)blockIdx.x * ZDEC_LIT_GROUP;
+    // ---- phase 1: tables ----
+    for (int i = 0; i < ZDEC_LIT_GROUP; i++) {
+        const uint64_t s = s0 + (uint64_t)i;
+        if (lane == 0) { S.bits[i] = 0; S.used[i] = 0; }
+        if (s >= n_slots) continue; // uniform
+        const ZdecBlock zb = zblocks[s];
+        if (zb.type != 2 || zb.lit_type < 2) continue;
+        const uint32_t f = zb.frame;
+        if (!zd::uniform(fast[f])) continue; // one value for the whole wave even while other waves clear the flag
+        if (lane == 0) for (int c = 0; c < 16; c++) S.build.ctrl[c] = 0;
+        zd::wave_sync();
+        uint64_t from = s;
+        bool ok = true;
+        if (zb.lit_type == 3) { // Treeless: the tree of the nearest earlier block of the frame that carries one
+            ok = false;
+            const uint64_t first = slot_prefix[f];
+            for (uint64_t j = s; j > first;) {
+                j--;
+                const ZdecBlock pb = zblocks[j];
+                if (pb.type == 2 && pb.lit_type == 2) { from = j; ok = true; break; }
+            }
+        }
+        int used = 0;
+        if (ok) {
+            const ZdecBlock sb = zblocks[from];
+            int nw = 0;
+            used = huf_read_weights(S.build, frames_base + frame_off[f] + sb.lit_off, sb.lit_comp, lane, &nw);
+            ok = used >= 0 && huf_build_table(S.build, nw, lane);
+        }
+        if (ok) {
+            const int cells = 1 << S.build.ctrl[C_HUF_BITS];
+            for (int c = lane; c < cells; c += 64) S.huf[i][c] = S.build.huf[c];
+            if (lane == 0) { S.bits[i] = S.build.ctrl[C_HUF_BITS]; S.used[i] = zb.lit_type == 2 ? (uint32_t)used : 0u; }
+        } else if (lane == 0) fast[f] = 0;
+        zd::wave_sync();
+    }
     zd::wave_sync();
-    // Treeless literals use the tree of the nearest earlier block of the frame that carries one
-    uint64_t from = s;
-    bool ok = true;
-    if (zb.lit_type == 3) {
-        ok = false;
-        const uint64_t first = slot_prefix[f];
-        for (uint64_t j = s; j > first;) {
-            j--;
-            const ZdecBlock pb = zblocks[j];
-            if (pb.type == 2 && pb.lit_type == 2) { from = j; ok = true; break; }
+    // ---- phase 2: one stream per lane ----
+    static_assert(ZDEC_LIT_GROUP * 4 == 64, "four streams per block, one wave");
+    const int i = lane >> 2;
+    const uint32_t k = (uint32_t)lane & 3u;
+    const uint64_t s = s0 + (uint64_t)i;
+    if (s >= n_slots || S.bits[i] == 0) return;
+    const ZdecBlock zb = zblocks[s];
+    if (zb.lit_streams == 1 && k != 0) return;
+    const uint32_t f = zb.frame;
+    bool ok = S.used[i] <= zb.lit_comp;
+    if (ok) {
+        const uint8_t *hp = frames_base + frame_off[f] + zb.lit_off + S.used[i];
+        const uint32_t rem = zb.lit_comp - S.used[i];
+        uint8_t *dst = lits + lit_index[s];
+        const uint16_t *ht = S.huf[i];
+        const int tl = S.bits[i];
+        if (zb.lit_streams == 1) ok = huf_decode_stream8(ht, tl, hp, rem, dst, zb.lit_len);
+        else if (rem < 6) ok = false;
+        else {
+            const uint32_t s1 = hp[0] | ((uint32_t)hp[1] << 8), s2 = hp[2] | ((uint32_t)hp[3] << 8), s3 = hp[4] | ((uint32_t)hp[5] << 8);
+            const uint32_t per = (zb.lit_len + 3) / 4;
+            if (6 + s1 + s2 + s3 > rem || per * 3 > zb.lit_len) ok = false;
+            else {
+                const uint32_t s4 = rem - 6 - s1 - s2 - s3;
+                const uint32_t so = k == 0 ? 0 : (k == 1 ? s1 : (k == 2 ? s1 + s2 : s1 + s2 + s3));
+                const uint32_t sl = k == 0 ? s1 : (k == 1 ? s2 : (k == 2 ? s3 : s4));
+                ok = huf_decode_stream8(ht, tl, hp + 6 + so, sl, dst + k * per, k < 3 ? per : zb.lit_len - 3 * per);
+            }
         }
     }
-    int used = 0;
-    if (ok) {
-        const ZdecBlock sb = zblocks[from];
-        int nw = 0;
-        used = huf_read_weights(L, frames_base + frame_off[f] + sb.lit_off, sb.lit_comp, lane, &nw);
-        ok = used >= 0 && huf_build_table(L, nw, lane);
-    }
-    if (ok) {
-        uint16_t *ht = huf_tables + s * (uint64_t)ZDEC_HUF_CELLS;
-        const int cells = 1 << L.ctrl[C_HUF_BITS];
-        for (int i = lane; i < cells; i += 64) ht[i] = L.huf[i];
-        if (lane == 0) { zblocks[s].huf_used = zb.lit_type == 2 ? (uint32_t)used : 0u; zblocks[s].huf_bits = (uint32_t)L.ctrl[C_HUF_BITS]; }
-    } else if (lane == 0) fast[f] = 0;
+    if (!ok) fast[f] = 0;
 }
