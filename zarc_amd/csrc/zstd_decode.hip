@@ -254,6 +254,30 @@ __device__ __forceinline__ void wave_copy(uint8_t *dst, const uint8_t *src, uint
     for (uint32_t i = (uint32_t)lane; i < n; i += 64) dst[i] = src[i];
 }
 
+// One lane copies n <= 32 bytes (source and destination do not overlap): head and tail pieces of the largest power of two
+// that fits, both read before either is written -- at most two loads and two stores per lane instead of one per byte.
+__device__ __forceinline__ void lane_copy32(uint8_t *d, const uint8_t *s, uint32_t n)
+{
+    struct B16 { uint64_t a, b; };
+    if (n >= 16) {
+        B16 x, y;
+        __builtin_memcpy(&x, s, 16); __builtin_memcpy(&y, s + n - 16, 16);
+        __builtin_memcpy(d, &x, 16); __builtin_memcpy(d + n - 16, &y, 16);
+    } else if (n >= 8) {
+        uint64_t x, y;
+        __builtin_memcpy(&x, s, 8); __builtin_memcpy(&y, s + n - 8, 8);
+        __builtin_memcpy(d, &x, 8); __builtin_memcpy(d + n - 8, &y, 8);
+    } else if (n >= 4) {
+        uint32_t x, y;
+        __builtin_memcpy(&x, s, 4); __builtin_memcpy(&y, s + n - 4, 4);
+        __builtin_memcpy(d, &x, 4); __builtin_memcpy(d + n - 4, &y, 4);
+    } else if (n >= 2) {
+        uint16_t x, y;
+        __builtin_memcpy(&x, s, 2); __builtin_memcpy(&y, s + n - 2, 2);
+        __builtin_memcpy(d, &x, 2); __builtin_memcpy(d + n - 2, &y, 2);
+    } else if (n == 1) d[0] = s[0];
+}
+
 // Huffman tree description -> weights in LDS, returns bytes consumed (or -1); lane-serial part on lane 0.
 __device__ int huf_read_weights(Lds &L, const uint8_t *src, uint32_t len, int lane, int *nweights)
 {
@@ -813,24 +837,12 @@ __device__ __forceinline__ void decode_frame(Lds &L, const int lane, const uint3
                     const uint32_t msrc = dmat - offset;
                     const bool far = have && msrc + ml <= bpos;                // source entirely below this batch's output
                     if (!(dbg & 1)) {
-                    // (1) literal runs: short ones one lane per sequence (4 bytes in flight per lane), long ones wave-wide
+                    // (1) literal runs: short ones one lane per sequence, long ones wave-wide
                     {
-                        const uint32_t ns = ll <= 16 ? ll : 0u;
-                        for (uint32_t r = 0; r < 16; r += 4) {
-                            if (zd::ballot(ns > r) == 0) break;
-                            uint8_t v0 = lit_rle_byte, v1 = lit_rle_byte, v2 = lit_rle_byte, v3 = lit_rle_byte;
-                            if (!lit_rle) {
-                                if (r < ns) v0 = lit[slit + r];
-                                if (r + 1 < ns) v1 = lit[slit + r + 1];
-                                if (r + 2 < ns) v2 = lit[slit + r + 2];
-                                if (r + 3 < ns) v3 = lit[slit + r + 3];
-                            }
-                            if (r < ns) out[dlit + r] = v0;
-                            if (r + 1 < ns) out[dlit + r + 1] = v1;
-                            if (r + 2 < ns) out[dlit + r + 2] = v2;
-                            if (r + 3 < ns) out[dlit + r + 3] = v3;
-                        }
-                        uint64_t longs = zd::ballot(ll > 16);
+                        const uint32_t ns = ll <= 32 ? ll : 0u;
+                        if (lit_rle) { for (uint32_t r = 0; r < ns; r++) out[dlit + r] = lit_rle_byte; }
+                        else lane_copy32(out + dlit, lit + slit, ns);
+                        uint64_t longs = zd::ballot(ll > 32);
                         while (longs) {
                             const int i = zd::ctz64(longs);
                             longs &= longs - 1;
@@ -842,18 +854,7 @@ __device__ __forceinline__ void decode_frame(Lds &L, const int lane, const uint3
                     // (2) far matches: no dependence on this batch (and no self-overlap: offset >= length)
                     {
                         const uint32_t ns = (far && ml <= 32) ? ml : 0u;
-                        for (uint32_t r = 0; r < 32; r += 4) {
-                            if (zd::ballot(ns > r) == 0) break;
-                            uint8_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;
-                            if (r < ns) v0 = out[msrc + r];
-                            if (r + 1 < ns) v1 = out[msrc + r + 1];
-                            if (r + 2 < ns) v2 = out[msrc + r + 2];
-                            if (r + 3 < ns) v3 = out[msrc + r + 3];
-                            if (r < ns) out[dmat + r] = v0;
-                            if (r + 1 < ns) out[dmat + r + 1] = v1;
-                            if (r + 2 < ns) out[dmat + r + 2] = v2;
-                            if (r + 3 < ns) out[dmat + r + 3] = v3;
-                        }
+                        lane_copy32(out + dmat, out + msrc, ns);
                         uint64_t longs = zd::ballot(far && ml > 32);
                         while (longs) {
                             const int i = zd::ctz64(longs);
