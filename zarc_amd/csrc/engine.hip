@@ -37,6 +37,8 @@ struct DevBuf {
 struct zarc_gpu {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr; // side stream: independent stage-2 kernels of the decoder run next to each other
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     zarc_gpu_params params{};
     std::string last_error;
     // descriptors
@@ -178,7 +180,8 @@ int zarc_gpu_create(zarc_gpu_t **out, int device)
     zarc_gpu *h = new (std::nothrow) zarc_gpu();
     if (!h) return ZARC_GPU_E_NOMEM;
     h->device = device;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) { delete h; return ZARC_GPU_E_DEVICE; }
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess || hipStreamCreate(&h->stream2) != hipSuccess ||
+        hipEventCreate(&h->ev_fork) != hipSuccess || hipEventCreate(&h->ev_join) != hipSuccess) { delete h; return ZARC_GPU_E_DEVICE; }
     for (auto &e : h->ev)
         if (hipEventCreate(&e) != hipSuccess) { delete h; return ZARC_GPU_E_DEVICE; }
     hipDeviceProp_t prop;
@@ -204,6 +207,9 @@ void zarc_gpu_destroy(zarc_gpu_t *h)
     for (DevBuf *b : all) b->release();
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->stream2) (void)hipStreamDestroy(h->stream2);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     delete h;
 }
 
@@ -500,8 +506,11 @@ int zarc_gpu_unpack_batch_device(zarc_gpu_t *h, size_t n, const void *d_frames_b
         if ((rc = upload_u64(h, h->d_litidx, litidx.data(), nslots))) return rc;
         ZHIP(h->d_seqs.reserve(std::max<uint64_t>(total, 1) * 8));
         ZHIP(h->d_lits.reserve(std::max<uint64_t>(lit_total, 1) + 64));
+        // the literal and the sequence kernels are independent and neither fills the chip: they run side by side
+        const bool side = lit_total && total;
+        if (side) { ZHIP(hipEventRecord(h->ev_fork, h->stream)); ZHIP(hipStreamWaitEvent(h->stream2, h->ev_fork, 0)); }
         if (lit_total) {
-            hipLaunchKernelGGL(zarc_zdec_literals, dim3((unsigned)((nslots + ZDEC_LIT_GROUP - 1) / ZDEC_LIT_GROUP)), dim3(64), 0, h->stream, (const uint8_t *)d_frames_base,
+            hipLaunchKernelGGL(zarc_zdec_literals, dim3((unsigned)((nslots + ZDEC_LIT_GROUP - 1) / ZDEC_LIT_GROUP)), dim3(64), 0, side ? h->stream2 : h->stream, (const uint8_t *)d_frames_base,
                                h->d_frame_off.as<uint64_t>(), (uint64_t)nslots, h->d_slot_prefix.as<uint64_t>(), h->d_zblocks.as<ZdecBlock>(), h->d_litidx.as<uint64_t>(),
                                h->d_lits.as<uint8_t>(), h->d_fast.as<uint32_t>());
             ZHIP(hipGetLastError());
@@ -512,6 +521,7 @@ int zarc_gpu_unpack_batch_device(zarc_gpu_t *h, size_t n, const void *d_frames_b
                                h->d_ztables.as<uint16_t>(), h->d_fast.as<uint32_t>());
             ZHIP(hipGetLastError());
         }
+        if (side) { ZHIP(hipEventRecord(h->ev_join, h->stream2)); ZHIP(hipStreamWaitEvent(h->stream, h->ev_join, 0)); }
     }
     ZHIP(hipMemsetAsync(h->d_queue.p, 0, 4, h->stream));
     hipLaunchKernelGGL(zarc_zstd_decode, dim3((unsigned)dec_grid), dim3(64), getenv("ZARC_GPU_DEC_PADLDS") ? atoi(getenv("ZARC_GPU_DEC_PADLDS")) : 0, h->stream, (const uint8_t *)d_frames_base, h->d_frame_off.as<uint64_t>(),
