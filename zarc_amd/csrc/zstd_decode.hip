@@ -409,31 +409,6 @@ __device__ bool huf_decode_stream(const uint16_t *tab, int max_bits, const uint8
     return b.bitpos == 0;
 }
 
-// Same, for a lane of the fast path: symbols leave in 8-byte stores (64 lanes storing single bytes to 64 different places is
-// what bounds a lane-per-stream decoder otherwise).
-__device__ bool huf_decode_stream8(const uint16_t *tab, int max_bits, const uint8_t *src, uint32_t len, uint8_t *out, uint32_t nout)
-{
-    BackBits b;
-    if (!b.init(src, len)) return false;
-    uint32_t i = 0;
-    for (; i + 8 <= nout; i += 8) {
-        uint64_t w = 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const uint32_t e = tab[b.peek(max_bits)];
-            b.skip((int)(e >> 8));
-            w |= (uint64_t)(e & 0xFF) << (8 * j);
-        }
-        __builtin_memcpy(out + i, &w, 8);
-    }
-    for (; i < nout; i++) {
-        const uint32_t e = tab[b.peek(max_bits)];
-        b.skip((int)(e >> 8));
-        out[i] = (uint8_t)e;
-    }
-    return b.bitpos == 0;
-}
-
 // (Re)build one sequence table according to its mode.  Uniform entry; the work runs on lane 0.
 // Returns bytes consumed from src, or -1.
 __device__ int seq_table(Lds &L, uint16_t *tab, int ctrl_al, int ctrl_ok, int mode, const uint8_t *src, uint32_t len,
@@ -1123,15 +1098,144 @@ __global__ void __launch_bounds__(64) zarc_zdec_seqs(const uint8_t *__restrict__
 }
 
 
-// Huffman literals of the fast path.  One wave per ZDEC_LIT_GROUP consecutive block slots: the wave builds the blocks' decode
-// tables in LDS one after the other (the construction is wave-cooperative, as in the frame pass), then every lane decodes one
-// stream (4 streams x 16 blocks) out of LDS -- the only global traffic left is the bitstream and 8-byte stores of the output.
+// Huffman literals of the fast path.  One wave per ZDEC_LIT_GROUP consecutive block slots: the wave prepares the blocks'
+// decoders in LDS one after the other (wave-cooperative), then every lane decodes one stream (4 streams x 16 blocks).
+// A full 2^11-cell decode table per block would cap a CU at 160 decoding lanes (160 KiB / 4 KiB x 4 streams), so the table
+// is kept in its canonical form (0.55 KiB): cells of the format's table are ordered by weight, then by symbol, and the cells
+// of weight w start at a multiple of 2^(w-1), hence for a cell x of weight w the symbol is sorted[adj[w] + (x >> (w-1))] with
+// adj[w] = (symbols of lower weight) - (start[w] >> (w-1)).  A 128-entry index over the top bits of x gives (w, adj[w]) in one
+// access wherever its bucket lies inside one weight (always, except among the longest codes); the rest compare against start[].
+struct HufCanon {
+    uint16_t lut[128];   // w | adj[w] << 4 (signed), 0 = bucket spans several weights
+    uint8_t sorted[256]; // symbols by (weight, symbol)
+    uint16_t start[12];  // first cell of weight w (start[w] for w = 1 .. table log; beyond: 2^log)
+    int16_t adj[12];
+};
 struct LitLds {
-    Lds build;                                   // construction scratch (weights, FSE table of the weights) and one table
-    uint16_t huf[ZDEC_LIT_GROUP][2048];
-    int32_t bits[ZDEC_LIT_GROUP];                // table log per block, 0 = no table
+    Lds build;                                   // construction scratch: weights, FSE table of the weights
+    HufCanon canon[ZDEC_LIT_GROUP];
+    int32_t bits[ZDEC_LIT_GROUP];                // table log per block, 0 = no decoder
     uint32_t used[ZDEC_LIT_GROUP];               // bytes of the tree description in front of the streams
 };
+
+// weights[0..n) in L.b -> canonical decoder.  Uniform; same validity rules as huf_build_table.  Returns the table log or 0.
+__device__ int huf_build_canon(Lds &L, int n, int lane, HufCanon &C)
+{
+    uint32_t part = 0;
+    bool bad = false;
+    for (int i = lane; i < n; i += 64) {
+        const uint32_t w = L.b.weights[i];
+        if (w > 11) bad = true;
+        else if (w) part += 1u << (w - 1);
+    }
+    const uint32_t sum = zd::wave_sum(part);
+    if (zd::ballot(bad) != 0 || sum == 0) return 0;
+    const int max_bits = zd::hb32(sum) + 1;
+    if (max_bits > 11) return 0;
+    const uint32_t left = (1u << max_bits) - sum;
+    if (left & (left - 1)) return 0;
+    const uint32_t last_w = (uint32_t)zd::hb32(left) + 1;
+    if (lane == 0) L.b.weights[n] = (uint8_t)last_w;
+    zd::wave_sync();
+    const int nsym = n + 1;
+    uint32_t cnt[12], my_w[4];
+#pragma unroll
+    for (int w = 0; w < 12; w++) cnt[w] = 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int sidx = r * 64 + lane;
+        const uint32_t w = sidx < nsym ? L.b.weights[sidx] : 0u;
+        my_w[r] = w;
+#pragma unroll
+        for (int ww = 1; ww < 12; ww++) cnt[ww] += (uint32_t)__popcll(zd::ballot(w == (uint32_t)ww));
+    }
+    uint32_t start[13], rb[12], pos = 0, rank = 0;
+    start[0] = 0;
+#pragma unroll
+    for (int ww = 1; ww < 12; ww++) { start[ww] = pos; rb[ww] = rank; pos += cnt[ww] << (ww - 1); rank += cnt[ww]; }
+    start[12] = pos;
+    if (pos != (1u << max_bits)) return 0;
+    // symbols in (weight, symbol) order
+    const uint64_t lt = (1ull << lane) - 1;
+    uint32_t run[12];
+#pragma unroll
+    for (int w = 0; w < 12; w++) run[w] = 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const uint32_t w = my_w[r];
+#pragma unroll
+        for (int ww = 1; ww < 12; ww++) {
+            const uint64_t m = zd::ballot(w == (uint32_t)ww);
+            if (w == (uint32_t)ww) C.sorted[rb[ww] + run[ww] + (uint32_t)__popcll(m & lt)] = (uint8_t)(r * 64 + lane);
+            run[ww] += (uint32_t)__popcll(m);
+        }
+    }
+    if (lane < 12) {
+        uint32_t st = 1u << max_bits;
+        int32_t ad = 0;
+#pragma unroll
+        for (int ww = 1; ww < 12; ww++)
+            if (lane == ww) { st = ww <= max_bits ? start[ww] : (1u << max_bits); ad = (int32_t)rb[ww] - (int32_t)(start[ww] >> (ww - 1)); }
+        C.start[lane] = (uint16_t)st;
+        C.adj[lane] = (int16_t)ad;
+    }
+    // index over the top min(log, 7) bits
+    const int q = max_bits < 7 ? max_bits : 7, sh = max_bits - q;
+    for (int bkt = lane; bkt < (1 << q); bkt += 64) {
+        const uint32_t x0 = (uint32_t)bkt << sh, x1 = x0 + (1u << sh) - 1;
+        uint32_t w0 = 0, w1 = 0;
+#pragma unroll
+        for (int ww = 1; ww < 12; ww++) {
+            if (ww <= max_bits && cnt[ww]) { if (x0 >= start[ww]) w0 = (uint32_t)ww; if (x1 >= start[ww]) w1 = (uint32_t)ww; }
+        }
+        int32_t ad = 0;
+#pragma unroll
+        for (int ww = 1; ww < 12; ww++) if (w0 == (uint32_t)ww) ad = (int32_t)rb[ww] - (int32_t)(start[ww] >> (ww - 1));
+        C.lut[bkt] = (w0 == w1 && w0) ? (uint16_t)(w0 | ((uint32_t)ad << 4)) : (uint16_t)0;
+    }
+    zd::wave_sync();
+    return max_bits;
+}
+
+// one stream on the calling lane through the canonical decoder; symbols leave in 8-byte stores
+__device__ __forceinline__ uint32_t canon_symbol(const HufCanon &C, int max_bits, int sh, uint32_t x, uint32_t *nbits)
+{
+    const uint32_t e = C.lut[x >> sh];
+    uint32_t w;
+    int32_t ad;
+    if (e) { w = e & 15u; ad = (int32_t)(int16_t)e >> 4; }
+    else {
+        w = 1;
+        for (int ww = 2; ww <= max_bits; ww++) if (x >= C.start[ww]) w = (uint32_t)ww; // start[] of unused weights repeats the next one
+        ad = C.adj[w];
+    }
+    *nbits = (uint32_t)max_bits + 1u - w;
+    return C.sorted[ad + (int32_t)(x >> (w - 1))];
+}
+__device__ bool huf_decode_stream_canon(const HufCanon &C, int max_bits, const uint8_t *src, uint32_t len, uint8_t *out, uint32_t nout)
+{
+    BackBits b;
+    if (!b.init(src, len)) return false;
+    const int sh = max_bits - (max_bits < 7 ? max_bits : 7);
+    uint32_t i = 0;
+    for (; i + 8 <= nout; i += 8) {
+        uint64_t w = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            uint32_t nb;
+            const uint32_t sym = canon_symbol(C, max_bits, sh, b.peek(max_bits), &nb);
+            b.skip((int)nb);
+            w |= (uint64_t)sym << (8 * j);
+        }
+        __builtin_memcpy(out + i, &w, 8);
+    }
+    for (; i < nout; i++) {
+        uint32_t nb;
+        out[i] = (uint8_t)canon_symbol(C, max_bits, sh, b.peek(max_bits), &nb);
+        b.skip((int)nb);
+    }
+    return b.bitpos == 0;
+}
 
 __global__ void __launch_bounds__(64) zarc_zdec_literals(const uint8_t *__restrict__ frames_base, const uint64_t *__restrict__ frame_off, uint64_t n_slots,
                                                          const uint64_t *__restrict__ slot_prefix, const ZdecBlock *__restrict__ zblocks,
@@ -1167,13 +1271,12 @@ __global__ void __launch_bounds__(64) zarc_zdec_literals(const uint8_t *__restri
             const ZdecBlock sb = zblocks[from];
             int nw = 0;
             used = huf_read_weights(S.build, frames_base + frame_off[f] + sb.lit_off, sb.lit_comp, lane, &nw);
-            ok = used >= 0 && huf_build_table(S.build, nw, lane);
+            int tl = 0;
+            if (used >= 0) tl = huf_build_canon(S.build, nw, lane, S.canon[i]);
+            ok = tl != 0;
+            if (ok && lane == 0) { S.bits[i] = tl; S.used[i] = zb.lit_type == 2 ? (uint32_t)used : 0u; }
         }
-        if (ok) {
-            const int cells = 1 << S.build.ctrl[C_HUF_BITS];
-            for (int c = lane; c < cells; c += 64) S.huf[i][c] = S.build.huf[c];
-            if (lane == 0) { S.bits[i] = S.build.ctrl[C_HUF_BITS]; S.used[i] = zb.lit_type == 2 ? (uint32_t)used : 0u; }
-        } else if (lane == 0) fast[f] = 0;
+        if (!ok && lane == 0) fast[f] = 0;
         zd::wave_sync();
     }
     zd::wave_sync();
@@ -1191,9 +1294,9 @@ __global__ void __launch_bounds__(64) zarc_zdec_literals(const uint8_t *__restri
         const uint8_t *hp = frames_base + frame_off[f] + zb.lit_off + S.used[i];
         const uint32_t rem = zb.lit_comp - S.used[i];
         uint8_t *dst = lits + lit_index[s];
-        const uint16_t *ht = S.huf[i];
+        const HufCanon &ht = S.canon[i];
         const int tl = S.bits[i];
-        if (zb.lit_streams == 1) ok = huf_decode_stream8(ht, tl, hp, rem, dst, zb.lit_len);
+        if (zb.lit_streams == 1) ok = huf_decode_stream_canon(ht, tl, hp, rem, dst, zb.lit_len);
         else if (rem < 6) ok = false;
         else {
             const uint32_t s1 = hp[0] | ((uint32_t)hp[1] << 8), s2 = hp[2] | ((uint32_t)hp[3] << 8), s3 = hp[4] | ((uint32_t)hp[5] << 8);
@@ -1203,7 +1306,7 @@ __global__ void __launch_bounds__(64) zarc_zdec_literals(const uint8_t *__restri
                 const uint32_t s4 = rem - 6 - s1 - s2 - s3;
                 const uint32_t so = k == 0 ? 0 : (k == 1 ? s1 : (k == 2 ? s1 + s2 : s1 + s2 + s3));
                 const uint32_t sl = k == 0 ? s1 : (k == 1 ? s2 : (k == 2 ? s3 : s4));
-                ok = huf_decode_stream8(ht, tl, hp + 6 + so, sl, dst + k * per, k < 3 ? per : zb.lit_len - 3 * per);
+                ok = huf_decode_stream_canon(ht, tl, hp + 6 + so, sl, dst + k * per, k < 3 ? per : zb.lit_len - 3 * per);
             }
         }
     }
