@@ -507,7 +507,7 @@ int zarc_gpu_unpack_batch_device(zarc_gpu_t *h, size_t n, const void *d_frames_b
         ZHIP(h->d_seqs.reserve(std::max<uint64_t>(total, 1) * 8));
         ZHIP(h->d_lits.reserve(std::max<uint64_t>(lit_total, 1) + 64));
         // the literal and the sequence kernels are independent and neither fills the chip: they run side by side
-        const bool side = lit_total && total;
+        const bool side = lit_total && total && !(getenv("ZARC_GPU_DEC_SIDE") && atoi(getenv("ZARC_GPU_DEC_SIDE")) == 0);
         if (side) { ZHIP(hipEventRecord(h->ev_fork, h->stream)); ZHIP(hipStreamWaitEvent(h->stream2, h->ev_fork, 0)); }
         if (lit_total) {
             hipLaunchKernelGGL(zarc_zdec_literals, dim3((unsigned)((nslots + ZDEC_LIT_GROUP - 1) / ZDEC_LIT_GROUP)), dim3(64), 0, side ? h->stream2 : h->stream, (const uint8_t *)d_frames_base,

@@ -1222,8 +1222,11 @@ __device__ bool huf_decode_stream_canon(const HufCanon &C, int max_bits, const u
         uint64_t w = 0;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
+            // refill on a fixed schedule (4 symbols take at most 44 of the >= 57 bits a refill provides): a data-dependent
+            // refill would have some lane of the wave waiting for its load at nearly every symbol
+            if ((j & 3) == 0) b.refill();
             uint32_t nb;
-            const uint32_t sym = canon_symbol(C, max_bits, sh, b.peek(max_bits), &nb);
+            const uint32_t sym = canon_symbol(C, max_bits, sh, (uint32_t)((b.c << b.used) >> (64 - max_bits)), &nb);
             b.skip((int)nb);
             w |= (uint64_t)sym << (8 * j);
         }
