@@ -169,16 +169,17 @@ def main():
         achieved = alg_bytes / (k_ms[dom] * 1e-3) / 1e9 if k_ms[dom] > 0 else 0.0
         # HBM traffic of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
         # runs; FETCH_SIZE doubled per MI355X_MICROARCH.md -- calibrated here on zarc_xxh64, which reads exactly N bytes
-        # and reports N/2), scaled from the profiled batch (2048 x 1 MiB) to this one by uncompressed bytes.
+        # and reports N/2), scaled from the profiled batch to this one by uncompressed bytes.
         traffic, traffic_src = None, None
-        pmc_file = os.path.join(ROOT, "profiles", "r01_bench2048_pmc_summary.json")
+        pmc_file = os.path.join(ROOT, "profiles", "r01_bench_pmc_summary.json")
         if os.path.exists(pmc_file):
             pmc = json.load(open(pmc_file))
             kname = "zarc_" + names[dom]
             if kname in pmc.get("fetch", {}) and kname in pmc.get("write", {}):
                 per = (2.0 * pmc["fetch"][kname]["per_dispatch"] + pmc["write"][kname]["per_dispatch"]) * 1024.0
-                traffic = per * raw_bytes / (2048.0 * (1 << 20))
-                traffic_src = "profiles/r01_bench2048_pmc_summary.json, scaled by uncompressed bytes"
+                prof_bytes = float(pmc.get("entries", 2048)) * float(pmc.get("entry_bytes", 1 << 20))
+                traffic = per * raw_bytes / prof_bytes
+                traffic_src = "profiles/r01_bench_pmc_summary.json (%d entries profiled), scaled by uncompressed bytes" % pmc.get("entries", 2048)
         line = {
             "metric": "uncompressed GiB/s (pack) at zstd -3", "value": round(pack_gibs, 3), "unit": "GiB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(tp / args.steps * 1e3, 3),

@@ -20,7 +20,9 @@ for name in ("fetch", "write"):
             agg[k][0] += 1
             agg[k][1] += float(row["Counter_Value"])
     out[name] = {k: {"dispatches": v[0], "sum": v[1], "per_dispatch": v[1] / max(v[0], 1)} for k, v in agg.items()}
+out["entries"] = $N
+out["entry_bytes"] = 1 << 20
 json.dump(out, open("$O/pmc_summary.json", "w"), indent=1, sort_keys=True)
-print(json.dumps({k: {kk: round(vv["per_dispatch"]) for kk, vv in v.items()} for k, v in out.items()}, indent=0)[:1500])
+print(json.dumps({k: {kk: round(vv["per_dispatch"]) for kk, vv in v.items()} for k, v in out.items() if isinstance(v, dict)}, indent=0)[:1500])
 PY
 tail -1 $O/trace.log | cut -c1-600
