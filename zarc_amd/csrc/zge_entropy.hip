@@ -9,8 +9,10 @@
 //     (direct or FSE-compressed) on lane 0
 //   - literal streams: 64 symbols per step, wave prefix-sum of code lengths, codes OR-ed into an LDS
 //     staging window (ds_or), whole bytes flushed to HBM
-//   - sequences: code histograms in parallel; the three FSE state chains run on lanes 0..2 for 64
-//     sequences at a time, then all 64 lanes pack their sequence's bit fields the same way
+//   - sequences: literal lengths and repeat-offset codes for 64 sequences at a time (the history after sequence i
+//     is a function of few neighbours: two ballots + count-leading-zeros); code histograms in parallel; the three
+//     FSE state chains run on lanes 0..2 with the per-symbol constants fetched by all lanes beforehand (one
+//     dependent LDS access per step), then all 64 lanes pack their sequence's bit fields the same way
 // Bit-identical to oracle/zstd_enc_model.c (encode_literals / encode_sequences).
 #include "zarc_device.h"
 #include "zarc_kernels.h"

@@ -3,23 +3,26 @@
 // Part of the replacement for `CCtx::compress2` at crates/zarc/src/encode/lowlevel_frames.rs:29-31
 // (called per entry from Encoder::add_data_frame, crates/zarc/src/encode/content_frame.rs:41).
 //
-// One 512-thread workgroup per frame, TWO frames per CU (their latencies overlap): the two position hash
-// tables (8-byte "long" hash and 5-byte "short" hash, 2^13 u32 entries each = 64 KiB per frame) stay in LDS
-// for the whole frame, so matches reach back across all earlier blocks (window = frame, up to 2 MiB).  Each
-// entry packs (position+1) << 10 | 10 hash check bits: a lookup rejects most false candidates without
-// touching memory.
+// Persistent 512-thread workgroups, TWO per CU (their waits overlap), take frames from a queue (largest first).  The
+// two position hash tables of a frame (8-byte "long" hash and 5-byte "short" hash, 2^13 u32 entries each = 64 KiB)
+// stay in LDS for the whole frame, so matches reach back across all earlier blocks (up to the 2 MiB table segment).
+// Each entry packs (position+1) << 10 | 10 hash check bits: a lookup rejects most false candidates without touching
+// memory.  The kernel is bound by VALU issue and by barrier / L2 waits, not by HBM.
 // A block (<= 128 KiB) is swept in tiles of 1024 positions, two positions per thread (t and t+512):
-//   S0/S1 stage the tile's bytes in LDS (coalesced dword loads), hash every position (64-bit multiplies)
-//   S2    ordered lookup + insert by wave 0, 64 positions per step: LDS executes one wave's instructions in
-//         order, so a position sees every insert of earlier 64-groups with no waiting between steps
-//   S3    every position scores its candidates {long, short, 2 recent offsets}: all source words are
-//         requested up front (one round trip to L2/HBM), tile side comes from LDS; backward-extension potential
+//   S0/S1 the tile's window (recent-offset range before it, compare overrun after it) goes to LDS -- the dword of the
+//         NEXT tile is requested now and parked in a register; every position is hashed (32-bit multiplies)
+//   S2    ordered lookup + insert, one wave per table, 64 positions per step: LDS executes one wave's instructions
+//         in order, so a position sees every insert of earlier 64-groups with no waiting between steps
+//   S3    every position scores its candidates: one 16-byte request source[-8..8) per table candidate (first compare
+//         and backward extension), the two recent-offset guesses are scored out of LDS while those are in flight;
+//         offers for backward propagation are posted with ds_max
 //   S4    backward propagation: position t may start the match found at t+k, k bytes earlier
 //   S5    one-byte lazy rule -> take flag and successor next[t] for every position
 //   S6    the greedy parse IS the path from the entry cursor through next[]: per 64-position chunk the exit of
 //         every position by 6 rounds of shuffle pointer-jumping, then the chunk entries by a short chain
 //         through LDS, then each wave marks its chunk's path with v_readlane -- no workgroup barriers
-//   S7    ballot/popcount prefix sums place literal bytes and sequences; nothing is serial per sequence
+//   S7    ballot/popcount prefix sums (16-lane scan over the chunks) place literal bytes and sequences
+//   A tile in which no position found a match takes an all-literals path after S3.
 // Output per block: packed (literal position, match length, offset) + literal bytes in HBM scratch; literal
 // lengths and repcodes are resolved by the entropy stage.  Deterministic and bit-identical to
 // oracle/zstd_enc_model.c (tests/ compare them).
@@ -76,7 +79,7 @@ __device__ __forceinline__ uint32_t hash_short(uint64_t v, int bits, int nbytes)
 }
 
 // Bit-cost model (lit_cost 5, match_cost 12, rep_cost 9: the engine's fixed defaults, so the literal cost is a
-// shift-add instead of a quarter-rate multiply).  The engine refuses to launch with other values.
+// shift-add instead of a quarter-rate multiply; engine.hip: derive_params() sets exactly these, they are not tunable).
 constexpr int LIT_COST = 5, MATCH_COST = 12, REP_COST = 9;
 __device__ __forceinline__ int32_t score_of(const ZgeParams &, uint32_t len, uint32_t off, bool is_rep)
 {

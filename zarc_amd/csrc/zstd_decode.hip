@@ -2,17 +2,20 @@
 //
 // Replaces libzstd's ZSTD_decompressStream as driven by the reference at
 //   crates/zarc/src/decode/zstd_iterator.rs:88-153 (decompress_step) / :24-36 (one fresh DCtx per frame).
-// Frames are independent (no dictionary, no cross-frame window), so the unit of parallelism is the frame:
-// ONE WAVE PER FRAME, thousands of frames in flight.  Inside a frame the format is a chain of serial
-// dependencies (backward bitstreams, FSE states, repeat offsets, LZ window), so:
-//   - table construction and bitstream decoding run on one lane (or four lanes for the four Huffman
-//     streams) -- latency is hidden by the other resident waves, not by lanes of this wave;
-//   - every byte move (raw/RLE blocks, literal runs, match copies) is wave-cooperative, 64 lanes wide;
-//   - decode tables live in LDS (about 9.5 KiB per wave: 2048x2 B Huffman + 512/512/256 x 4 B FSE), which
-//     also makes Treeless literals and Repeat-mode tables free: the previous block's tables simply stay.
-// Literals of Huffman-coded blocks are regenerated into a per-frame scratch area in HBM; raw literals
-// are used in place from the compressed stream.
-// Algorithmic traffic per frame: C bytes read + N bytes written (+ literals scratch round trip).
+// Frames are independent (no dictionary, no cross-frame window).  Inside a frame the format is a chain of serial
+// dependencies (backward bitstreams, FSE states, repeat offsets, LZ window), and a wave that decodes a bitstream on one
+// lane spends 64 lanes' worth of issue slots on it.  So decoding is split by the kind of parallelism each part has:
+//   zarc_zdec_scan      one LANE per frame: frame header, block headers, where each block's sections are, how many
+//                       sequences and Huffman literal bytes it holds (the host sizes the scratch from these counts)
+//   zarc_zdec_seqs      one LANE per block: FSE tables (built in HBM scratch) and the sequence bitstream -> 8-byte
+//                       (literal length, match length, offset) records; repeat offsets resolved symbolically
+//   zarc_zdec_literals  one wave per 16 blocks: canonical Huffman decoders in LDS, one LANE per stream -> literal bytes
+//   zarc_zstd_decode    one persistent WAVE per frame (frames come from a queue): prefix sums give every sequence of a
+//                       batch of 64 its literal and output position, every byte move is wave-cooperative or one
+//                       16-byte head/tail pair per lane
+// Anything unusual in a frame clears fast[frame]; zarc_zstd_decode then decodes that frame INLINE (tables in LDS, about
+// 7.5 KiB per wave; bitstreams on lane 0 / lanes 0..3), which is also the only place where error statuses are decided.
+// Algorithmic traffic per frame: C bytes read + N bytes written (+ the sequence / literal scratch round trip).
 #include "zarc_device.h"
 #include "zarc_kernels.h"
 
