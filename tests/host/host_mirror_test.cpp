@@ -68,6 +68,20 @@ int main(int argc, char **argv)
         CHECK(res[i].data == ents[i] && res[i].digest == dig[i]);
     }
     CHECK(res[6].status == ZARC_GPU_FRAME_DIGEST && res[6].verify.has_value() && !*res[6].verify && res[6].data == ents[2]);
+    // --- Encoder::enable_compression(false): stored (raw-block) frame, bookkeeping as for any other frame (content_frame.rs:35-44) ---
+    {
+        std::vector<uint8_t> e(200000);
+        zarc_corpus_entry(e.data(), e.size(), 4242, 0);
+        const uint64_t before = enc.offset();
+        enc.enable_compression(false);
+        const zarc::Digest d = enc.add_data_frame(e.data(), e.size());
+        enc.enable_compression(true);
+        const zarc::Frame &f = enc.frames().at(d);
+        CHECK(f.offset == before && f.uncompressed == e.size() && f.length == 14 + e.size() + 3 * 2 && enc.offset() == before + f.length);
+        const std::string img = file.str();
+        auto r = rd.read_content_frames((const uint8_t *)img.data(), img.size(), {f});
+        CHECK(r[0].status == ZARC_GPU_FRAME_OK && r[0].verify.value_or(false) && r[0].data == e);
+    }
     // --- parameter errors surface as exceptions carrying the libzstd-style name ---
     bool threw = false;
     try { enc.set_zstd_parameter(ZARC_GPU_P_COMPRESSION_LEVEL, 99); } catch (const zarc::Error &e) { threw = e.code == ZARC_GPU_E_PARAM; }

@@ -132,6 +132,35 @@ def check_unpack_errors(engine, oracle, corpus, golden_frames):
         assert oracle.zstd_decode(frames[i], len(raw))[0] != 0
 
 
+def check_store(engine, oracle, corpus, libzstds):
+    """Encoder::enable_compression(false) (encode.rs:95-97, lowlevel_frames.rs:47-84): raw-block frames.  The layout is pinned
+    byte for byte: the reference's descriptor (8-byte content size, no single segment, no checksum) plus the window byte
+    the reference forgets, 128 KiB raw blocks.  Every real libzstd must decode them."""
+    sizes = [0, 1, 300, 65535, 65536, 131072, 131073, 400000]
+    ents = [corpus.entry(700 + i, n, i & 3) for i, n in enumerate(sizes)]
+    engine.enable_compression(False)
+    try:
+        res = engine.pack(ents)
+    finally:
+        engine.enable_compression(True)
+    for (frame, dig), raw in zip(res, ents):
+        want = bytes.fromhex("28B52FFD" "C0" "38") + len(raw).to_bytes(8, "little")
+        nb = max(1, (len(raw) + 131071) // 131072)
+        for b in range(nb):
+            chunk = raw[b * 131072:(b + 1) * 131072]
+            want += ((1 if b + 1 == nb else 0) | (len(chunk) << 3)).to_bytes(3, "little") + chunk
+        assert frame == want
+        assert dig == oracle.blake3(raw)
+        st, out, _ = oracle.zstd_decode(frame, len(raw))
+        assert st == 0 and out == raw
+        for z in libzstds:
+            out, err = z.decompress(frame, len(raw))
+            assert err is None and out == raw, (z.version, err)
+    outs = engine.unpack([f for f, _ in res], [len(e) for e in ents], expect=[d for _, d in res])
+    for (out, dig, st), raw in zip(outs, ents):
+        assert st == 0 and out == raw
+
+
 def check_params(engine):
     import pytest
     from zarc_amd import ZarcGpuError

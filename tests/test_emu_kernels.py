@@ -28,6 +28,10 @@ def test_emu_params(emu_engine):
     pc.check_params(emu_engine)
 
 
+def test_emu_store_mode(emu_engine, oracle, corpus, libzstds):
+    pc.check_store(emu_engine, oracle, corpus, libzstds)
+
+
 def test_emu_unpack_fuzz_agrees_with_oracle(emu_engine, oracle, corpus, golden_frames):
     ok, bad = pc.check_unpack_fuzz(emu_engine, oracle, corpus, golden_frames, n_mut=160, seed=1, max_raw=70000)
     assert bad > 40 and ok >= 0

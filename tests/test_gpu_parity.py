@@ -47,6 +47,11 @@ def test_gpu_params(engine):
     pc.check_params(engine)
 
 
+@pytest.mark.gpu
+def test_gpu_store_mode(engine, oracle, corpus, libzstds):
+    pc.check_store(engine, oracle, corpus, libzstds)
+
+
 def test_gpu_c1_config(engine, oracle, corpus):
     # BASELINE.json configs[0]: 10 x 64 KiB random -> 10 frames of exactly 65 550 bytes
     ents = [corpus.entry(i, 65536, 3) for i in range(10)]

@@ -332,7 +332,6 @@ int zarc_gpu_pack_batch_device(zarc_gpu_t *h, size_t n, const void *d_src_base, 
     if (rc) return rc;
     if (n == 0) return ZARC_GPU_OK;
     if (!d_src_base || !src_off || !src_len || !d_dst || !dst_off || !dst_len || !digest) return ZARC_GPU_E_PARAM;
-    if (!h->params.compress) { h->last_error = "store mode (enable_compression(false)) is not implemented on the device path"; return ZARC_GPU_E_UNSUPPORTED; }
     const ZgeParams P = derive_params(h->params);
     uint64_t need = 0;
     for (size_t i = 0; i < n; i++) {
@@ -353,6 +352,24 @@ int zarc_gpu_pack_batch_device(zarc_gpu_t *h, size_t n, const void *d_src_base, 
     ZHIP(t.mark(&e0));
     if ((rc = run_blake3(h, n, base, src_off, src_len, d_off, d_len))) return rc;
     ZHIP(t.mark(&e1));
+    if (!h->params.compress) {
+        // store mode (Encoder::enable_compression(false)): raw-block frames, no checksum (lowlevel_frames.rs:47-84)
+        hipLaunchKernelGGL(zarc_zge_store, dim3((unsigned)n), dim3(256), 0, h->stream, base, d_off, d_len, (uint32_t)n, (uint8_t *)d_dst,
+                           h->d_dst_off.as<uint64_t>(), h->d_dst_len.as<uint64_t>());
+        ZHIP(hipGetLastError());
+        ZHIP(t.mark(&e2));
+        ZHIP(hipMemcpyAsync(dst_len, h->d_dst_len.p, n * 8, hipMemcpyDeviceToHost, h->stream));
+        ZHIP(hipMemcpyAsync(digest, h->d_digests.p, n * 32, hipMemcpyDeviceToHost, h->stream));
+        ZHIP(hipStreamSynchronize(h->stream));
+        if (status) for (size_t i = 0; i < n; i++) status[i] = ZARC_GPU_FRAME_OK;
+        h->ms[ZARC_GPU_T_BLAKE3] = elapsed(h, e0, e1);
+        h->ms[ZARC_GPU_T_XXH64] = 0;
+        h->ms[ZARC_GPU_T_MATCH] = 0;
+        h->ms[ZARC_GPU_T_ENTROPY] = 0;
+        h->ms[ZARC_GPU_T_ASSEMBLE] = elapsed(h, e1, e2);
+        h->ms[ZARC_GPU_T_TOTAL] = h->ms[ZARC_GPU_T_BLAKE3] + h->ms[ZARC_GPU_T_ASSEMBLE];
+        return ZARC_GPU_OK;
+    }
     if ((rc = run_xxh64(h, n, base, d_off, d_len))) return rc;
     ZHIP(t.mark(&e2));
 

@@ -70,6 +70,42 @@ __global__ void __launch_bounds__(256) zarc_zge_assemble(ZgeParams P, const uint
     if (tid == 0) dst_len[f] = pos;
 }
 
+// Store mode (Encoder::enable_compression(false), crates/zarc/src/encode.rs:95-97 -> write_uncompressed_frame,
+// encode/lowlevel_frames.rs:47-84): the content goes into Raw blocks.  Like the reference's frame this one carries an
+// 8-byte Frame_Content_Size, no Single_Segment flag and no checksum -- but it also carries the Window_Descriptor that
+// flag combination requires (the reference omits it, which makes its stored frames undecodable: SURVEY.md quirk 2), and
+// the blocks are the format's 128 KiB instead of 65 535 bytes.  Window 128 KiB = the smallest that allows such blocks.
+//   28 B5 2F FD | C0 | 38 | content size (8 bytes LE) | { 3-byte block header, <= 131072 raw bytes }*
+__global__ void __launch_bounds__(256) zarc_zge_store(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off,
+                                                      const uint64_t *__restrict__ src_len, uint32_t n_frames, uint8_t *__restrict__ dst_base,
+                                                      const uint64_t *__restrict__ dst_off, uint64_t *__restrict__ dst_len)
+{
+    const uint32_t f = blockIdx.x;
+    if (f >= n_frames) return;
+    const int tid = (int)threadIdx.x;
+    const uint8_t *src = src_base + src_off[f];
+    const uint64_t n = src_len[f];
+    uint8_t *dst = dst_base + dst_off[f];
+    if (tid == 0) {
+        dst[0] = 0x28; dst[1] = 0xB5; dst[2] = 0x2F; dst[3] = 0xFD;
+        dst[4] = 0xC0; // Frame_Content_Size flag 3 (8 bytes), not single segment, no checksum, no dictionary id
+        dst[5] = 0x38; // Window_Descriptor: exponent 7, mantissa 0 -> 128 KiB
+        for (int i = 0; i < 8; i++) dst[6 + i] = (uint8_t)(n >> (8 * i));
+    }
+    uint64_t pos = 14;
+    const uint64_t nblocks = n == 0 ? 1 : (n + ZARC_BLOCK - 1) / ZARC_BLOCK;
+    for (uint64_t b = 0; b < nblocks; b++) {
+        const uint64_t at = b * ZARC_BLOCK;
+        const uint32_t cnt = (uint32_t)(n - at > ZARC_BLOCK ? ZARC_BLOCK : n - at);
+        const uint32_t hdr = (b + 1 == nblocks ? 1u : 0u) | (cnt << 3); // type 0 = Raw
+        if (tid == 0) { dst[pos] = (uint8_t)hdr; dst[pos + 1] = (uint8_t)(hdr >> 8); dst[pos + 2] = (uint8_t)(hdr >> 16); }
+        pos += 3;
+        for (uint32_t i = (uint32_t)tid; i < cnt; i += blockDim.x) dst[pos + i] = src[at + i];
+        pos += cnt;
+    }
+    if (tid == 0) dst_len[f] = pos;
+}
+
 // status[i] keeps a decode error; otherwise CHECKSUM when the stored XXH64 differs (what libzstd reports as
 // "Restored data doesn't match checksum"); otherwise DIGEST when the BLAKE3 differs from `expect` -- which the
 // reference only logs (crates/zarc-cli/src/unpack.rs:118-120), so the bytes are delivered either way.

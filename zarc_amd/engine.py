@@ -45,6 +45,10 @@ class Engine:
     def set_parameter(self, param_id, value):
         self._check(self.lib.zarc_gpu_set_parameter(self.h, param_id, value))
 
+    def enable_compression(self, compress):
+        """Encoder::enable_compression (crates/zarc/src/encode.rs:95-97): False -> raw-block ("stored") frames."""
+        self.lib.zarc_gpu_enable_compression(self.h, 1 if compress else 0)
+
     def params(self):
         p = _lib.Params()
         self.lib.zarc_gpu_get_params(self.h, ctypes.byref(p))
