@@ -2,6 +2,7 @@
 #include "hip/hip_runtime.h"
 #include <chrono>
 #include <csetjmp>
+#include <mutex>
 #include <sys/mman.h>
 #include <ucontext.h>
 #include <vector>
@@ -171,6 +172,9 @@ static void run_block(dim3 block)
 
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &body)
 {
+    // one kernel at a time, whichever host thread launches it (the engine's staging helper thread launches a gather kernel)
+    static std::mutex launch_mutex;
+    std::lock_guard<std::mutex> guard(launch_mutex);
     g_body = &body;
     g_gdim = grid;
     g_bdim = block;

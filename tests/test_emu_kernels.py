@@ -35,3 +35,12 @@ def test_emu_store_mode(emu_engine, oracle, corpus, libzstds):
 def test_emu_unpack_fuzz_agrees_with_oracle(emu_engine, oracle, corpus, golden_frames):
     ok, bad = pc.check_unpack_fuzz(emu_engine, oracle, corpus, golden_frames, n_mut=160, seed=1, max_raw=70000)
     assert bad > 40 and ok >= 0
+
+
+def test_emu_host_staging_in_chunks(emu_engine, oracle, corpus, golden_frames, monkeypatch):
+    """The host-pointer entry points cut a batch into chunks and overlap their copies: with a tiny chunk size every
+    batch below runs through many chunks, double-buffered arenas and the helper thread; results must not change."""
+    monkeypatch.setenv("ZARC_GPU_STAGE_CHUNK", "20000")
+    pc.check_roundtrip(emu_engine, oracle, corpus, big=False)
+    pc.check_unpack_errors(emu_engine, oracle, corpus, golden_frames)
+    pc.check_store(emu_engine, oracle, corpus, [])

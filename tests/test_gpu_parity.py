@@ -144,3 +144,12 @@ def test_gpu_unpack_fuzz_agrees_with_oracle(engine, oracle, corpus, golden_frame
         ok, bad = pc.check_unpack_fuzz(engine, oracle, corpus, golden_frames, n_mut=1500, seed=100 + seed, max_raw=310000)
         tot_ok += ok; tot_bad += bad
     assert tot_bad > 1000
+
+
+def test_gpu_host_staging_in_chunks(engine, oracle, corpus, golden_frames, libzstds, monkeypatch):
+    """Host-pointer entry points with many small chunks (double-buffered arenas, helper thread copies overlapping the kernels)."""
+    monkeypatch.setenv("ZARC_GPU_STAGE_CHUNK", "300000")
+    pc.check_roundtrip(engine, oracle, corpus, big=True)
+    pc.check_unpack_errors(engine, oracle, corpus, golden_frames)
+    pc.check_store(engine, oracle, corpus, libzstds)
+    pc.check_pack(engine, oracle, corpus, libzstds, big=True)

@@ -8,9 +8,11 @@
 #include "zarc_kernels.h"
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <new>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -39,6 +41,12 @@ struct zarc_gpu {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr; // side stream: independent stage-2 kernels of the decoder run next to each other
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // pinned staging ring of the host-pointer entry points (allocated on first use)
+    static constexpr int PIN_SLOTS = 4;
+    static constexpr size_t PIN_PIECE = (size_t)32 << 20;
+    uint8_t *pin[PIN_SLOTS] = {};
+    hipEvent_t pin_ev[PIN_SLOTS] = {};
+    DevBuf d_dense, d_goff, d_glen, d_gdense; // gather of the frames of a chunk before they cross PCIe
     zarc_gpu_params params{};
     std::string last_error;
     // descriptors
@@ -208,6 +216,8 @@ void zarc_gpu_destroy(zarc_gpu_t *h)
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
+    for (int i = 0; i < zarc_gpu::PIN_SLOTS; i++) { if (h->pin[i]) (void)hipHostFree(h->pin[i]); if (h->pin_ev[i]) (void)hipEventDestroy(h->pin_ev[i]); }
+    h->d_dense.release(); h->d_goff.release(); h->d_glen.release(); h->d_gdense.release();
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     delete h;
@@ -606,6 +616,122 @@ int zarc_gpu_blake3_batch(zarc_gpu_t *h, size_t n, const void *const *src, const
     return zarc_gpu_blake3_batch_device(h, n, h->d_arena_in.p, off.data(), l64.data(), (uint8_t *)digest);
 }
 
+// ---- host-pointer entry points: chunked, with the PCIe copies of neighbouring chunks overlapped -----------------------
+// The caller's buffers are ordinary pageable memory, so hipMemcpyAsync blocks the calling thread while it stages the
+// bytes.  A helper thread therefore moves chunk c+1 in and chunk c-1 out (side stream) while this thread runs the
+// kernels of chunk c (engine stream); arenas are double-buffered, which also bounds the staging memory of huge batches.
+// Chunks are large (4 GiB of content): the kernels need thousands of frames in flight to fill the chip (a 1 MiB frame is
+// a ~10 ms serial chain for one workgroup / wave), measured: 256 MiB chunks halve the throughput.  SURVEY.md 8 row f4.
+namespace {
+
+// A byte range of the caller's memory and where it sits in a flat device range
+struct Seg { uint8_t *host; uint64_t dev; uint64_t len; };
+
+int pin_ring(zarc_gpu *h)
+{
+    for (int i = 0; i < zarc_gpu::PIN_SLOTS; i++) {
+        if (!h->pin[i] && hipHostMalloc((void **)&h->pin[i], zarc_gpu::PIN_PIECE, 0) != hipSuccess) { h->pin[i] = nullptr; return ZARC_GPU_E_NOMEM; }
+        if (!h->pin_ev[i] && hipEventCreate(&h->pin_ev[i]) != hipSuccess) return ZARC_GPU_E_DEVICE;
+    }
+    return 0;
+}
+
+// copy the parts of `segs` (sorted by .dev, non-overlapping) that fall into device range [lo, hi) between the caller's memory
+// and `pinned` (which mirrors [lo, hi)), with several threads: the single-thread memcpy rate is far below PCIe
+void piece_copy(const std::vector<Seg> &segs, size_t first_seg, uint64_t lo, uint64_t hi, uint8_t *pinned, bool to_pinned)
+{
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = nt < 2 ? 1 : (nt > 8 ? 8 : nt);
+    if (hi - lo < ((uint64_t)1 << 20)) nt = 1;
+    auto work = [&](uint64_t a, uint64_t b) {
+        for (size_t k = first_seg; k < segs.size() && segs[k].dev < b; k++) {
+            const uint64_t s0 = std::max(segs[k].dev, a), s1 = std::min(segs[k].dev + segs[k].len, b);
+            if (s0 >= s1) continue;
+            if (to_pinned) memcpy(pinned + (s0 - lo), segs[k].host + (s0 - segs[k].dev), s1 - s0);
+            else memcpy(segs[k].host + (s0 - segs[k].dev), pinned + (s0 - lo), s1 - s0);
+        }
+    };
+    if (nt == 1) { work(lo, hi); return; }
+    std::vector<std::thread> th;
+    const uint64_t step = (hi - lo + nt - 1) / nt;
+    for (unsigned t = 0; t < nt; t++) {
+        const uint64_t a = lo + t * step, b = std::min(hi, a + step);
+        if (a < b) th.emplace_back(work, a, b);
+    }
+    for (auto &x : th) x.join();
+}
+
+// caller memory -> device range [0, total) at `dev_base`, through the pinned ring on `stream`
+int staged_h2d(zarc_gpu *h, hipStream_t stream, const std::vector<Seg> &segs, uint8_t *dev_base, uint64_t total)
+{
+    int rc = pin_ring(h);
+    if (rc) return rc;
+    size_t first = 0;
+    int slot = 0;
+    for (uint64_t lo = 0; lo < total; lo += zarc_gpu::PIN_PIECE, slot = (slot + 1) % zarc_gpu::PIN_SLOTS) {
+        const uint64_t hi = std::min<uint64_t>(total, lo + zarc_gpu::PIN_PIECE);
+        while (first < segs.size() && segs[first].dev + segs[first].len <= lo) first++;
+        ZHIP(hipEventSynchronize(h->pin_ev[slot])); // the transfer that last used this slot is over
+        piece_copy(segs, first, lo, hi, h->pin[slot], true);
+        ZHIP(hipMemcpyAsync(dev_base + lo, h->pin[slot], hi - lo, hipMemcpyHostToDevice, stream));
+        ZHIP(hipEventRecord(h->pin_ev[slot], stream));
+    }
+    return 0;
+}
+
+// device range [0, total) at `dev_base` -> caller memory; the scatter of piece p overlaps the transfer of piece p+1
+int staged_d2h(zarc_gpu *h, hipStream_t stream, const std::vector<Seg> &segs, const uint8_t *dev_base, uint64_t total)
+{
+    int rc = pin_ring(h);
+    if (rc) return rc;
+    struct Piece { uint64_t lo, hi; int slot; size_t first; };
+    size_t first = 0;
+    int slot = 0;
+    bool have_prev = false;
+    Piece prev{};
+    for (uint64_t lo = 0; lo < total; lo += zarc_gpu::PIN_PIECE, slot = (slot + 1) % 2) { // two slots alternate
+        const uint64_t hi = std::min<uint64_t>(total, lo + zarc_gpu::PIN_PIECE);
+        while (first < segs.size() && segs[first].dev + segs[first].len <= lo) first++;
+        ZHIP(hipMemcpyAsync(h->pin[slot], dev_base + lo, hi - lo, hipMemcpyDeviceToHost, stream));
+        ZHIP(hipEventRecord(h->pin_ev[slot], stream));
+        if (have_prev) { ZHIP(hipEventSynchronize(h->pin_ev[prev.slot])); piece_copy(segs, prev.first, prev.lo, prev.hi, h->pin[prev.slot], false); }
+        prev = Piece{lo, hi, slot, first};
+        have_prev = true;
+    }
+    if (have_prev) { ZHIP(hipEventSynchronize(h->pin_ev[prev.slot])); piece_copy(segs, prev.first, prev.lo, prev.hi, h->pin[prev.slot], false); }
+    return 0;
+}
+
+// bytes of (uncompressed) content per chunk; ZARC_GPU_STAGE_CHUNK overrides it (tests force many small chunks)
+uint64_t stage_chunk()
+{
+    const char *e = getenv("ZARC_GPU_STAGE_CHUNK");
+    const long long v = e ? atoll(e) : 0;
+    return v >= 4096 ? (uint64_t)v : (uint64_t)4 << 30;
+}
+
+struct Chunk { size_t i0, i1; uint64_t in_bytes, out_bytes; };
+
+// cut [0, n) into chunks of about stage_chunk() content bytes (at least one entry each)
+bool stage_threaded() { const char *e = getenv("ZARC_GPU_STAGE_THREAD"); return !(e && atoi(e) == 0); }
+
+std::vector<Chunk> make_chunks(size_t n, const std::vector<uint64_t> &in_sz, const std::vector<uint64_t> &out_sz, const std::vector<uint64_t> &weight)
+{
+    std::vector<Chunk> cs;
+    const uint64_t STAGE_CHUNK = stage_chunk();
+    size_t i = 0;
+    while (i < n) {
+        Chunk c{i, i, 0, 0};
+        uint64_t w = 0;
+        while (c.i1 < n && (c.i1 == c.i0 || w + weight[c.i1] <= STAGE_CHUNK)) { w += weight[c.i1]; c.in_bytes += in_sz[c.i1]; c.out_bytes += out_sz[c.i1]; c.i1++; }
+        cs.push_back(c);
+        i = c.i1;
+    }
+    return cs;
+}
+
+} // namespace
+
 int zarc_gpu_pack_batch(zarc_gpu_t *h, size_t n, const void *const *src, const size_t *src_len, void *dst, size_t dst_cap, size_t *dst_off,
                         size_t *dst_len, uint8_t (*digest)[ZARC_GPU_DIGEST_LEN], int *status)
 {
@@ -613,23 +739,79 @@ int zarc_gpu_pack_batch(zarc_gpu_t *h, size_t n, const void *const *src, const s
     if (rc) return rc;
     if (n == 0) return ZARC_GPU_OK;
     if (!src || !src_len || !dst || !dst_off || !dst_len || !digest) return ZARC_GPU_E_PARAM;
-    std::vector<uint64_t> off, l64, doff(n), dlen(n);
-    if ((rc = stage_in(h, n, src, src_len, off, l64))) return rc;
+    std::vector<uint64_t> in_sz(n), out_sz(n), l64(n);
     uint64_t need = 0;
-    for (size_t i = 0; i < n; i++) need += zarc_gpu_bound(src_len[i]);
-    if (need > dst_cap) return ZARC_GPU_E_DSTSIZE;
-    ZHIP(h->d_arena_out.reserve(need + ZARC_GPU_PAD));
-    rc = zarc_gpu_pack_batch_device(h, n, h->d_arena_in.p, off.data(), l64.data(), h->d_arena_out.p, need, doff.data(), dlen.data(),
-                                    (uint8_t *)digest, status);
-    if (rc) return rc;
-    const float keep[ZARC_GPU_T_COUNT] = {h->ms[0], h->ms[1], h->ms[2], h->ms[3], h->ms[4], h->ms[5], h->ms[6]};
     for (size_t i = 0; i < n; i++) {
-        dst_off[i] = (size_t)doff[i];
-        dst_len[i] = (size_t)dlen[i];
-        ZHIP(hipMemcpyAsync((uint8_t *)dst + doff[i], h->d_arena_out.as<uint8_t>() + doff[i], dlen[i], hipMemcpyDeviceToHost, h->stream));
+        if (src_len[i] && !src[i]) return ZARC_GPU_E_PARAM;
+        l64[i] = src_len[i];
+        in_sz[i] = align_up(src_len[i], ZARC_GPU_ALIGN);
+        out_sz[i] = zarc_gpu_bound(src_len[i]);
+        dst_off[i] = (size_t)need; // the caller's buffer uses the same slot layout as the device arena
+        need += out_sz[i];
     }
-    ZHIP(hipStreamSynchronize(h->stream));
-    for (int i = 0; i < ZARC_GPU_T_COUNT; i++) h->ms[i] = keep[i];
+    if (need > dst_cap) return ZARC_GPU_E_DSTSIZE;
+    const std::vector<Chunk> cs = make_chunks(n, in_sz, out_sz, in_sz);
+    uint64_t max_in = 0, max_out = 0;
+    for (const Chunk &c : cs) { max_in = std::max(max_in, c.in_bytes); max_out = std::max(max_out, c.out_bytes); }
+    const uint64_t in_half = align_up(max_in + ZARC_GPU_PAD + 256, 256), out_half = align_up(max_out + ZARC_GPU_PAD, 256);
+    ZHIP(h->d_arena_in.reserve(2 * in_half));
+    ZHIP(h->d_arena_out.reserve(2 * out_half));
+    uint8_t *const ain = h->d_arena_in.as<uint8_t>(), *const aout = h->d_arena_out.as<uint8_t>();
+    const int device = h->device;
+    hipStream_t side = h->stream2;
+    std::vector<uint64_t> doff(n), dlen(n);
+    auto copy_in = [&](size_t c) -> int { // entries of chunk c -> input half c & 1
+        std::vector<Seg> segs;
+        uint64_t at = 0;
+        for (size_t i = cs[c].i0; i < cs[c].i1; i++) { if (src_len[i]) segs.push_back(Seg{(uint8_t *)src[i], at, src_len[i]}); at += in_sz[i]; }
+        return staged_h2d(h, side, segs, ain + (c & 1) * in_half, at);
+    };
+    auto copy_out = [&](size_t c) -> int { // frames of chunk c (lengths known): packed back to back on the device, then to the caller's slots
+        const size_t m = cs[c].i1 - cs[c].i0, i0 = cs[c].i0;
+        std::vector<uint64_t> dense(m);
+        std::vector<Seg> segs;
+        uint64_t at = 0;
+        for (size_t k = 0; k < m; k++) { dense[k] = at; if (dlen[i0 + k]) segs.push_back(Seg{(uint8_t *)dst + dst_off[i0 + k], at, dlen[i0 + k]}); at += dlen[i0 + k]; }
+        if (h->d_dense.reserve(at + 256) != hipSuccess || h->d_goff.reserve(m * 8) != hipSuccess || h->d_glen.reserve(m * 8) != hipSuccess ||
+            h->d_gdense.reserve(m * 8) != hipSuccess) return ZARC_GPU_E_NOMEM;
+        if (hipMemcpyAsync(h->d_goff.p, doff.data() + i0, m * 8, hipMemcpyHostToDevice, side) != hipSuccess ||
+            hipMemcpyAsync(h->d_glen.p, dlen.data() + i0, m * 8, hipMemcpyHostToDevice, side) != hipSuccess ||
+            hipMemcpyAsync(h->d_gdense.p, dense.data(), m * 8, hipMemcpyHostToDevice, side) != hipSuccess) return ZARC_GPU_E_DEVICE;
+        hipLaunchKernelGGL(zarc_gather, dim3((unsigned)m), dim3(256), 0, side, aout + (c & 1) * out_half, h->d_goff.as<uint64_t>(), h->d_glen.as<uint64_t>(),
+                           h->d_gdense.as<uint64_t>(), (uint32_t)m, h->d_dense.as<uint8_t>());
+        if (hipGetLastError() != hipSuccess) return ZARC_GPU_E_DEVICE;
+        const int r = staged_d2h(h, side, segs, h->d_dense.as<uint8_t>(), at);
+        if (hipStreamSynchronize(side) != hipSuccess) return ZARC_GPU_E_DEVICE; // `dense` is read by an async copy above
+        return r;
+    };
+    float sum[ZARC_GPU_T_COUNT] = {0, 0, 0, 0, 0, 0, 0};
+    if ((rc = copy_in(0))) return rc;
+    ZHIP(hipStreamSynchronize(side));
+    for (size_t c = 0; c < cs.size(); c++) {
+        int helper_rc = 0;
+        auto moves = [&] {
+            (void)hipSetDevice(device);
+            if (c + 1 < cs.size()) helper_rc = copy_in(c + 1);
+            if (!helper_rc && c > 0) helper_rc = copy_out(c - 1);
+            if (hipStreamSynchronize(side) != hipSuccess) helper_rc = ZARC_GPU_E_DEVICE;
+        };
+        std::thread helper;
+        if (stage_threaded()) helper = std::thread(moves); else moves();
+        const size_t m = cs[c].i1 - cs[c].i0, i0 = cs[c].i0;
+        std::vector<uint64_t> off(m);
+        uint64_t at = 0;
+        for (size_t k = 0; k < m; k++) { off[k] = at; at += in_sz[i0 + k]; }
+        rc = zarc_gpu_pack_batch_device(h, m, ain + (c & 1) * in_half, off.data(), l64.data() + i0, aout + (c & 1) * out_half, cs[c].out_bytes, doff.data() + i0,
+                                        dlen.data() + i0, (uint8_t *)digest[i0], status ? status + i0 : nullptr);
+        if (helper.joinable()) helper.join();
+        if (rc) return rc;
+        if (helper_rc) return helper_rc;
+        for (size_t k = 0; k < m; k++) dst_len[i0 + k] = (size_t)dlen[i0 + k];
+        for (int t = 0; t < ZARC_GPU_T_COUNT; t++) sum[t] += h->ms[t] > 0 ? h->ms[t] : 0;
+    }
+    if ((rc = copy_out(cs.size() - 1))) return rc;
+    ZHIP(hipStreamSynchronize(side));
+    for (int t = 0; t < ZARC_GPU_T_COUNT; t++) h->ms[t] = sum[t];
     return ZARC_GPU_OK;
 }
 
@@ -640,33 +822,67 @@ int zarc_gpu_unpack_batch(zarc_gpu_t *h, size_t n, const void *const *frame, con
     if (rc) return rc;
     if (n == 0) return ZARC_GPU_OK;
     if (!frame || !frame_len || !raw_len || !dst || !digest || !status) return ZARC_GPU_E_PARAM;
-    std::vector<uint64_t> foff(n), flen(n), doff(n), rlen(n);
-    uint64_t ftotal = 0, dtotal = 0;
+    std::vector<uint64_t> in_sz(n), out_sz(n), weight(n), flen(n), rlen(n);
     for (size_t i = 0; i < n; i++) {
-        foff[i] = ftotal; flen[i] = frame_len[i]; ftotal += align_up(frame_len[i], ZARC_GPU_ALIGN);
-        doff[i] = dtotal; rlen[i] = raw_len[i]; dtotal += align_up(raw_len[i], ZARC_GPU_ALIGN);
+        if ((frame_len[i] && !frame[i]) || (raw_len[i] && !dst[i])) return ZARC_GPU_E_PARAM;
+        flen[i] = frame_len[i]; rlen[i] = raw_len[i];
+        in_sz[i] = align_up(frame_len[i], ZARC_GPU_ALIGN);
+        out_sz[i] = align_up(raw_len[i], ZARC_GPU_ALIGN);
+        weight[i] = std::max(in_sz[i], out_sz[i]);
     }
-    ZHIP(h->d_arena_in.reserve(ftotal + ZARC_GPU_PAD + 256));
-    ZHIP(h->d_arena_out.reserve(dtotal + ZARC_GPU_PAD + 256));
-    for (size_t i = 0; i < n; i++)
-        if (frame_len[i]) {
-            if (!frame[i]) return ZARC_GPU_E_PARAM;
-            ZHIP(hipMemcpyAsync(h->d_arena_in.as<uint8_t>() + foff[i], frame[i], frame_len[i], hipMemcpyHostToDevice, h->stream));
+    const std::vector<Chunk> cs = make_chunks(n, in_sz, out_sz, weight);
+    uint64_t max_in = 0, max_out = 0;
+    for (const Chunk &c : cs) { max_in = std::max(max_in, c.in_bytes); max_out = std::max(max_out, c.out_bytes); }
+    const uint64_t in_half = align_up(max_in + ZARC_GPU_PAD + 256, 256), out_half = align_up(max_out + ZARC_GPU_PAD + 256, 256);
+    ZHIP(h->d_arena_in.reserve(2 * in_half));
+    ZHIP(h->d_arena_out.reserve(2 * out_half));
+    uint8_t *const ain = h->d_arena_in.as<uint8_t>(), *const aout = h->d_arena_out.as<uint8_t>();
+    const int device = h->device;
+    hipStream_t side = h->stream2;
+    auto copy_in = [&](size_t c) -> int {
+        std::vector<Seg> segs;
+        uint64_t at = 0;
+        for (size_t i = cs[c].i0; i < cs[c].i1; i++) { if (frame_len[i]) segs.push_back(Seg{(uint8_t *)frame[i], at, frame_len[i]}); at += in_sz[i]; }
+        return staged_h2d(h, side, segs, ain + (c & 1) * in_half, at);
+    };
+    auto copy_out = [&](size_t c) -> int {
+        std::vector<Seg> segs;
+        uint64_t at = 0;
+        for (size_t i = cs[c].i0; i < cs[c].i1; i++) {
+            // like the reference, bytes are delivered unless the frame itself failed to decode
+            const bool decoded = status[i] == ZARC_GPU_FRAME_OK || status[i] == ZARC_GPU_FRAME_DIGEST || status[i] == ZARC_GPU_FRAME_CHECKSUM;
+            if (decoded && raw_len[i]) segs.push_back(Seg{(uint8_t *)dst[i], at, raw_len[i]});
+            at += out_sz[i];
         }
-    rc = zarc_gpu_unpack_batch_device(h, n, h->d_arena_in.p, foff.data(), flen.data(), h->d_arena_out.p, doff.data(), rlen.data(),
-                                      (const uint8_t *)expect, (uint8_t *)digest, status);
-    if (rc) return rc;
-    const float keep[ZARC_GPU_T_COUNT] = {h->ms[0], h->ms[1], h->ms[2], h->ms[3], h->ms[4], h->ms[5], h->ms[6]};
-    for (size_t i = 0; i < n; i++) {
-        // like the reference, bytes are delivered unless the frame itself failed to decode
-        const bool decoded = status[i] == ZARC_GPU_FRAME_OK || status[i] == ZARC_GPU_FRAME_DIGEST || status[i] == ZARC_GPU_FRAME_CHECKSUM;
-        if (decoded && raw_len[i]) {
-            if (!dst[i]) return ZARC_GPU_E_PARAM;
-            ZHIP(hipMemcpyAsync(dst[i], h->d_arena_out.as<uint8_t>() + doff[i], raw_len[i], hipMemcpyDeviceToHost, h->stream));
-        }
+        return staged_d2h(h, side, segs, aout + (c & 1) * out_half, at);
+    };
+    float sum[ZARC_GPU_T_COUNT] = {0, 0, 0, 0, 0, 0, 0};
+    if ((rc = copy_in(0))) return rc;
+    ZHIP(hipStreamSynchronize(side));
+    for (size_t c = 0; c < cs.size(); c++) {
+        int helper_rc = 0;
+        auto moves = [&] {
+            (void)hipSetDevice(device);
+            if (c + 1 < cs.size()) helper_rc = copy_in(c + 1);
+            if (!helper_rc && c > 0) helper_rc = copy_out(c - 1);
+            if (hipStreamSynchronize(side) != hipSuccess) helper_rc = ZARC_GPU_E_DEVICE;
+        };
+        std::thread helper;
+        if (stage_threaded()) helper = std::thread(moves); else moves();
+        const size_t m = cs[c].i1 - cs[c].i0, i0 = cs[c].i0;
+        std::vector<uint64_t> foff(m), doff(m);
+        uint64_t fa = 0, da = 0;
+        for (size_t k = 0; k < m; k++) { foff[k] = fa; fa += in_sz[i0 + k]; doff[k] = da; da += out_sz[i0 + k]; }
+        rc = zarc_gpu_unpack_batch_device(h, m, ain + (c & 1) * in_half, foff.data(), flen.data() + i0, aout + (c & 1) * out_half, doff.data(), rlen.data() + i0,
+                                          expect ? (const uint8_t *)expect[i0] : nullptr, (uint8_t *)digest[i0], status + i0);
+        if (helper.joinable()) helper.join();
+        if (rc) return rc;
+        if (helper_rc) return helper_rc;
+        for (int t = 0; t < ZARC_GPU_T_COUNT; t++) sum[t] += h->ms[t] > 0 ? h->ms[t] : 0;
     }
-    ZHIP(hipStreamSynchronize(h->stream));
-    for (int i = 0; i < ZARC_GPU_T_COUNT; i++) h->ms[i] = keep[i];
+    if ((rc = copy_out(cs.size() - 1))) return rc;
+    ZHIP(hipStreamSynchronize(side));
+    for (int t = 0; t < ZARC_GPU_T_COUNT; t++) h->ms[t] = sum[t];
     return ZARC_GPU_OK;
 }
 

@@ -71,6 +71,7 @@ __global__ void zarc_zstd_decode(const uint8_t *frames_base, const uint64_t *fra
                                  const uint32_t *fast /* per frame: sequences are pre-decoded; may be null */, const uint64_t *slot_prefix,
                                  const ZdecBlock *zblocks, const uint64_t *seq_index, const uint64_t *seqs, const uint64_t *lit_index,
                                  const uint8_t *lits);
+__global__ void zarc_gather(const uint8_t *src_base, const uint64_t *src_off, const uint64_t *len, const uint64_t *dense_off, uint32_t n, uint8_t *dst);
 __global__ void zarc_zge_store(const uint8_t *src_base, const uint64_t *src_off, const uint64_t *src_len, uint32_t n_frames, uint8_t *dst_base,
                                const uint64_t *dst_off, uint64_t *dst_len);
 // decoder fast path, stage 1: one LANE per frame walks the block headers (no payload is touched) -> block slots, nseq[], fast[]

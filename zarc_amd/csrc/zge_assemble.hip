@@ -70,6 +70,19 @@ __global__ void __launch_bounds__(256) zarc_zge_assemble(ZgeParams P, const uint
     if (tid == 0) dst_len[f] = pos;
 }
 
+// Dense copy of n scattered byte ranges (frames in their worst-case slots -> back to back), so that the host-pointer
+// entry points move only real bytes over PCIe.  One workgroup per range.
+__global__ void __launch_bounds__(256) zarc_gather(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off, const uint64_t *__restrict__ len,
+                                                   const uint64_t *__restrict__ dense_off, uint32_t n, uint8_t *__restrict__ dst)
+{
+    const uint32_t i = blockIdx.x;
+    if (i >= n) return;
+    const uint8_t *s = src_base + src_off[i];
+    uint8_t *d = dst + dense_off[i];
+    const uint64_t l = len[i];
+    for (uint64_t k = threadIdx.x; k < l; k += blockDim.x) d[k] = s[k];
+}
+
 // Store mode (Encoder::enable_compression(false), crates/zarc/src/encode.rs:95-97 -> write_uncompressed_frame,
 // encode/lowlevel_frames.rs:47-84): the content goes into Raw blocks.  Like the reference's frame this one carries an
 // 8-byte Frame_Content_Size, no Single_Segment flag and no checksum -- but it also carries the Window_Descriptor that
