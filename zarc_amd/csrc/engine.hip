@@ -586,36 +586,6 @@ int zarc_gpu_unpack_batch_device(zarc_gpu_t *h, size_t n, const void *d_frames_b
 }
 
 // ---- host-memory entry points: stage through engine-owned arenas -----------------------------------
-static int stage_in(zarc_gpu *h, size_t n, const void *const *src, const size_t *len, std::vector<uint64_t> &off, std::vector<uint64_t> &l64)
-{
-    off.resize(n);
-    l64.resize(n);
-    uint64_t total = 0;
-    for (size_t i = 0; i < n; i++) {
-        off[i] = total;
-        l64[i] = len[i];
-        total += align_up(len[i], ZARC_GPU_ALIGN);
-    }
-    ZHIP(h->d_arena_in.reserve(total + ZARC_GPU_PAD + 256));
-    for (size_t i = 0; i < n; i++)
-        if (len[i]) {
-            if (!src[i]) return ZARC_GPU_E_PARAM;
-            ZHIP(hipMemcpyAsync(h->d_arena_in.as<uint8_t>() + off[i], src[i], len[i], hipMemcpyHostToDevice, h->stream));
-        }
-    return 0;
-}
-
-int zarc_gpu_blake3_batch(zarc_gpu_t *h, size_t n, const void *const *src, const size_t *len, uint8_t (*digest)[ZARC_GPU_DIGEST_LEN])
-{
-    int rc = check_common(h, n);
-    if (rc) return rc;
-    if (n == 0) return ZARC_GPU_OK;
-    if (!src || !len || !digest) return ZARC_GPU_E_PARAM;
-    std::vector<uint64_t> off, l64;
-    if ((rc = stage_in(h, n, src, len, off, l64))) return rc;
-    return zarc_gpu_blake3_batch_device(h, n, h->d_arena_in.p, off.data(), l64.data(), (uint8_t *)digest);
-}
-
 // ---- host-pointer entry points: chunked, with the PCIe copies of neighbouring chunks overlapped -----------------------
 // The caller's buffers are ordinary pageable memory, so hipMemcpyAsync blocks the calling thread while it stages the
 // bytes.  A helper thread therefore moves chunk c+1 in and chunk c-1 out (side stream) while this thread runs the
@@ -731,6 +701,26 @@ std::vector<Chunk> make_chunks(size_t n, const std::vector<uint64_t> &in_sz, con
 }
 
 } // namespace
+
+int zarc_gpu_blake3_batch(zarc_gpu_t *h, size_t n, const void *const *src, const size_t *len, uint8_t (*digest)[ZARC_GPU_DIGEST_LEN])
+{
+    int rc = check_common(h, n);
+    if (rc) return rc;
+    if (n == 0) return ZARC_GPU_OK;
+    if (!src || !len || !digest) return ZARC_GPU_E_PARAM;
+    std::vector<uint64_t> off(n), l64(n);
+    std::vector<Seg> segs;
+    uint64_t total = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (len[i] && !src[i]) return ZARC_GPU_E_PARAM;
+        off[i] = total; l64[i] = len[i];
+        if (len[i]) segs.push_back(Seg{(uint8_t *)src[i], total, len[i]});
+        total += align_up(len[i], ZARC_GPU_ALIGN);
+    }
+    ZHIP(h->d_arena_in.reserve(total + ZARC_GPU_PAD + 256));
+    if ((rc = staged_h2d(h, h->stream, segs, h->d_arena_in.as<uint8_t>(), total))) return rc;
+    return zarc_gpu_blake3_batch_device(h, n, h->d_arena_in.p, off.data(), l64.data(), (uint8_t *)digest);
+}
 
 int zarc_gpu_pack_batch(zarc_gpu_t *h, size_t n, const void *const *src, const size_t *src_len, void *dst, size_t dst_cap, size_t *dst_off,
                         size_t *dst_len, uint8_t (*digest)[ZARC_GPU_DIGEST_LEN], int *status)

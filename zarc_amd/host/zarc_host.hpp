@@ -4,7 +4,7 @@
 // meaning and error behaviour follow the reference:
 //
 //   zarc::Encoder            crates/zarc/src/encode.rs:27-97 (struct + new/set_zstd_parameter/enable_compression)
-//   Encoder::add_data_frame  crates/zarc/src/encode/content_frame.rs:20-60 (hash -> dedup -> compress -> Frame record)
+//   Encoder::add_data_frame  crates/zarc/src/encode/content_frame.rs:20-60 (hash + compress -> dedup -> Frame record)
 //   zarc::Frame              crates/zarc/src/directory/frame.rs:10-32
 //   zarc::Digest             crates/zarc/src/integrity.rs:14-36 (constant-time equality :17-22)
 //   zarc::FrameReader        crates/zarc/src/decode/frame_iterator.rs:14-104 (read_content_frame + verify)
@@ -99,41 +99,33 @@ class Encoder {
     }
 
     // Batched add_data_frame: returns the digest of every entry in call order.
+    // The reference hashes first and skips compression of known content (content_frame.rs:26-33).  Over PCIe a separate
+    // hashing pass would move every byte twice, so the batch is packed in one pass (the engine returns digest AND frame)
+    // and duplicates are dropped afterwards: same archive bytes, some wasted compression when content repeats (SURVEY
+    // quirk 6 names both orders).
     std::vector<Digest> add_data_frames(const void *const *content, const size_t *len, size_t n)
     {
         std::vector<Digest> digests(n);
         if (n == 0) return digests;
-        // 1. content hashes first: the digest must be known before compression for dedup (content_frame.rs:26-33)
-        engine_.check(zarc_gpu_blake3_batch(engine_.get(), n, content, len, (uint8_t(*)[32])digests.data()));
-        // 2. first occurrence wins -- against frames already written and inside this batch
-        std::vector<size_t> uniq;
-        std::map<Digest, size_t> seen;
-        for (size_t i = 0; i < n; i++) {
-            if (frames_.count(digests[i]) || seen.count(digests[i])) continue; // "frame already exists, skipping"
-            seen.emplace(digests[i], i);
-            uniq.push_back(i);
-        }
-        if (uniq.empty()) return digests;
-        // 3. one fresh session per frame (reset(SessionOnly), content_frame.rs:37-39) == one independent frame each
-        std::vector<const void *> src(uniq.size());
-        std::vector<size_t> slen(uniq.size()), doff(uniq.size()), dlen(uniq.size());
+        // 1. one fresh session per frame (reset(SessionOnly), content_frame.rs:37-39) == one independent frame each
+        std::vector<size_t> doff(n), dlen(n);
         size_t cap = 0;
-        for (size_t k = 0; k < uniq.size(); k++) { src[k] = content[uniq[k]]; slen[k] = len[uniq[k]]; cap += zarc_gpu_bound(slen[k]); }
+        for (size_t k = 0; k < n; k++) cap += zarc_gpu_bound(len[k]);
         std::vector<uint8_t> buffer(cap);
-        std::vector<Digest> d2(uniq.size());
-        std::vector<int> status(uniq.size());
-        engine_.check(zarc_gpu_pack_batch(engine_.get(), uniq.size(), src.data(), slen.data(), buffer.data(), cap, doff.data(), dlen.data(),
-                                          (uint8_t(*)[32])d2.data(), status.data()));
-        // 4. append in call order; offset/length bookkeeping as content_frame.rs:22,45-57
-        for (size_t k = 0; k < uniq.size(); k++) {
+        std::vector<int> status(n);
+        engine_.check(zarc_gpu_pack_batch(engine_.get(), n, content, len, buffer.data(), cap, doff.data(), dlen.data(), (uint8_t(*)[32])digests.data(),
+                                          status.data()));
+        // 2. append in call order; first occurrence wins -- against frames already written and inside this batch -- later
+        //    duplicates write nothing; offset/length bookkeeping as content_frame.rs:22,45-57
+        for (size_t k = 0; k < n; k++) {
             if (status[k] != ZARC_GPU_FRAME_OK) throw Error(status[k], zarc_gpu_frame_status_name(status[k]));
-            if (!(d2[k] == digests[uniq[k]])) throw Error(ZARC_GPU_E_DEVICE, "digest mismatch between hash and pack passes");
+            if (frames_.count(digests[k])) continue; // "frame already exists, skipping"
             Frame f;
             f.edition = edition_;
             f.offset = offset_;
-            f.digest = d2[k];
+            f.digest = digests[k];
             f.length = dlen[k];
-            f.uncompressed = slen[k];
+            f.uncompressed = len[k];
             writer_.write((const char *)buffer.data() + doff[k], (std::streamsize)dlen[k]);
             if (!writer_) throw Error(ZARC_GPU_E_DEVICE, "write failed");
             offset_ += dlen[k];
