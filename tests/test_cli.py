@@ -1,0 +1,116 @@
+"""SURVEY.md section 8 rows f2 + f3: the `zarc pack | unpack | list-files` command line over the engine
+(zarc_amd/host/zarc_cli.cpp), driven the way crates/zarc-cli is: a directory tree goes in, a `.zarc` comes out, the
+tree comes back with contents, modes and timestamps.  The archive is also re-read by the independent python parser of
+test_container.py and decoded as one Zstandard stream by every libzstd on the box."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from test_container import parse_archive
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def make_tree(base, corpus):
+    src = base / "src"
+    (src / "sub" / "deep").mkdir(parents=True)
+    files = {
+        "a.txt": corpus.entry(900, 12000, 0),
+        "b.bin": corpus.entry(901, 70000, 3),
+        "empty": b"",
+        "sub/c.txt": corpus.entry(900, 12000, 0),          # same content as a.txt: one frame
+        "sub/deep/d.rec": corpus.entry(902, 300000, 1),
+    }
+    for name, data in files.items():
+        p = src / name
+        p.write_bytes(data)
+        os.chmod(p, 0o640)
+        os.utime(p, ns=(1_600_000_000_123_456_000, 1_650_000_000_654_321_000))
+    os.symlink("../a.txt", src / "sub" / "link")
+    os.chmod(src / "sub", 0o750)
+    return files
+
+
+def run_cli(binary, tmp_path, corpus, oracle, libzstds, store=False):
+    files = make_tree(tmp_path, corpus)
+    arc = tmp_path / ("out-store.zarc" if store else "out.zarc")
+    cmd = [binary, "pack", "--output", str(arc), "--level", "3", "--zstd", "ChecksumFlag=true"] + (["--store"] if store else []) + ["src"]
+    out = subprocess.run(cmd, cwd=tmp_path, capture_output=True, timeout=900, check=True)
+    m = re.fullmatch(rb"digest: ([A-Za-z0-9+/]{43}=)\n", out.stdout)
+    assert m, out.stdout
+    digest = m.group(1).decode()
+    img = arc.read_bytes()
+
+    # --- the archive, read independently ---
+    def dec(frame, raw_len):
+        st, o, _ = oracle.zstd_decode(frame, raw_len)
+        assert st == 0
+        return o
+    a = parse_archive(img, dec, oracle.blake3)
+    import base64
+    assert base64.b64encode(img[-54:-22]).decode() == digest
+    names = ["/".join(c if isinstance(c, str) else c.decode() for c in f[1]) for f in a["files"]]
+    assert names == sorted(["src", "src/a.txt", "src/b.bin", "src/empty", "src/sub", "src/sub/c.txt", "src/sub/deep", "src/sub/deep/d.rec", "src/sub/link"],
+                           key=lambda n: n.split("/"))
+    by_name = dict(zip(names, a["files"]))
+    assert by_name["src/a.txt"][2] == by_name["src/sub/c.txt"][2] == oracle.blake3(files["a.txt"])
+    assert len(a["frames"]) == 4                                                  # a(=c), b, empty, d
+    assert by_name["src/sub"][7] == [1] and by_name["src/sub/link"][7] == [10, "../a.txt"] and 2 not in by_name["src/sub/link"]
+    assert by_name["src/a.txt"][3] & 0o7777 == 0o640 and by_name["src/sub"][3] & 0o7777 == 0o750
+    assert by_name["src/a.txt"][6][2] == ("tag", 0, "2022-04-15T05:20:00.654321+00:00")   # modified
+    assert by_name["src/a.txt"][6][3] == ("tag", 0, "2020-09-13T12:26:40.123456+00:00")   # accessed
+    assert by_name["src/a.txt"][4][0] == os.getuid() and by_name["src/a.txt"][5][0] == os.getgid()
+    total_raw = sum(f[4] for f in a["frames"])
+    for z in libzstds:                                                            # `zstd --test` equivalent
+        o, err = z.decompress(img, total_raw + len(a["directory"]))
+        assert err is None, (z.version, err)
+    if store:
+        assert all(f[3] == 14 + f[4] + 3 * max(1, -(-f[4] // 131072)) for f in a["frames"])
+
+    # --- list-files ---
+    out = subprocess.run([binary, "list-files", str(arc)], capture_output=True, timeout=600, check=True)
+    assert out.stdout.decode().splitlines() == [n + ("/" if n in ("src", "src/sub", "src/sub/deep") else "@" if n.endswith("link") else "") for n in names]
+    out = subprocess.run([binary, "list", str(arc), "--only-files", "--filter", r"\.txt$"], capture_output=True, timeout=600, check=True)
+    assert out.stdout.decode().splitlines() == ["src/a.txt", "src/sub/c.txt"]
+
+    # --- unpack ---
+    dest = tmp_path / ("dest-store" if store else "dest")
+    dest.mkdir()
+    out = subprocess.run([binary, "unpack", str(arc)], cwd=dest, capture_output=True, timeout=900, check=True)
+    assert ("digest: %s\n" % digest).encode() in out.stderr and b"unpacked 5 files" in out.stderr
+    for name, data in files.items():
+        p = dest / "src" / name
+        assert p.read_bytes() == data, name
+        st = p.stat()
+        assert st.st_mode & 0o7777 == 0o640 and st.st_mtime_ns == 1_650_000_000_654_321_000
+    assert (dest / "src" / "sub").stat().st_mode & 0o7777 == 0o750
+    assert not os.path.lexists(dest / "src" / "sub" / "link")                     # like the reference: links are listed, not recreated
+    # --verify
+    ok = subprocess.run([binary, "unpack", str(arc), "--verify", digest, "--filter", "b.bin"], cwd=dest, capture_output=True, timeout=600)
+    assert ok.returncode == 0 and b"unpacked 1 files" in ok.stderr and b"digest:" not in ok.stderr
+    bad = subprocess.run([binary, "unpack", str(arc), "--verify", "A" * 43 + "="], cwd=dest, capture_output=True, timeout=600)
+    assert bad.returncode == 1 and b"integrity failure: zarc file digest is " + digest.encode() in bad.stderr
+    # a damaged archive is refused
+    broken = bytearray(img); broken[-5] ^= 1
+    (tmp_path / "broken.zarc").write_bytes(bytes(broken))
+    bad = subprocess.run([binary, "list-files", str(tmp_path / "broken.zarc")], capture_output=True, timeout=600)
+    assert bad.returncode == 1 and b"check byte" in bad.stderr
+
+
+def test_cli_emulated(emu_lib_path, tmp_path, corpus, oracle, libzstds):
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu"), "host"])
+    binary = os.path.join(ROOT, "tests", "emu", "_build", "zarc")
+    run_cli(binary, tmp_path, corpus, oracle, libzstds)
+    (tmp_path / "s").mkdir()
+    run_cli(binary, tmp_path / "s", corpus, oracle, libzstds, store=True)
+
+
+@pytest.mark.gpu
+def test_cli_gpu(tmp_path, corpus, oracle, libzstds):
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "zarc_amd", "csrc"), "host"])
+    binary = os.path.join(ROOT, "zarc_amd", "zarc")
+    run_cli(binary, tmp_path, corpus, oracle, libzstds)
+    (tmp_path / "s").mkdir()
+    run_cli(binary, tmp_path / "s", corpus, oracle, libzstds, store=True)

@@ -146,8 +146,14 @@ struct File { // directory/file.rs:16-62 (fields this host mirror carries; the r
     std::optional<Digest> digest;
     std::optional<uint32_t> mode;
     std::optional<Timestamp> created, modified, accessed;
-    std::optional<uint8_t> special_kind; // 1 = directory (specials.rs:36-61)
+    std::optional<uint8_t> special_kind; // 1 = directory, 10..13 symlinks, 20..22 hardlinks (specials.rs:36-61)
+    std::optional<std::string> link_target; // LinkTarget::FullPath (specials.rs:158-186); text when valid UTF-8, bytes otherwise
+    struct Owner { std::optional<uint64_t> id; std::optional<std::string> name; }; // PosixOwner (posix_owner.rs:17-21)
+    std::optional<Owner> user, group;
     bool is_normal() const { return digest.has_value() && !special_kind.has_value(); }
+    bool is_dir() const { return special_kind.has_value() && *special_kind == 1; }
+    bool is_symlink() const { return special_kind.has_value() && *special_kind >= 10 && *special_kind <= 13; }
+    bool is_hardlink() const { return special_kind.has_value() && *special_kind >= 20 && *special_kind <= 22; }
 };
 
 // BTreeMap<Pathname, _> order: component-wise, Text before Binary, then bytewise (strings.rs:8-13,57-62)
@@ -181,12 +187,20 @@ inline void encode_edition(CborWriter &w, const Edition &e) // {0: number, 1: wr
 inline void encode_file(CborWriter &w, const File &f)
 {
     const bool ts = f.created || f.modified || f.accessed;
-    w.map(2 + (f.digest ? 1 : 0) + (f.mode ? 1 : 0) + (ts ? 1 : 0) + (f.special_kind ? 1 : 0));
+    w.map(2 + (f.digest ? 1 : 0) + (f.mode ? 1 : 0) + (f.user ? 1 : 0) + (f.group ? 1 : 0) + (ts ? 1 : 0) + (f.special_kind ? 1 : 0));
     w.uint(0); w.uint(f.edition);
     w.uint(1); w.array(f.name.size());
     for (const auto &c : f.name) { if (valid_utf8(c)) w.text(c); else w.bytes((const uint8_t *)c.data(), c.size()); }
     if (f.digest) { w.uint(2); w.bytes(f.digest->bytes.data(), 32); }
     if (f.mode) { w.uint(3); w.uint(*f.mode); }
+    for (int which = 0; which < 2; which++) { // PosixOwner: array of the fields that are present (posix_owner.rs:181-203)
+        const auto &o = which == 0 ? f.user : f.group;
+        if (!o) continue;
+        w.uint(4 + (uint64_t)which);
+        w.array((o->id ? 1 : 0) + (o->name ? 1 : 0));
+        if (o->id) w.uint(*o->id);
+        if (o->name) w.text(*o->name);
+    }
     if (ts) {
         w.uint(6);
         w.map((f.created ? 1 : 0) + (f.modified ? 1 : 0) + (f.accessed ? 1 : 0));
@@ -194,7 +208,12 @@ inline void encode_file(CborWriter &w, const File &f)
         if (f.modified) { w.uint(2); encode_timestamp(w, *f.modified); }
         if (f.accessed) { w.uint(3); encode_timestamp(w, *f.accessed); }
     }
-    if (f.special_kind) { w.uint(7); w.array(1); w.uint(*f.special_kind); } // [kind]; trailing None (target) dropped
+    if (f.special_kind) { // SpecialFile [kind, link_target]; a trailing None is dropped
+        w.uint(7);
+        w.array(f.link_target ? 2 : 1);
+        w.uint(*f.special_kind);
+        if (f.link_target) { if (valid_utf8(*f.link_target)) w.text(*f.link_target); else w.bytes((const uint8_t *)f.link_target->data(), f.link_target->size()); }
+    }
 }
 
 inline void append_element(std::vector<uint8_t> &dir, uint8_t kind, const CborWriter &payload) // elements.rs:10-25
@@ -426,7 +445,16 @@ class ArchiveReader {
                 }
             } else if (k == 2) { auto b = r.bytes(); if (b.size() != 32) throw Error(ZARC_GPU_E_PARAM, "digest length"); Digest d; std::memcpy(d.bytes.data(), b.data(), 32); f.digest = d; }
             else if (k == 3) f.mode = (uint32_t)r.uint();
-            else if (k == 6) {
+            else if (k == 4 || k == 5) {
+                File::Owner o;
+                const uint64_t c = r.head(4);
+                for (uint64_t j = 0; j < c; j++) {
+                    if (r.major() == 0) o.id = r.uint();
+                    else if (r.major() == 3) o.name = r.text();
+                    else r.skip();
+                }
+                (k == 4 ? f.user : f.group) = o;
+            } else if (k == 6) {
                 const uint64_t m = r.head(5);
                 for (uint64_t j = 0; j < m; j++) {
                     const uint64_t tk = r.uint();
@@ -437,7 +465,9 @@ class ArchiveReader {
                 const uint64_t c = r.head(4);
                 for (uint64_t j = 0; j < c; j++) {
                     if (j == 0 && !r.is_null()) f.special_kind = (uint8_t)r.uint();
-                    else r.skip();
+                    else if (j == 1 && r.major() == 3) f.link_target = r.text();
+                    else if (j == 1 && r.major() == 2) { auto b = r.bytes(); f.link_target = std::string((const char *)b.data(), b.size()); }
+                    else r.skip(); // component-array targets are what the reference cannot read back either (specials.rs:193-196)
                 }
             } else r.skip();
         }
