@@ -543,7 +543,12 @@ int zarc_gpu_unpack_batch_device(zarc_gpu_t *h, size_t n, const void *d_frames_b
             ZHIP(hipGetLastError());
         }
         if (total) {
-            hipLaunchKernelGGL(zarc_zdec_seqs, dim3((unsigned)((nslots + 63) / 64)), dim3(64), 0, h->stream, (const uint8_t *)d_frames_base, h->d_frame_off.as<uint64_t>(),
+            // Each lane is a long serial chain (about one L2/HBM round trip and 340 instructions per sequence).  Partly filled
+            // waves (more waves to interleave) were measured and are slower: 35 ms with 64 lanes per wave, 54 ms with 16
+            // (ZARC_GPU_SEQ_LANES reproduces it) -- the waves' own instruction issue dominates, not exposed waits.
+            int seq_lanes = getenv("ZARC_GPU_SEQ_LANES") ? atoi(getenv("ZARC_GPU_SEQ_LANES")) : 64;
+            if (seq_lanes != 8 && seq_lanes != 16 && seq_lanes != 32 && seq_lanes != 64) seq_lanes = 64;
+            hipLaunchKernelGGL(zarc_zdec_seqs, dim3((unsigned)((nslots + seq_lanes - 1) / seq_lanes)), dim3(seq_lanes), 0, h->stream, (const uint8_t *)d_frames_base, h->d_frame_off.as<uint64_t>(),
                                (uint64_t)nslots, h->d_slot_prefix.as<uint64_t>(), h->d_zblocks.as<ZdecBlock>(), h->d_seqidx.as<uint64_t>(), h->d_seqs.as<uint64_t>(),
                                h->d_ztables.as<uint16_t>(), h->d_fast.as<uint32_t>());
             ZHIP(hipGetLastError());

@@ -1011,7 +1011,7 @@ __global__ void __launch_bounds__(64) zarc_zdec_seqs(const uint8_t *__restrict__
                                                      const uint64_t *__restrict__ seq_index, uint64_t *__restrict__ seqs, uint16_t *__restrict__ tables,
                                                      uint32_t *__restrict__ fast)
 {
-    const uint64_t s = (uint64_t)blockIdx.x * 64u + threadIdx.x;
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; // the engine launches partly filled waves (see engine.hip)
     if (s >= n_slots) return;
     const ZdecBlock zb = zblocks[s];
     if (zb.type != 2 || zb.nseq == 0) return;
