@@ -44,3 +44,10 @@ def test_emu_host_staging_in_chunks(emu_engine, oracle, corpus, golden_frames, m
     pc.check_roundtrip(emu_engine, oracle, corpus, big=False)
     pc.check_unpack_errors(emu_engine, oracle, corpus, golden_frames)
     pc.check_store(emu_engine, oracle, corpus, [])
+
+
+def test_emu_pack_in_sub_batches(emu_engine, oracle, corpus, libzstds, monkeypatch):
+    """A batch whose encoder scratch does not fit the budget is packed in several sub-batches (scratch reused between them):
+    frames must not change."""
+    monkeypatch.setenv("ZARC_GPU_SCRATCH_MB", "1")
+    pc.check_pack(emu_engine, oracle, corpus, libzstds, big=False)

@@ -153,3 +153,10 @@ def test_gpu_host_staging_in_chunks(engine, oracle, corpus, golden_frames, libzs
     pc.check_unpack_errors(engine, oracle, corpus, golden_frames)
     pc.check_store(engine, oracle, corpus, libzstds)
     pc.check_pack(engine, oracle, corpus, libzstds, big=True)
+
+
+def test_gpu_pack_in_sub_batches(engine, oracle, corpus, libzstds, monkeypatch):
+    """Encoder scratch budget of 2 MiB: every few blocks form their own sub-batch (scratch reuse, per-sub-batch queues)."""
+    monkeypatch.setenv("ZARC_GPU_SCRATCH_MB", "2")
+    pc.check_pack(engine, oracle, corpus, libzstds, big=True)
+    pc.check_roundtrip(engine, oracle, corpus, big=True)

@@ -389,6 +389,7 @@ int zarc_gpu_pack_batch_device(zarc_gpu_t *h, size_t n, const void *d_src_base, 
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return src_len[a] > src_len[b]; });
     const size_t per_block = (size_t)ZARC_MAX_SEQ * 8 + (ZARC_BLOCK + 64) + (ZARC_BLOCK + 1024) + sizeof(ZgeBlock);
     size_t budget = h->scratch_budget;
+    if (const char *e = getenv("ZARC_GPU_SCRATCH_MB")) budget = (size_t)std::max(1, atoi(e)) << 20; // tests force several sub-batches
     if (!budget) {
         // up to 64 GiB of scratch (BASELINE configs[1] needs 46 GiB to run as ONE launch per kernel), at most 45 % of what is free
         size_t free_b = 0, total_b = 0;
