@@ -160,18 +160,22 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
         if (bs > 0 && (bs & seg_mask) == 0) { // new 2^seg_log segment (a multiple of the block size): table positions restart
             for (int i = tid; i < (1 << TAB_LOG); i += THREADS) { L.tl[i] = 0; L.ts[i] = 0; }
         }
-        // ---- RLE block detection: every byte equals the first one (8 bytes per load; blocks start 16-byte aligned) ----
+        // ---- RLE block detection: every byte equals the first one (8 bytes per load; blocks start 16-byte aligned).  Nearly
+        // every block is cleared by a look at its first KiB; only a block that passes that look is read in full here, so the
+        // input is not fetched twice ----
         if (tid == 0) { L.ctrl[K_FLAG] = 0; L.ctrl[K_POS] = 0; L.ctrl[K_REP0] = 0; L.ctrl[K_REP1] = 0; }
         zd::lds_barrier();
-        {
+        const uint8_t first = blen ? src[bs] : 0;
+        const uint64_t pat = 0x0101010101010101ull * first;
+        const uint64_t *w = (const uint64_t *)(src + bs);
+        if (blen >= 1024 && tid < 128 && w[tid] != pat) L.ctrl[K_FLAG] = 1; // benign race: every writer stores 1
+        zd::lds_barrier();
+        if (L.ctrl[K_FLAG] == 0) {
             bool diff = false;
-            const uint8_t first = blen ? src[bs] : 0;
-            const uint64_t pat = 0x0101010101010101ull * first;
-            const uint64_t *w = (const uint64_t *)(src + bs);
             const uint32_t nw = blen / 8;
             for (uint32_t i = (uint32_t)tid; i < nw; i += THREADS) diff |= w[i] != pat;
             for (uint32_t i = nw * 8 + (uint32_t)tid; i < blen; i += THREADS) diff |= src[bs + i] != first;
-            if (diff) L.ctrl[K_FLAG] = 1; // benign race: every writer stores 1
+            if (diff) L.ctrl[K_FLAG] = 1;
         }
         zd::lds_barrier();
         const bool all_same = L.ctrl[K_FLAG] == 0;
