@@ -234,9 +234,17 @@ __device__ int fse_read_desc(const uint8_t *src, uint32_t len, int max_al, int m
 
 // About 7.5 KiB per wave.  The table-construction scratch (weights, normalised counts)
 // and the per-batch sequence buffer are never live at the same time and share storage.
+constexpr uint32_t OBUF = 6144; // bytes of batch output staged in LDS on the fast path
 struct Lds {
-    uint16_t huf[2048];   // sym | nbits << 8
-    uint16_t ll[512], ml[512], of[256];
+    union {
+        struct {
+            uint16_t huf[2048];   // sym | nbits << 8
+            uint16_t ll[512], ml[512], of[256];
+        };
+        // Frames whose sequences and literals were decoded ahead need none of the tables: the same storage stages the output
+        // of a batch of sequences, so near matches resolve at LDS speed and HBM sees whole lines
+        alignas(16) uint8_t obuf[OBUF + 80];
+    };
     union {
         struct {
             uint8_t weights[256];
@@ -266,6 +274,28 @@ __device__ __forceinline__ void lane_copy32(uint8_t *d, const uint8_t *s, uint32
         B16 x, y;
         __builtin_memcpy(&x, s, 16); __builtin_memcpy(&y, s + n - 16, 16);
         __builtin_memcpy(d, &x, 16); __builtin_memcpy(d + n - 16, &y, 16);
+    } else if (n >= 8) {
+        uint64_t x, y;
+        __builtin_memcpy(&x, s, 8); __builtin_memcpy(&y, s + n - 8, 8);
+        __builtin_memcpy(d, &x, 8); __builtin_memcpy(d + n - 8, &y, 8);
+    } else if (n >= 4) {
+        uint32_t x, y;
+        __builtin_memcpy(&x, s, 4); __builtin_memcpy(&y, s + n - 4, 4);
+        __builtin_memcpy(d, &x, 4); __builtin_memcpy(d + n - 4, &y, 4);
+    } else if (n >= 2) {
+        uint16_t x, y;
+        __builtin_memcpy(&x, s, 2); __builtin_memcpy(&y, s + n - 2, 2);
+        __builtin_memcpy(d, &x, 2); __builtin_memcpy(d + n - 2, &y, 2);
+    } else if (n == 1) d[0] = s[0];
+}
+
+// Same shape for global -> LDS (8-byte pieces: unaligned ds_write_b64 is native, b128 is not)
+__device__ __forceinline__ void lane_stage32(uint8_t *d, const uint8_t *s, uint32_t n)
+{
+    if (n >= 16) {
+        uint64_t a, b, c, e;
+        __builtin_memcpy(&a, s, 8); __builtin_memcpy(&b, s + 8, 8); __builtin_memcpy(&c, s + n - 16, 8); __builtin_memcpy(&e, s + n - 8, 8);
+        __builtin_memcpy(d, &a, 8); __builtin_memcpy(d + 8, &b, 8); __builtin_memcpy(d + n - 16, &c, 8); __builtin_memcpy(d + n - 8, &e, 8);
     } else if (n >= 8) {
         uint64_t x, y;
         __builtin_memcpy(&x, s, 8); __builtin_memcpy(&y, s + n - 8, 8);
@@ -814,7 +844,51 @@ __device__ __forceinline__ void decode_frame(Lds &L, const int lane, const uint3
                     if (zd::ballot(have && offset > dmat) != 0) { err = ZARC_FRAME_CORRUPT; break; }
                     const uint32_t msrc = dmat - offset;
                     const bool far = have && msrc + ml <= bpos;                // source entirely below this batch's output
-                    if (!(dbg & 1)) {
+                    if (!(dbg & 1) && pre && tot_all <= OBUF) {
+                        // ---- fast path: the batch's output is put together in LDS, then written out as whole lines ----
+                        uint8_t *const ob = L.obuf;
+                        const uint32_t o_lit = dlit - bpos, o_mat = dmat - bpos;
+                        // (1) literal runs and (2) far matches (sources below this batch's output): independent of each other
+                        if (lit_rle) { for (uint32_t r = 0; r < ll; r++) ob[o_lit + r] = lit_rle_byte; }
+                        else if (ll <= 32) lane_stage32(ob + o_lit, lit + slit, ll);
+                        if (far && ml <= 32) lane_stage32(ob + o_mat, out + msrc, ml);
+                        uint64_t longs = lit_rle ? 0ull : zd::ballot(ll > 32);
+                        while (longs) {
+                            const int i = zd::ctz64(longs);
+                            longs &= longs - 1;
+                            const uint32_t n_ = zd::readlane(ll, (uint32_t)i), d_ = zd::readlane(o_lit, (uint32_t)i), s_ = zd::readlane(slit, (uint32_t)i);
+                            for (uint32_t k = (uint32_t)lane; k < n_; k += 64) ob[d_ + k] = lit[s_ + k];
+                        }
+                        longs = zd::ballot(far && ml > 32);
+                        while (longs) {
+                            const int i = zd::ctz64(longs);
+                            longs &= longs - 1;
+                            const uint32_t n_ = zd::readlane(ml, (uint32_t)i), d_ = zd::readlane(o_mat, (uint32_t)i), s_ = zd::readlane(msrc, (uint32_t)i);
+                            for (uint32_t k = (uint32_t)lane; k < n_; k += 64) ob[d_ + k] = out[s_ + k];
+                        }
+                        zd::wave_sync();
+                        // (3) near matches in order: their sources are bytes of this batch (LDS) or, below its start, earlier output
+                        uint64_t near = zd::ballot(have && !far);
+                        while (near) {
+                            const int i = zd::ctz64(near);
+                            near &= near - 1;
+                            const uint32_t n_ = zd::readlane(ml, (uint32_t)i), d_ = zd::readlane(o_mat, (uint32_t)i), o_ = zd::readlane(offset, (uint32_t)i);
+                            // all reads come from below the match start: byte k <- source[k mod offset]
+                            for (uint32_t k = (uint32_t)lane; k < n_; k += 64) {
+                                uint32_t j = k;
+                                if (j >= o_) j = j % o_;
+                                const int32_t sp = (int32_t)d_ - (int32_t)o_ + (int32_t)j; // relative to the batch start
+                                ob[d_ + k] = sp >= 0 ? ob[sp] : out[bpos + sp];
+                            }
+                            zd::wave_sync();
+                        }
+                        // (4) the finished bytes leave LDS 16 per lane
+                        for (uint32_t k = (uint32_t)lane * 16; k < tot_all; k += 64 * 16) {
+                            if (k + 16 <= tot_all) { struct { uint64_t a, b; } v; __builtin_memcpy(&v, ob + k, 16); __builtin_memcpy(out + bpos + k, &v, 16); }
+                            else for (uint32_t r = k; r < tot_all; r++) out[bpos + r] = ob[r];
+                        }
+                        zd::wave_sync_global(); // later batches may copy from anything written here; obuf is reused
+                    } else if (!(dbg & 1)) {
                     // (1) literal runs: short ones one lane per sequence, long ones wave-wide
                     {
                         const uint32_t ns = ll <= 32 ? ll : 0u;
