@@ -41,6 +41,8 @@ struct zarc_gpu {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr; // side stream: independent stage-2 kernels of the decoder run next to each other
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t stream3 = nullptr;
+    hipEvent_t ev_fork3 = nullptr, ev_join3 = nullptr;
     // pinned staging ring of the host-pointer entry points (allocated on first use)
     static constexpr int PIN_SLOTS = 4;
     static constexpr size_t PIN_PIECE = (size_t)32 << 20;
@@ -188,7 +190,8 @@ int zarc_gpu_create(zarc_gpu_t **out, int device)
     zarc_gpu *h = new (std::nothrow) zarc_gpu();
     if (!h) return ZARC_GPU_E_NOMEM;
     h->device = device;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess || hipStreamCreate(&h->stream2) != hipSuccess ||
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess || hipStreamCreate(&h->stream2) != hipSuccess || hipStreamCreate(&h->stream3) != hipSuccess ||
+        hipEventCreate(&h->ev_fork3) != hipSuccess || hipEventCreate(&h->ev_join3) != hipSuccess ||
         hipEventCreate(&h->ev_fork) != hipSuccess || hipEventCreate(&h->ev_join) != hipSuccess) { delete h; return ZARC_GPU_E_DEVICE; }
     for (auto &e : h->ev)
         if (hipEventCreate(&e) != hipSuccess) { delete h; return ZARC_GPU_E_DEVICE; }
@@ -216,6 +219,9 @@ void zarc_gpu_destroy(zarc_gpu_t *h)
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
+    if (h->stream3) (void)hipStreamDestroy(h->stream3);
+    if (h->ev_fork3) (void)hipEventDestroy(h->ev_fork3);
+    if (h->ev_join3) (void)hipEventDestroy(h->ev_join3);
     for (int i = 0; i < zarc_gpu::PIN_SLOTS; i++) { if (h->pin[i]) (void)hipHostFree(h->pin[i]); if (h->pin_ev[i]) (void)hipEventDestroy(h->pin_ev[i]); }
     h->d_dense.release(); h->d_goff.release(); h->d_glen.release(); h->d_gdense.release();
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -549,9 +555,26 @@ int zarc_gpu_unpack_batch_device(zarc_gpu_t *h, size_t n, const void *d_frames_b
             // (ZARC_GPU_SEQ_LANES reproduces it) -- the waves' own instruction issue dominates, not exposed waits.
             int seq_lanes = getenv("ZARC_GPU_SEQ_LANES") ? atoi(getenv("ZARC_GPU_SEQ_LANES")) : 64;
             if (seq_lanes != 8 && seq_lanes != 16 && seq_lanes != 32 && seq_lanes != 64) seq_lanes = 64;
-            hipLaunchKernelGGL(zarc_zdec_seqs, dim3((unsigned)((nslots + seq_lanes - 1) / seq_lanes)), dim3(seq_lanes), 0, h->stream, (const uint8_t *)d_frames_base, h->d_frame_off.as<uint64_t>(),
-                               (uint64_t)nslots, h->d_slot_prefix.as<uint64_t>(), h->d_zblocks.as<ZdecBlock>(), h->d_seqidx.as<uint64_t>(), h->d_seqs.as<uint64_t>(),
-                               h->d_ztables.as<uint16_t>(), h->d_fast.as<uint32_t>());
+            // The two sequence kernels stress different things (zarc_zdec_seqs: HBM / MALL bandwidth; zarc_zdec_seqs_lds: nothing
+            // but its own serial chains, one wave per SIMD), so the slots are split between them and they run side by side.
+            double frac = getenv("ZARC_GPU_SEQ_LDS_FRAC") ? atof(getenv("ZARC_GPU_SEQ_LDS_FRAC")) : 0.0;
+            if (frac < 0) frac = 0;
+            if (frac > 1) frac = 1;
+            const uint64_t split = (uint64_t)((double)nslots * (1.0 - frac)) / 64 * 64; // slots [0, split): tables in HBM scratch; [split, nslots): in LDS
+            if (split < nslots) {
+                ZHIP(hipEventRecord(h->ev_fork3, h->stream));
+                ZHIP(hipStreamWaitEvent(h->stream3, h->ev_fork3, 0));
+                hipLaunchKernelGGL(zarc_zdec_seqs_lds, dim3((unsigned)((nslots - split + ZDEC_LDS_LANES - 1) / ZDEC_LDS_LANES)), dim3(ZDEC_LDS_LANES), 0, h->stream3,
+                                   (const uint8_t *)d_frames_base, h->d_frame_off.as<uint64_t>(), (uint64_t)nslots, h->d_slot_prefix.as<uint64_t>(),
+                                   h->d_zblocks.as<ZdecBlock>(), h->d_seqidx.as<uint64_t>(), h->d_seqs.as<uint64_t>(), h->d_fast.as<uint32_t>(), split);
+                ZHIP(hipGetLastError());
+                ZHIP(hipEventRecord(h->ev_join3, h->stream3));
+            }
+            if (split > 0)
+            hipLaunchKernelGGL(zarc_zdec_seqs, dim3((unsigned)((split + seq_lanes - 1) / seq_lanes)), dim3(seq_lanes), 0, h->stream, (const uint8_t *)d_frames_base, h->d_frame_off.as<uint64_t>(),
+                               (uint64_t)split, h->d_slot_prefix.as<uint64_t>(), h->d_zblocks.as<ZdecBlock>(), h->d_seqidx.as<uint64_t>(), h->d_seqs.as<uint64_t>(),
+                               h->d_ztables.as<uint16_t>(), h->d_fast.as<uint32_t>(), (uint64_t)0);
+            if (split < nslots) ZHIP(hipStreamWaitEvent(h->stream, h->ev_join3, 0));
             ZHIP(hipGetLastError());
         }
         if (side) { ZHIP(hipEventRecord(h->ev_join, h->stream2)); ZHIP(hipStreamWaitEvent(h->stream, h->ev_join, 0)); }

@@ -52,6 +52,7 @@ struct ZdecBlock {
     uint32_t pad[3];
 };
 static_assert(sizeof(ZdecBlock) == 72, "block slot layout");
+constexpr int ZDEC_LDS_LANES = 16;  // active lanes (= block slots) per wave of zarc_zdec_seqs_lds: 16 x 2.5 KiB of tables in LDS
 constexpr int ZDEC_LIT_GROUP = 16;  // block slots per wave of zarc_zdec_literals (4 Huffman streams each)
 // Fast-path sequences are stored with zge_pack_seq(); the offset field is already resolved against the repeat-offset history
 // as far as the block alone allows: bit 17 of the literal-length field set = the offset is (history slot at block start) - delta,
@@ -81,9 +82,12 @@ __global__ void zarc_zdec_scan(const uint8_t *frames_base, const uint64_t *frame
 // Huffman literals of the fast path: one wave per ZDEC_LIT_GROUP block slots (tables in LDS, one stream per lane) -> lits[]
 __global__ void zarc_zdec_literals(const uint8_t *frames_base, const uint64_t *frame_off, uint64_t n_slots, const uint64_t *slot_prefix,
                                    const ZdecBlock *zblocks, const uint64_t *lit_index, uint8_t *lits, uint32_t *fast);
+// stage 2 with the tables in LDS: one wave of ZDEC_LDS_LANES active lanes per workgroup
+__global__ void zarc_zdec_seqs_lds(const uint8_t *frames_base, const uint64_t *frame_off, uint64_t n_slots, const uint64_t *slot_prefix,
+                                   ZdecBlock *zblocks, const uint64_t *seq_index, uint64_t *seqs, uint32_t *fast, uint64_t slot_base);
 // stage 2: one LANE per block slot entropy-decodes the block's sequences (FSE tables in HBM scratch) into seqs[]
 __global__ void zarc_zdec_seqs(const uint8_t *frames_base, const uint64_t *frame_off, uint64_t n_slots, const uint64_t *slot_prefix,
-                               ZdecBlock *zblocks, const uint64_t *seq_index, uint64_t *seqs, uint16_t *tables, uint32_t *fast);
+                               ZdecBlock *zblocks, const uint64_t *seq_index, uint64_t *seqs, uint16_t *tables, uint32_t *fast, uint64_t slot_base);
 // status[i]: keeps decode errors; else CHECKSUM if the stored XXH64 differs; else DIGEST if expect differs
 __global__ void zarc_unpack_verdict(uint32_t n, const uint64_t *xxh, const uint32_t *stored_checksum, const uint32_t *digests,
                                     const uint32_t *expect /* may be null */, int32_t *status);

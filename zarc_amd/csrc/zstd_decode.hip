@@ -129,6 +129,55 @@ struct SeqBits {
     }
 };
 
+// ---- backward bit reader of zarc_zdec_seqs_lds: one 16-byte window per sequence, requested at a fixed point of the loop
+// and consumed in two phases of at most 57 bits each; nothing in it depends on what other lanes have consumed ----
+struct Bits128 {
+    const uint8_t *p;
+    int32_t bitpos; // unread bits below the cursor; negative = read past the beginning
+    uint64_t hi, lo;
+    int32_t u;      // bits of `hi` already consumed
+    int32_t top;    // byte (exclusive) where the window ends
+    __device__ __forceinline__ bool init(const uint8_t *ptr, uint32_t len)
+    {
+        p = ptr; hi = lo = 0; u = 0; top = 0;
+        if (len == 0) return false;
+        const uint32_t last = ptr[len - 1];
+        if (last == 0) return false;
+        bitpos = (int32_t)(len - 1) * 8 + zd::hb32(last);
+        return true;
+    }
+    __device__ __forceinline__ void request() // the 128 bits that end at the cursor's byte; no branch, no wait
+    {
+        top = (bitpos + 7) >> 3;
+        const int32_t base = top >= 16 ? top - 16 : 0;
+        lo = zd::load_u64(p + base);
+        hi = zd::load_u64(p + base + 8);
+        u = 8 * top - bitpos;
+    }
+    __device__ __forceinline__ void settle() // within 16 bytes of the stream's start: move the bytes up, zeros come in below
+    {
+        if (top < 16) {
+            const int32_t sb = 16 - top; // bytes to shift by, >= 1
+            if (sb >= 16) { hi = 0; lo = 0; }
+            else if (sb >= 8) { hi = sb == 8 ? lo : lo << (8 * (sb - 8)); lo = 0; }
+            else { hi = (hi << (8 * sb)) | (lo >> (64 - 8 * sb)); lo <<= 8 * sb; }
+        }
+    }
+    __device__ __forceinline__ void second_phase() // bring the next 64 unread bits to the top of `hi`
+    {
+        if (u) hi = (hi << u) | (lo >> (64 - u));
+        u = 0;
+    }
+    __device__ __forceinline__ uint32_t take(uint32_t k) // 0 <= k <= 32, within the phase's budget
+    {
+        const uint32_t t = (uint32_t)((hi << u) >> 32);
+        const uint32_t v = k ? t >> (32 - k) : 0u;
+        u += (int32_t)k;
+        bitpos -= (int32_t)k;
+        return v;
+    }
+};
+
 // literal-length / match-length code -> baseline and number of extra bits, in registers (RFC 8878 tables 15 and 16)
 __device__ __forceinline__ void ll_code_info(uint32_t code, uint32_t &base, uint32_t &bits)
 {
@@ -1079,13 +1128,38 @@ __global__ void __launch_bounds__(64) zarc_zdec_scan(const uint8_t *__restrict__
     fast[f] = 1;
 }
 
+// table of type t for block slot s: from the block's own description or, in Repeat mode, from the nearest earlier block of
+// the frame that has sequences and sets this table.  Returns the accuracy or -1.
+__device__ int make_seq_table(uint16_t *tab, int t, const SeqHeader &own, const uint8_t *src, uint64_t s, uint32_t f,
+                              const uint64_t *__restrict__ slot_prefix, const ZdecBlock *__restrict__ zblocks)
+{
+    uint32_t mode = own.mode[t], off = own.off[t], len = own.len[t];
+    if (mode == 3) {
+        bool found = false;
+        const uint64_t first = slot_prefix[f];
+        for (uint64_t j = s; j > first;) {
+            j--;
+            const ZdecBlock pb = zblocks[j];
+            if (pb.type != 2 || pb.nseq == 0) continue;
+            SeqHeader ph;
+            if (!scan_seq_header(src, pb.seq_hdr, pb.payload + pb.size, &ph)) break;
+            if (ph.mode[t] == 3) continue;
+            mode = ph.mode[t]; off = ph.off[t]; len = ph.len[t];
+            found = true;
+            break;
+        }
+        if (!found) return -1;
+    }
+    return build_seq_table(tab, t, mode, src + off, mode == 2 ? len : (mode == 1 ? 1u : 0u));
+}
+
 // Stage 2: one lane per block slot.
 __global__ void __launch_bounds__(64) zarc_zdec_seqs(const uint8_t *__restrict__ frames_base, const uint64_t *__restrict__ frame_off, uint64_t n_slots,
                                                      const uint64_t *__restrict__ slot_prefix, ZdecBlock *__restrict__ zblocks,
                                                      const uint64_t *__restrict__ seq_index, uint64_t *__restrict__ seqs, uint16_t *__restrict__ tables,
-                                                     uint32_t *__restrict__ fast)
+                                                     uint32_t *__restrict__ fast, uint64_t slot_base)
 {
-    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; // the engine launches partly filled waves (see engine.hip)
+    const uint64_t s = slot_base + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; // slots [slot_base, n_slots); waves may be partly filled (engine.hip)
     if (s >= n_slots) return;
     const ZdecBlock zb = zblocks[s];
     if (zb.type != 2 || zb.nseq == 0) return;
@@ -1160,6 +1234,90 @@ __global__ void __launch_bounds__(64) zarc_zdec_seqs(const uint8_t *__restrict__
                 sl = cell_base(cl, al[0]) + b.read((int)cell_nbits(cl, al[0]));
                 sm = cell_base(cm, al[2]) + b.read((int)cell_nbits(cm, al[2]));
                 so = cell_base(co, al[1]) + b.read((int)cell_nbits(co, al[1]));
+            }
+            if (b.bitpos < 0) ok = false;
+        }
+        if (ok && b.bitpos != 0) ok = false;
+    }
+    if (ok) {
+        zblocks[s].rep[0] = hr0 ? (ZDEC_REP_REF | hv0) : hv0;
+        zblocks[s].rep[1] = hr1 ? (ZDEC_REP_REF | hv1) : hv1;
+        zblocks[s].rep[2] = hr2 ? (ZDEC_REP_REF | hv2) : hv2;
+        zblocks[s].state = 1;
+    }
+    else fast[f] = 0; // the frame pass decodes this frame inline and reports whatever is wrong with it
+}
+
+
+// Stage 2, tables in LDS.  The lookups of zarc_zdec_seqs go to 80 000 different 2.5 KiB tables: every 2-byte lookup costs a
+// cache line from HBM / MALL (about 170 GB per launch on BASELINE configs[1]).  Here a workgroup is ONE wave with 16 active
+// lanes and their tables in LDS (40 KiB, four workgroups per CU, one per SIMD): fewer blocks in flight, but each sequence is
+// a chain of ALU work plus one LDS access instead of an HBM round trip.
+__global__ void __launch_bounds__(ZDEC_LDS_LANES) zarc_zdec_seqs_lds(const uint8_t *__restrict__ frames_base, const uint64_t *__restrict__ frame_off,
+                                                                     uint64_t n_slots, const uint64_t *__restrict__ slot_prefix, ZdecBlock *__restrict__ zblocks,
+                                                                     const uint64_t *__restrict__ seq_index, uint64_t *__restrict__ seqs, uint32_t *__restrict__ fast,
+                                                                     uint64_t slot_base)
+{
+    __shared__ uint16_t T[ZDEC_LDS_LANES][ZDEC_TABLE_CELLS];
+    const int l = (int)threadIdx.x;
+    const uint64_t s = slot_base + (uint64_t)blockIdx.x * ZDEC_LDS_LANES + (uint64_t)l; // slots [slot_base, n_slots)
+    if (s >= n_slots) return;
+    const ZdecBlock zb = zblocks[s];
+    if (zb.type != 2 || zb.nseq == 0) return;
+    const uint32_t f = zb.frame;
+    if (!fast[f]) return;
+    const uint8_t *src = frames_base + frame_off[f];
+    const uint32_t end = zb.payload + zb.size;
+    SeqHeader own;
+    bool ok = scan_seq_header(src, zb.seq_hdr, end, &own);
+    int al_l = 0, al_o = 0, al_m = 0;
+    if (ok) { al_l = make_seq_table(&T[l][0], 0, own, src, s, f, slot_prefix, zblocks); ok = al_l >= 0; }
+    if (ok) { al_o = make_seq_table(&T[l][1024], 1, own, src, s, f, slot_prefix, zblocks); ok = al_o >= 0; }
+    if (ok) { al_m = make_seq_table(&T[l][512], 2, own, src, s, f, slot_prefix, zblocks); ok = al_m >= 0; }
+    // repeat-offset history, symbolic: hv = offset (hr = 0) or hv = slot | delta << 2 of the history at block start (hr = 1)
+    uint32_t hv0 = 0, hv1 = 1, hv2 = 2, hr0 = 1, hr1 = 1, hr2 = 1;
+    if (ok) {
+        Bits128 b;
+        ok = b.init(src + own.bits_off, end - own.bits_off);
+        uint32_t sl = 0, so = 0, sm = 0;
+        if (ok) { b.request(); b.settle(); sl = b.take((uint32_t)al_l); so = b.take((uint32_t)al_o); sm = b.take((uint32_t)al_m); ok = b.bitpos >= 0; } // <= 7 + 26 bits
+        uint64_t *outp = seqs + seq_index[s];
+        for (uint32_t i = 0; i < zb.nseq && ok; i++) {
+            b.request(); // one bitstream window per sequence, in flight during the table lookups
+            const uint32_t cl = T[l][sl], co = T[l][1024 + so], cm = T[l][512 + sm];
+            b.settle();
+            const uint32_t ofc = cell_sym(co), mlc = cell_sym(cm), llc = cell_sym(cl);
+            if (ofc > 27 || mlc > 52 || llc > 35) { ok = false; break; } // offsets past the format's largest window: left to the frame pass
+            const uint32_t ofv = (1u << ofc) + b.take(ofc);                // phase 1: <= 7 + 27 + 16 bits
+            uint32_t mbase, mbits, lbase, lbits;
+            ml_code_info(mlc, mbase, mbits);
+            ll_code_info(llc, lbase, lbits);
+            const uint32_t ml = mbase + b.take(mbits);
+            b.second_phase();                                              // phase 2: <= 16 + 9 + 9 + 8 bits
+            const uint32_t ll = lbase + b.take(lbits);
+            uint32_t ov, orf; // this sequence's offset, same symbolic form
+            if (ofv > 3) { ov = ofv - 3; orf = 0; hv2 = hv1; hr2 = hr1; hv1 = hv0; hr1 = hr0; hv0 = ov; hr0 = orf; }
+            else {
+                const uint32_t idx = ofv - 1 + (ll == 0 ? 1u : 0u);
+                if (idx == 0) { ov = hv0; orf = hr0; }
+                else {
+                    if (idx == 1) { ov = hv1; orf = hr1; }
+                    else if (idx == 2) { ov = hv2; orf = hr2; }
+                    else { // first history entry minus one
+                        ov = hv0; orf = hr0;
+                        if (orf) { if ((ov >> 2) >= 3) { ok = false; break; } ov += 4; } // delta + 1 (deeper chains: left to the frame pass)
+                        else { if (ov <= 1) { ok = false; break; } ov -= 1; }
+                    }
+                    if (idx > 1) { hv2 = hv1; hr2 = hr1; }
+                    hv1 = hv0; hr1 = hr0;
+                    hv0 = ov; hr0 = orf;
+                }
+            }
+            outp[i] = zge_pack_seq(ll | (orf ? ZDEC_LL_REF : 0u), ml, ov);
+            if (i + 1 < zb.nseq) {
+                sl = cell_base(cl, al_l) + b.take(cell_nbits(cl, al_l));
+                sm = cell_base(cm, al_m) + b.take(cell_nbits(cm, al_m));
+                so = cell_base(co, al_o) + b.take(cell_nbits(co, al_o));
             }
             if (b.bitpos < 0) ok = false;
         }
