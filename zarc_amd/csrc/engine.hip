@@ -560,7 +560,7 @@ int zarc_gpu_unpack_batch_device(zarc_gpu_t *h, size_t n, const void *d_frames_b
             double frac = getenv("ZARC_GPU_SEQ_LDS_FRAC") ? atof(getenv("ZARC_GPU_SEQ_LDS_FRAC")) : 0.0;
             if (frac < 0) frac = 0;
             if (frac > 1) frac = 1;
-            const uint64_t split = (uint64_t)((double)nslots * (1.0 - frac)) / 64 * 64; // slots [0, split): tables in HBM scratch; [split, nslots): in LDS
+            const uint64_t split = frac <= 0 ? (uint64_t)nslots : (uint64_t)((double)nslots * (1.0 - frac)) / 64 * 64; // slots [0, split): tables in HBM scratch; [split, nslots): in LDS
             if (split < nslots) {
                 ZHIP(hipEventRecord(h->ev_fork3, h->stream));
                 ZHIP(hipStreamWaitEvent(h->stream3, h->ev_fork3, 0));
