@@ -86,7 +86,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--entries", type=int, default=10000, help="entries per GPU (BASELINE configs[1]: 10000)")
     ap.add_argument("--size", type=int, default=1 << 20, help="bytes per entry (BASELINE configs[1]: 1 MiB)")
-    ap.add_argument("--cpu-sample", type=int, default=48, help="entries timed on the host for cpu_baseline (rank 0, N=1)")
+    ap.add_argument("--cpu-sample", type=int, default=1024, help="entries timed on the host for cpu_baseline (rank 0, N=1): about 20 s of libzstd + BLAKE3 on one thread")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kind", type=int, default=-1, help="diagnostics: use one corpus kind for every entry (default: round-robin)")
     args = ap.parse_args()
