@@ -90,9 +90,8 @@ struct FseCtab { uint16_t *state_tab; int32_t *dnb; int32_t *dfs; int al; };
 // The Huffman-construction arrays are dead once the literals section is coded, and the FSE sequence tables are
 // only needed after it: the two live in a union, which keeps the footprint under 10 KiB (16 waves per CU).
 struct EntLds {
-    uint32_t code[256]; // code | len << 16
-    uint32_t stage[224];
-    uint8_t cellsym[512];
+    uint16_t code[256]; // code | len << 11 (codes are at most 11 bits long)
+    union { uint32_t stage[224]; uint8_t cellsym[512]; }; // bit-packing window; FSE table construction happens between packings
     int32_t ctrl[32];
     union {
         struct {
@@ -332,7 +331,7 @@ __device__ void huf_assign_codes(EntLds &L)
     for (int i = 0; i < 256; i++) {
         if (!L.h.len8[i]) { L.code[i] = 0; continue; }
         const int w = maxlen + 1 - L.h.len8[i];
-        L.code[i] = (rank_start[w] >> (w - 1)) | ((uint32_t)L.h.len8[i] << 16);
+        L.code[i] = (uint16_t)((rank_start[w] >> (w - 1)) | ((uint32_t)L.h.len8[i] << 11));
         rank_start[w] += 1u << (w - 1);
     }
     L.ctrl[X_MAXBITS] = maxlen;
@@ -452,7 +451,7 @@ struct WavePacker {
 
 } // namespace
 
-__global__ void __launch_bounds__(64) zarc_zge_entropy(uint32_t n_blocks, ZgeBlock *__restrict__ blocks, uint64_t *__restrict__ seq_scratch,
+__global__ void __launch_bounds__(64, 5) zarc_zge_entropy(uint32_t n_blocks, ZgeBlock *__restrict__ blocks, uint64_t *__restrict__ seq_scratch,
                                                        const uint8_t *__restrict__ lit_scratch, uint8_t *__restrict__ out_scratch,
                                                        unsigned long long *__restrict__ prof /* stage ticks (diagnostics) or null */)
 {
@@ -516,7 +515,7 @@ __global__ void __launch_bounds__(64) zarc_zge_entropy(uint32_t n_blocks, ZgeBlo
                     for (uint32_t j0 = 0; j0 < cnt; j0 += 64) {
                         const uint32_t j = j0 + (uint32_t)lane;
                         uint32_t cv = 0, cl_ = 0;
-                        if (j < cnt) { const uint32_t e = L.code[lit[beg + cnt - 1 - j]]; cv = e & 0xFFFF; cl_ = e >> 16; }
+                        if (j < cnt) { const uint32_t e = L.code[lit[beg + cnt - 1 - j]]; cv = e & 0x7FF; cl_ = e >> 11; }
                         pk.put(cv, 0, cl_, lane);
                     }
                     ssz[k] = pk.finish(lane);
