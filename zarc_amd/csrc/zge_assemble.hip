@@ -9,6 +9,15 @@
 #include "zarc_kernels.h"
 #include "corpus.h"
 
+// workgroup-cooperative copy, 16 bytes per thread and step (source and destination need no alignment)
+__device__ __forceinline__ void group_copy(uint8_t *__restrict__ d, const uint8_t *__restrict__ s, uint32_t n, int tid, int nthreads)
+{
+    struct B16 { uint64_t a, b; };
+    const uint32_t n16 = n / 16;
+    for (uint32_t i = (uint32_t)tid; i < n16; i += (uint32_t)nthreads) { B16 v; __builtin_memcpy(&v, s + 16 * (uint64_t)i, 16); __builtin_memcpy(d + 16 * (uint64_t)i, &v, 16); }
+    for (uint32_t i = n16 * 16 + (uint32_t)tid; i < n; i += (uint32_t)nthreads) d[i] = s[i];
+}
+
 // One workgroup per frame: block payloads are gathered from the per-block scratch slots (or from the
 // source for raw / RLE blocks) into one contiguous frame.
 __global__ void __launch_bounds__(256) zarc_zge_assemble(ZgeParams P, const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off,
@@ -58,7 +67,7 @@ __global__ void __launch_bounds__(256) zarc_zge_assemble(ZgeParams P, const uint
             if (rec.type == 2) { from = out_scratch + (first + b) * (uint64_t)(ZARC_BLOCK + 1024); cnt = rec.out_len; }
             else if (rec.type == 1) { from = src + (uint64_t)b * ZARC_BLOCK; cnt = 1; }
             else { from = src + (uint64_t)b * ZARC_BLOCK; cnt = rec.src_len; }
-            for (uint32_t i = (uint32_t)tid; i < cnt; i += blockDim.x) dst[pos + i] = from[i];
+            group_copy(dst + pos, from, cnt, tid, (int)blockDim.x);
             pos += cnt;
         }
     }
@@ -80,7 +89,7 @@ __global__ void __launch_bounds__(256) zarc_gather(const uint8_t *__restrict__ s
     const uint8_t *s = src_base + src_off[i];
     uint8_t *d = dst + dense_off[i];
     const uint64_t l = len[i];
-    for (uint64_t k = threadIdx.x; k < l; k += blockDim.x) d[k] = s[k];
+    for (uint64_t at = 0; at < l; at += 0x40000000ull) group_copy(d + at, s + at, (uint32_t)(l - at > 0x40000000ull ? 0x40000000ull : l - at), (int)threadIdx.x, (int)blockDim.x);
 }
 
 // Store mode (Encoder::enable_compression(false), crates/zarc/src/encode.rs:95-97 -> write_uncompressed_frame,
@@ -113,7 +122,7 @@ __global__ void __launch_bounds__(256) zarc_zge_store(const uint8_t *__restrict_
         const uint32_t hdr = (b + 1 == nblocks ? 1u : 0u) | (cnt << 3); // type 0 = Raw
         if (tid == 0) { dst[pos] = (uint8_t)hdr; dst[pos + 1] = (uint8_t)(hdr >> 8); dst[pos + 2] = (uint8_t)(hdr >> 16); }
         pos += 3;
-        for (uint32_t i = (uint32_t)tid; i < cnt; i += blockDim.x) dst[pos + i] = src[at + i];
+        group_copy(dst + pos, src + at, cnt, tid, (int)blockDim.x);
         pos += cnt;
     }
     if (tid == 0) dst_len[f] = pos;
