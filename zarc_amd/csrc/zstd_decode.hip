@@ -311,7 +311,10 @@ enum { C_ERR = 0, C_HUF_BITS = 1, C_HUF_VALID = 2, C_LL_AL = 3, C_OF_AL = 4, C_M
 // wave-cooperative byte copy; src and dst never overlap forward within one call
 __device__ __forceinline__ void wave_copy(uint8_t *dst, const uint8_t *src, uint32_t n, int lane)
 {
-    for (uint32_t i = (uint32_t)lane; i < n; i += 64) dst[i] = src[i];
+    struct B16 { uint64_t a, b; };
+    const uint32_t n16 = n / 16; // 16 bytes per lane and step (no alignment needed), then the tail
+    for (uint32_t i = (uint32_t)lane; i < n16; i += 64) { B16 v; __builtin_memcpy(&v, src + 16 * i, 16); __builtin_memcpy(dst + 16 * i, &v, 16); }
+    for (uint32_t i = n16 * 16 + (uint32_t)lane; i < n; i += 64) dst[i] = src[i];
 }
 
 // One lane copies n <= 32 bytes (source and destination do not overlap): head and tail pieces of the largest power of two
