@@ -36,6 +36,9 @@ namespace {
 #else
 #define ZGE_CLOCK() ((unsigned long long)__builtin_readcyclecounter())
 #endif
+// A thread's positions: wave w owns the ADJACENT 64-position chunks 2w and 2w+1 of the tile (the parse walks a pair without
+// going through LDS, and the chain over chunk entries hops pair by pair)
+#define ZGE_IDX(u) ((uint32_t)((wave * PER + (u)) * 64 + lane))
 // stage timing (diagnostics): ticks since the previous mark, accumulated per stage; each mark sits after a barrier
 #define ZGE_PROF(i) do { if ((P.dbg & 1024) && tid == 0) { const unsigned long long now_ = ZGE_CLOCK(); L.prof[i] += now_ - tprev; tprev = now_; } } while (0)
 
@@ -222,7 +225,7 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
             uint64_t p8[PER]; // first 8 bytes at each of this thread's positions
 #pragma unroll
             for (int u = 0; u < PER; u++) {
-                const uint32_t idx = (uint32_t)(u * THREADS + tid);
+                const uint32_t idx = ZGE_IDX(u);
                 const uint32_t p = tile + idx;
                 uint32_t hl = 0xFFFFFFFFu, hs = 0xFFFFFFFFu;
                 p8[u] = 0;
@@ -281,7 +284,7 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
             U128 q16[PER][2];
 #pragma unroll
             for (int u = 0; u < PER; u++) {
-                const uint32_t idx = (uint32_t)(u * THREADS + tid);
+                const uint32_t idx = ZGE_IDX(u);
                 const uint32_t p = tile + idx;
                 uint32_t c0 = 0, c1 = 0;
                 if (idx < tcount && !(P.dbg & 5)) {
@@ -311,7 +314,7 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                 const bool use1 = P.rep_search > 1 && erep1 != 0 && erep1 != erep0 && erep1 <= window;
 #pragma unroll
                 for (int u = 0; u < PER; u++) {
-                    const uint32_t idx = (uint32_t)(u * THREADS + tid);
+                    const uint32_t idx = ZGE_IDX(u);
                     const uint32_t p = tile + idx;
                     const uint32_t limit = idx < tcount ? (uint32_t)(be - p) : 0u, cap = limit < cap_max ? limit : cap_max;
                     uint32_t res = 0;
@@ -335,7 +338,7 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
             ZGE_PROF(10);
 #pragma unroll
             for (int u = 0; u < PER; u++) {
-                const uint32_t idx = (uint32_t)(u * THREADS + tid);
+                const uint32_t idx = ZGE_IDX(u);
                 const uint32_t p = tile + idx;
                 mo[u] = 0; mw[u] = 0;
                 const uint32_t limit = idx < tcount ? (uint32_t)(be - p) : 0u, cap = limit < cap_max ? limit : cap_max;
@@ -391,14 +394,14 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
             // fits one word: offsets stay below 2^21 (table positions restart every 2^seg_log <= 2^21 bytes, recent-offset
             // guesses are shorter still) and lengths below 2^9 (cap 256 + 8 bytes of backward extension).
 #pragma unroll
-            for (int u = 0; u < PER; u++) L.a0[u * THREADS + tid] = match_pack(mo[u], mw[u] & 0xFFFF, (mw[u] >> 24) & 1);
+            for (int u = 0; u < PER; u++) L.a0[ZGE_IDX(u)] = match_pack(mo[u], mw[u] & 0xFFFF, (mw[u] >> 24) & 1);
             if (mo[0] | mo[1]) L.ctrl[K_ANY] = 1; // benign race: every writer stores 1
             // ---- S4: backward propagation.  A position whose match extends b bytes backwards offers it to the b
             // positions before it (ds_max of score << 4 | 8-k: best score wins, then the nearest source); every position
             // then adopts the best offer if it beats its own match.  Same result as scanning the 8 following positions.
 #pragma unroll
             for (int u = 0; u < PER; u++) {
-                const uint32_t idx = (uint32_t)(u * THREADS + tid);
+                const uint32_t idx = ZGE_IDX(u);
                 const uint32_t len = mw[u] & 0xFFFF, back = (mw[u] >> 16) & 0xFF;
                 if (len && back && !(P.dbg & 8)) {
                     const bool rep = (mw[u] >> 24) & 1;
@@ -415,7 +418,7 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                 const uint32_t start = (uint32_t)((pos > tile ? pos : tile) - tile);
 #pragma unroll
                 for (int u = 0; u < PER; u++) {
-                    const uint32_t idx = (uint32_t)(u * THREADS + tid);
+                    const uint32_t idx = ZGE_IDX(u);
                     if (idx >= start && idx < tcount && !(P.dbg & 32)) lit_out[lp + (idx - start)] = (uint8_t)p8[u];
                 }
                 lp += tcount - start;
@@ -424,7 +427,7 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
             }
 #pragma unroll
             for (int u = 0; u < PER; u++) {
-                const uint32_t idx = (uint32_t)(u * THREADS + tid);
+                const uint32_t idx = ZGE_IDX(u);
                 const uint32_t offer = L.ex[idx];
                 uint32_t blen_ = mw[u] & 0xFFFF, boff = mo[u];
                 bool brep = (mw[u] >> 24) & 1;
@@ -449,7 +452,7 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
             uint32_t nx[PER]; // true successor in tile coordinates (may leave the tile)
 #pragma unroll
             for (int u = 0; u < PER; u++) {
-                const uint32_t idx = (uint32_t)(u * THREADS + tid);
+                const uint32_t idx = ZGE_IDX(u);
                 const uint32_t my_len = mw[u] & 0xFFFF;
                 take[u] = idx < tcount && my_len != 0;
                 if (take[u] && P.lazy && idx + 1 < tcount) {
@@ -459,19 +462,29 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                 }
                 nx[u] = take[u] ? idx + my_len : idx + 1;
             }
-            // ---- S6a: per chunk, the first position outside the chunk reached from every position ----
+            // ---- S6a: per chunk, the first position outside the chunk reached from every position; for the first chunk of the
+            // wave's pair this is carried on through the second chunk (one more shuffle), so ex[] of a pair's first half holds
+            // the exit of the whole pair ----
+            {
+                uint32_t val[PER];
 #pragma unroll
-            for (int u = 0; u < PER; u++) {
-                const uint32_t idx = (uint32_t)(u * THREADS + tid);
-                const uint32_t cbase = idx & ~63u;
-                const uint32_t cend = cbase + 64 < tcount ? cbase + 64 : tcount;
-                uint32_t val = nx[u];
+                for (int u = 0; u < PER; u++) {
+                    const uint32_t cbase = (uint32_t)(wave * PER + u) * 64;
+                    const uint32_t cend = cbase + 64 < tcount ? cbase + 64 : tcount;
+                    val[u] = nx[u];
 #pragma unroll
-                for (int r = 0; r < 6; r++) {
-                    const uint32_t v2 = zd::shfl(val, (int)((val - cbase) & 63));
-                    if (val < cend) val = v2;
+                    for (int r = 0; r < 6; r++) {
+                        const uint32_t v2 = zd::shfl(val[u], (int)((val[u] - cbase) & 63));
+                        if (val[u] < cend) val[u] = v2;
+                    }
                 }
-                L.ex[idx] = val;
+                {
+                    const uint32_t obase = (uint32_t)(wave * PER + 1) * 64, oend = obase + 64 < tcount ? obase + 64 : tcount;
+                    const uint32_t through = zd::shfl(val[1], (int)((val[0] - obase) & 63));
+                    if (val[0] >= obase && val[0] < oend) val[0] = through;
+                }
+#pragma unroll
+                for (int u = 0; u < PER; u++) L.ex[ZGE_IDX(u)] = val[u];
             }
             zd::lds_barrier();
             ZGE_PROF(6);
@@ -481,13 +494,14 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                 uint32_t cur = (uint32_t)((pos > tile ? pos : tile) - tile);
                 int c = 0;
 #pragma unroll
+                for (; c < wave; c++) { // pairs of chunks before mine: hop over them (an entry in either half leaves through ex[])
+                    const uint32_t pend = (uint32_t)(c * 128 + 128) < tcount ? (uint32_t)(c * 128 + 128) : tcount;
+                    if (cur < pend) cur = L.ex[cur];
+                }
+                cur = zd::uniform(cur);
+#pragma unroll
                 for (int u = 0; u < PER; u++) {
-                    const int mychunk = wave + u * WAVES;
-                    for (; c < mychunk; c++) { // chunks before mine: hop over them
-                        const uint32_t cend = (uint32_t)(c * 64 + 64) < tcount ? (uint32_t)(c * 64 + 64) : tcount;
-                        if (cur < cend) cur = L.ex[cur];
-                    }
-                    cur = zd::uniform(cur);
+                    const int mychunk = wave * PER + u; // the walk of the first chunk ends at the entry of the second
                     const uint32_t cbase = (uint32_t)mychunk * 64;
                     const uint32_t cend = cbase + 64 < tcount ? cbase + 64 : tcount;
                     // walk the path inside my chunk: literal nodes step by one, so only the selected matches are
@@ -510,7 +524,6 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                             cur = zd::readlane(nx[u], q);
                         }
                     }
-                    c = mychunk + 1;
                     msel[u] = sel;
                     mlit[u] = lits;
                     if (lane == 0) L.wcnt[mychunk] = ((uint32_t)__popcll(msel[u]) << 16) | (uint32_t)__popcll(mlit[u]);
@@ -534,7 +547,7 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                 lit_total = tot & 0xFFFFu;
 #pragma unroll
                 for (int u = 0; u < PER; u++) {
-                    const uint32_t incl = zd::readlane(cv, (uint32_t)(wave + u * WAVES));
+                    const uint32_t incl = zd::readlane(cv, (uint32_t)(wave * PER + u));
                     sel_before[u] = (incl >> 16) - (uint32_t)__popcll(msel[u]);
                     lit_before[u] = (incl & 0xFFFFu) - (uint32_t)__popcll(mlit[u]);
                 }
