@@ -90,6 +90,16 @@ __device__ __forceinline__ uint32_t shfl_up(uint32_t v, unsigned d) { return (ui
 __device__ __forceinline__ uint32_t shfl_down(uint32_t v, unsigned d) { return (uint32_t)__shfl_down((int)v, d, 64); }
 __device__ __forceinline__ uint32_t shfl_xor(uint32_t v, int m) { return (uint32_t)__shfl_xor((int)v, m, 64); }
 
+// a store whose data is not read again by this kernel (non-temporal: does not displace what the caches should keep)
+__device__ __forceinline__ void store_streaming(uint64_t *p, uint64_t v)
+{
+#ifdef ZARC_HIPEMU
+    *p = v;
+#else
+    __builtin_nontemporal_store(v, p);
+#endif
+}
+
 __device__ __forceinline__ uint32_t rotr32(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
 __device__ __forceinline__ uint64_t rotl64(uint64_t x, int n) { return (x << n) | (x >> (64 - n)); }
 __device__ __forceinline__ int hb32(uint32_t v) { return 31 - __clz((int)v); }          // floor(log2 v), v > 0

@@ -1232,7 +1232,7 @@ __global__ void __launch_bounds__(64) zarc_zdec_seqs(const uint8_t *__restrict__
                     hv0 = ov; hr0 = orf;
                 }
             }
-            outp[i] = zge_pack_seq(ll | (orf ? ZDEC_LL_REF : 0u), ml, ov);
+            zd::store_streaming(outp + i, zge_pack_seq(ll | (orf ? ZDEC_LL_REF : 0u), ml, ov)); // written once, read by the frame pass: keep it out of the way of the tables
             if (i + 1 < zb.nseq) {
                 sl = cell_base(cl, al[0]) + b.read((int)cell_nbits(cl, al[0]));
                 sm = cell_base(cm, al[2]) + b.read((int)cell_nbits(cm, al[2]));
@@ -1316,7 +1316,7 @@ __global__ void __launch_bounds__(ZDEC_LDS_LANES) zarc_zdec_seqs_lds(const uint8
                     hv0 = ov; hr0 = orf;
                 }
             }
-            outp[i] = zge_pack_seq(ll | (orf ? ZDEC_LL_REF : 0u), ml, ov);
+            zd::store_streaming(outp + i, zge_pack_seq(ll | (orf ? ZDEC_LL_REF : 0u), ml, ov)); // written once, read by the frame pass: keep it out of the way of the tables
             if (i + 1 < zb.nseq) {
                 sl = cell_base(cl, al_l) + b.take(cell_nbits(cl, al_l));
                 sm = cell_base(cm, al_m) + b.take(cell_nbits(cm, al_m));
