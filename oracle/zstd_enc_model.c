@@ -793,6 +793,9 @@ void zge_default_params(zge_params *P, int level)
     P->back_cap = 8; P->lazy = 1; P->lazy_delta = 5;
     P->lit_cost = 5; P->match_cost = 12; P->rep_cost = 9;
     P->window_log = 21; P->short_window_log = 30;
+    if (level >= 9) { /* the engine's deep finder (engine.hip: derive_params) */
+        P->long_log = 14; P->short_log = 14; P->short_bytes = 4; P->min_match = 4; P->match_cost = 10; P->window_log = 22;
+    }
 }
 
 int zge_encode_frame(const zge_params *P, const void *src_, size_t n, void *dst_, size_t cap,

@@ -51,3 +51,18 @@ def test_emu_pack_in_sub_batches(emu_engine, oracle, corpus, libzstds, monkeypat
     frames must not change."""
     monkeypatch.setenv("ZARC_GPU_SCRATCH_MB", "1")
     pc.check_pack(emu_engine, oracle, corpus, libzstds, big=False)
+
+
+def test_emu_level9_deep_finder_matches_model(emu_lib_path, oracle, corpus):
+    """Level >= 9 launches the deep match finder (2^14-entry tables, one workgroup per CU): frames bit-identical to the model."""
+    from zarc_amd import Engine, _lib
+    e9 = Engine(0, lib_path=emu_lib_path)
+    try:
+        e9.set_parameter(_lib.P_CHECKSUM_FLAG, 1)
+        e9.set_parameter(_lib.P_COMPRESSION_LEVEL, 9)
+        raws = [corpus.entry(9100 + i, n, i & 3) for i, n in enumerate((0, 70000, 200000, 300001))]
+        for raw, (frame, dig) in zip(raws, e9.pack(raws)):
+            assert frame == oracle.zge_encode(raw, oracle.params(level=9))
+            assert dig == oracle.blake3(raw)
+    finally:
+        e9.close()

@@ -42,3 +42,16 @@ def test_model_ratio_within_5_percent_of_libzstd_level3(oracle, corpus, libzstds
         ours += o_
         ref += r_
     assert ours <= ref * 1.05
+
+
+def test_model_level9_within_5_percent_of_libzstd_level9(oracle, corpus, libzstds):
+    """BASELINE configs[3] is level 9: the deep finder (2^14-entry tables, 4-byte short hash) against libzstd -9."""
+    z = next((z for z in libzstds if z.version.startswith("1.5")), None) or (libzstds[0] if libzstds else None)
+    if z is None:
+        pytest.skip("no libzstd on this box")
+    for kind in (0, 1, 2):
+        raw = corpus.entry(5000 + kind, 4 << 20, kind)
+        frame = oracle.zge_encode(raw, oracle.params(level=9))
+        rc, out, used = oracle.zstd_decode(frame, len(raw))
+        assert rc == 0 and out == raw and used == len(frame)
+        assert len(frame) <= len(z.compress(raw, 9, 1)) * 1.05, kind

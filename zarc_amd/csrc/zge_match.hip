@@ -48,14 +48,13 @@ constexpr int WAVES = THREADS / 64;
 constexpr int PER = TILE / THREADS; // positions per thread
 static_assert(PER == 2, "the kernel is written for two positions per thread");
 constexpr int CHUNKS = TILE / 64;
-constexpr int TAB_LOG = 13;
 constexpr int TAG_BITS = 10;
 constexpr uint32_t TAG_MASK = (1u << TAG_BITS) - 1;
 constexpr int CAP_MAX = 256;
 constexpr int REP_BACK_MAX = 256;
 constexpr int TB_BYTES = 12 + REP_BACK_MAX + TILE + CAP_MAX + 24; // rep window + 8 bytes before the tile, compare overrun after it
 
-struct MatchLds {
+template <int TAB_LOG> struct MatchLds {
     uint32_t tl[1 << TAB_LOG];
     uint32_t ts[1 << TAB_LOG];
     uint32_t a0[TILE], a1[TILE]; // S1: hashes -> S2: candidates (pos+1) -> S3: a0 = own match (match_pack) -> S4: a1 = final match
@@ -83,12 +82,13 @@ __device__ __forceinline__ uint32_t hash_short(uint64_t v, int bits, int nbytes)
 
 // Bit-cost model (lit_cost 5, match_cost 12, rep_cost 9: the engine's fixed defaults, so the literal cost is a
 // shift-add instead of a quarter-rate multiply; engine.hip: derive_params() sets exactly these, they are not tunable).
-constexpr int LIT_COST = 5, MATCH_COST = 12, REP_COST = 9;
-__device__ __forceinline__ int32_t score_of(const ZgeParams &, uint32_t len, uint32_t off, bool is_rep)
+constexpr int LIT_COST = 5, REP_COST = 9;
+template <int MATCH_COST> __device__ __forceinline__ int32_t score_mc(uint32_t len, uint32_t off, bool is_rep)
 {
     const int32_t lits = (int32_t)((len << 2) + len);
     return is_rep ? lits - REP_COST : lits - MATCH_COST - zd::hb32(off);
 }
+#define score_of(P_, len_, off_, rep_) score_mc<MATCH_COST>((len_), (off_), (rep_))
 
 struct U128 { uint64_t lo, hi; };
 
@@ -119,12 +119,14 @@ __device__ __forceinline__ StageWin stage_window(const ZgeParams &P, const uint8
 
 } // namespace
 
-__global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off,
-                                                      const uint64_t *__restrict__ src_len, const uint32_t *__restrict__ order, uint32_t n_frames,
-                                                      const uint64_t *__restrict__ block_prefix, ZgeBlock *__restrict__ blocks,
-                                                      uint64_t *__restrict__ seq_scratch, uint8_t *__restrict__ lit_scratch, uint32_t *__restrict__ queue)
+// The body is compiled twice: the level-3 finder (2^13-entry tables, 5-byte short hash, two workgroups per CU) and the deep
+// one for level >= 9 (2^14-entry tables = 128 KiB of LDS, one workgroup per CU; 4-byte short hash, cheaper matches).
+template <int TAB_LOG, int SHORT_BYTES, int MATCH_COST>
+__device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgeParams &P, const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off,
+                                               const uint64_t *__restrict__ src_len, const uint32_t *__restrict__ order, uint32_t n_frames,
+                                               const uint64_t *__restrict__ block_prefix, ZgeBlock *__restrict__ blocks,
+                                               uint64_t *__restrict__ seq_scratch, uint8_t *__restrict__ lit_scratch, uint32_t *__restrict__ queue)
 {
-    __shared__ MatchLds L;
     const int tid = (int)threadIdx.x, lane = zd::lane_id();
     const int wave = (int)zd::uniform((uint32_t)zd::wave_id()); // scalar: chunk bounds and the parse walk stay on the SALU
     const uint64_t lt = (1ull << lane) - 1;
@@ -233,7 +235,7 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                     p8[u] = zd::load_u64(tbb + (uint32_t)(p + wofs));
                     if (p < hash_end && !(P.dbg & 64)) {
                         hl = hash_long(p8[u], TAB_LOG + TAG_BITS);
-                        hs = hash_short(p8[u], TAB_LOG + TAG_BITS, 5); // short_bytes is fixed at 5 by the engine
+                        hs = hash_short(p8[u], TAB_LOG + TAG_BITS, SHORT_BYTES);
                     }
                 }
                 L.a0[idx] = hl;
@@ -576,4 +578,23 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
     }
     } // next frame from the queue
     if ((P.dbg & 1024) && tid < 12) atomicAdd((unsigned long long *)(queue + 2) + tid, L.prof[tid]);
+}
+#undef score_of
+
+__global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off,
+                                                      const uint64_t *__restrict__ src_len, const uint32_t *__restrict__ order, uint32_t n_frames,
+                                                      const uint64_t *__restrict__ block_prefix, ZgeBlock *__restrict__ blocks,
+                                                      uint64_t *__restrict__ seq_scratch, uint8_t *__restrict__ lit_scratch, uint32_t *__restrict__ queue)
+{
+    __shared__ MatchLds<13> L;
+    zge_match_body<13, 5, 12>(L, P, src_base, src_off, src_len, order, n_frames, block_prefix, blocks, seq_scratch, lit_scratch, queue);
+}
+
+__global__ void __launch_bounds__(512, 2) zarc_zge_match_deep(ZgeParams P, const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off,
+                                                           const uint64_t *__restrict__ src_len, const uint32_t *__restrict__ order, uint32_t n_frames,
+                                                           const uint64_t *__restrict__ block_prefix, ZgeBlock *__restrict__ blocks,
+                                                           uint64_t *__restrict__ seq_scratch, uint8_t *__restrict__ lit_scratch, uint32_t *__restrict__ queue)
+{
+    __shared__ MatchLds<14> L;
+    zge_match_body<14, 4, 10>(L, P, src_base, src_off, src_len, order, n_frames, block_prefix, blocks, seq_scratch, lit_scratch, queue);
 }
