@@ -1,9 +1,11 @@
 // zarc_amd/csrc/engine.hip -- host side of the C ABI declared in include/zarc_gpu.h.
 //
-// One handle owns one HIP stream on one device plus grow-only workspaces in HBM.  A batch call uploads
-// the small per-entry descriptors, launches the kernel chain on the stream, times each stage with HIP
-// events recorded on that same stream, and copies back only per-entry results (lengths, digests, status).
-// There is no CPU implementation behind this file: every data-path byte is touched by the gfx950 kernels.
+// One handle owns its HIP streams on one device (the engine stream plus two side streams for kernels and copies
+// that may overlap it) and grow-only workspaces in HBM.  A batch call uploads the small per-entry descriptors,
+// launches the kernel chain, times each stage with HIP events recorded on the stream the stage runs on, and copies
+// back only per-entry results (lengths, digests, status).  The host-pointer entry points add chunked staging through
+// a pinned ring with a few copy threads.  There is no CPU implementation of the codec behind this file: every
+// data-path byte is hashed, matched, coded and decoded by the gfx950 kernels.
 #include "../../include/zarc_gpu.h"
 #include "zarc_kernels.h"
 #include <algorithm>
