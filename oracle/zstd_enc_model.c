@@ -790,7 +790,7 @@ void zge_default_params(zge_params *P, int level)
     P->long_log = 13; P->short_log = 13; P->short_bytes = 5; P->tag_bits = 10; P->seg_log = 21; P->rep_back = 256;
     P->tile = 1024; P->sub = 64; P->cap = 256;
     P->min_match = 5; P->min_rep = 3; P->rep_search = 2;
-    P->back_cap = 8; P->lazy = 1; P->lazy_delta = 5;
+    P->back_cap = 8; P->lazy = level >= 2 || level == 0 ? 1 : 0; P->lazy_delta = 5; /* engine.hip: derive_params */
     P->lit_cost = 5; P->match_cost = 12; P->rep_cost = 9;
     P->window_log = 21; P->short_window_log = 30;
     if (level >= 9) { /* the engine's deep finder (engine.hip: derive_params) */

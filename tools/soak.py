@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Randomised soak of the whole path on a GPU box (not part of the test suite): random sizes / kinds / levels / checksum,
+GPU frames against the CPU model (bit-exact), every frame decoded by the oracle, by libzstd and by the GPU decoder, plus
+GPU decoding of libzstd's own frames of the same inputs (levels 1..19: Repeat-mode tables, treeless literals, long offsets).
+usage: soak.py [seconds] [seed]"""
+import os, random, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "support"))
+from zarc_amd import Engine, _lib
+import harness
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+oracle, corpus, zs = harness.Oracle(), harness.Corpus(), harness.libzstds()
+t_end = time.time() + budget
+rounds = frames = 0
+while time.time() < t_end:
+    level = rnd.choice([1, 3, 3, 9])
+    checksum = rnd.randrange(2)
+    eng = Engine(0)
+    eng.set_parameter(_lib.P_COMPRESSION_LEVEL, level)
+    eng.set_parameter(_lib.P_CHECKSUM_FLAG, checksum)
+    n = rnd.randrange(1, 40)
+    ents = []
+    for _ in range(n):
+        size = rnd.choice([0, 1, rnd.randrange(2, 400), rnd.randrange(400, 70000), rnd.randrange(70000, 600000), rnd.randrange(600000, 3 << 20)])
+        kind = rnd.randrange(4)
+        raw = corpus.entry(rnd.randrange(1 << 30), size, kind)
+        if rnd.randrange(6) == 0 and size > 64:      # long runs / repeated halves: RLE blocks, overlapping matches, long matches
+            raw = raw[:size // 3] + bytes([raw[0]]) * (size // 3) + raw[:size - 2 * (size // 3)]
+        ents.append(raw)
+    packed = eng.pack(ents)
+    for raw, (frame, dig) in zip(ents, packed):
+        assert dig == oracle.blake3(raw)
+        if len(raw) <= 700000:                        # the sequential model is slow: check the smaller ones bit for bit
+            p = oracle.params(level=level, checksum=checksum)
+            assert frame == oracle.zge_encode(raw, p), (level, checksum, len(raw))
+        st, out, used = oracle.zstd_decode(frame, len(raw))
+        assert st == 0 and out == raw and used == len(frame)
+        for z in zs:
+            assert z.decompress(frame, len(raw))[0] == raw
+    res = eng.unpack([f for f, _ in packed], [len(e) for e in ents], [d for _, d in packed])
+    for raw, (out, dig, st) in zip(ents, res):
+        assert st == 0 and out == raw
+    # libzstd's own frames through the GPU decoder
+    if zs:
+        z = rnd.choice(zs)
+        lv = rnd.choice([1, 3, 5, 9, 13, 19])
+        their = [z.compress(e, lv, rnd.randrange(2)) for e in ents]
+        res = eng.unpack(their, [len(e) for e in ents], [oracle.blake3(e) for e in ents])
+        for raw, (out, dig, st) in zip(ents, res):
+            assert st == 0 and out == raw, (z.version, lv, len(raw))
+    eng.close()
+    rounds += 1
+    frames += n
+print("soak ok: %d rounds, %d entries, %.0f s" % (rounds, frames, budget))
