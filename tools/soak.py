@@ -23,7 +23,8 @@ while time.time() < t_end:
     n = rnd.randrange(1, 40)
     ents = []
     for _ in range(n):
-        size = rnd.choice([0, 1, rnd.randrange(2, 400), rnd.randrange(400, 70000), rnd.randrange(70000, 600000), rnd.randrange(600000, 3 << 20)])
+        size = rnd.choice([0, 1, rnd.randrange(2, 400), rnd.randrange(400, 70000), rnd.randrange(70000, 600000), rnd.randrange(600000, 3 << 20),
+                           rnd.randrange(3 << 20, 20 << 20) if rnd.randrange(8) == 0 else rnd.randrange(100000, 200000)])
         kind = rnd.randrange(4)
         raw = corpus.entry(rnd.randrange(1 << 30), size, kind)
         if rnd.randrange(6) == 0 and size > 64:      # long runs / repeated halves: RLE blocks, overlapping matches, long matches
