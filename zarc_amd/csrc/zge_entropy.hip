@@ -476,7 +476,16 @@ __global__ void __launch_bounds__(64, 5) zarc_zge_entropy(uint32_t n_blocks, Zge
         const uint32_t raw_hdr = n < 32 ? 1u : (n < 4096 ? 2u : 3u);
         for (int i = lane; i < 256; i += 64) L.h.count[i] = 0;
         zd::wave_sync();
-        for (uint32_t i = (uint32_t)lane; i < n; i += 64) atomicAdd(&L.h.count[lit[i]], 1u);
+        { // literal buffers start 16-byte aligned: four bytes per load
+            const uint32_t n4 = n / 4;
+            const uint32_t *l4 = (const uint32_t *)lit;
+            for (uint32_t i = (uint32_t)lane; i < n4; i += 64) {
+                const uint32_t w = l4[i];
+                atomicAdd(&L.h.count[w & 0xFF], 1u); atomicAdd(&L.h.count[(w >> 8) & 0xFF], 1u);
+                atomicAdd(&L.h.count[(w >> 16) & 0xFF], 1u); atomicAdd(&L.h.count[w >> 24], 1u);
+            }
+            for (uint32_t i = n4 * 4 + (uint32_t)lane; i < n; i += 64) atomicAdd(&L.h.count[lit[i]], 1u);
+        }
         zd::wave_sync();
         ENT_PROF(0);
         uint32_t distinct = 0;
@@ -512,10 +521,11 @@ __global__ void __launch_bounds__(64, 5) zarc_zge_entropy(uint32_t n_blocks, Zge
                     if (k >= nstreams) break;
                     const uint32_t beg = k * per, cnt = single ? n : (k < 3 ? per : n - 3 * per);
                     pk.begin(L.stage, body + pos, out_cap - hdr - pos, lane);
-                    for (uint32_t j0 = 0; j0 < cnt; j0 += 64) {
-                        const uint32_t j = j0 + (uint32_t)lane;
+                    for (uint32_t j0 = 0; j0 < cnt; j0 += 128) { // two symbols per lane and step: half as many prefix sums / flushes
+                        const uint32_t j = j0 + 2 * (uint32_t)lane;
                         uint32_t cv = 0, cl_ = 0;
                         if (j < cnt) { const uint32_t e = L.code[lit[beg + cnt - 1 - j]]; cv = e & 0x7FF; cl_ = e >> 11; }
+                        if (j + 1 < cnt) { const uint32_t e = L.code[lit[beg + cnt - 2 - j]]; cv |= (e & 0x7FF) << cl_; cl_ += e >> 11; }
                         pk.put(cv, 0, cl_, lane);
                     }
                     ssz[k] = pk.finish(lane);
