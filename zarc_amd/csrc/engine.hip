@@ -643,8 +643,9 @@ int zarc_gpu_unpack_batch_device(zarc_gpu_t *h, size_t n, const void *d_frames_b
 // The caller's buffers are ordinary pageable memory, so hipMemcpyAsync blocks the calling thread while it stages the
 // bytes.  A helper thread therefore moves chunk c+1 in and chunk c-1 out (side stream) while this thread runs the
 // kernels of chunk c (engine stream); arenas are double-buffered, which also bounds the staging memory of huge batches.
-// Chunks are large (4 GiB of content): the kernels need thousands of frames in flight to fill the chip (a 1 MiB frame is
-// a ~10 ms serial chain for one workgroup / wave), measured: 256 MiB chunks halve the throughput.  SURVEY.md 8 row f4.
+// Chunks are large (2 GiB of content for pack, 4 GiB for unpack): the kernels need thousands of frames in flight to fill the
+// chip (a 1 MiB frame is a ~10 ms serial chain for one workgroup / wave), measured: 256 MiB chunks halve the throughput.
+// SURVEY.md 8 row f4.
 namespace {
 
 // A byte range of the caller's memory and where it sits in a flat device range
@@ -664,7 +665,9 @@ int pin_ring(zarc_gpu *h)
 void piece_copy(const std::vector<Seg> &segs, size_t first_seg, uint64_t lo, uint64_t hi, uint8_t *pinned, bool to_pinned)
 {
     unsigned nt = std::thread::hardware_concurrency();
-    nt = nt < 2 ? 1 : (nt > 8 ? 8 : nt);
+    unsigned want = 8; // ZARC_GPU_COPY_THREADS overrides
+    if (const char *e = getenv("ZARC_GPU_COPY_THREADS")) want = (unsigned)std::max(1, atoi(e));
+    nt = nt < 2 ? 1 : (nt > want ? want : nt);
     if (hi - lo < ((uint64_t)1 << 20)) nt = 1;
     auto work = [&](uint64_t a, uint64_t b) {
         for (size_t k = first_seg; k < segs.size() && segs[k].dev < b; k++) {
@@ -726,22 +729,23 @@ int staged_d2h(zarc_gpu *h, hipStream_t stream, const std::vector<Seg> &segs, co
 }
 
 // bytes of (uncompressed) content per chunk; ZARC_GPU_STAGE_CHUNK overrides it (tests force many small chunks)
-uint64_t stage_chunk()
+uint64_t stage_chunk(uint64_t dflt)
 {
     const char *e = getenv("ZARC_GPU_STAGE_CHUNK");
     const long long v = e ? atoll(e) : 0;
-    return v >= 4096 ? (uint64_t)v : (uint64_t)4 << 30;
+    return v >= 4096 ? (uint64_t)v : dflt;
 }
 
 struct Chunk { size_t i0, i1; uint64_t in_bytes, out_bytes; };
 
-// cut [0, n) into chunks of about stage_chunk() content bytes (at least one entry each)
+// cut [0, n) into chunks of about stage_chunk(default) content bytes (at least one entry each)
 bool stage_threaded() { const char *e = getenv("ZARC_GPU_STAGE_THREAD"); return !(e && atoi(e) == 0); }
 
-std::vector<Chunk> make_chunks(size_t n, const std::vector<uint64_t> &in_sz, const std::vector<uint64_t> &out_sz, const std::vector<uint64_t> &weight)
+std::vector<Chunk> make_chunks(size_t n, const std::vector<uint64_t> &in_sz, const std::vector<uint64_t> &out_sz, const std::vector<uint64_t> &weight,
+                               uint64_t dflt_chunk)
 {
     std::vector<Chunk> cs;
-    const uint64_t STAGE_CHUNK = stage_chunk();
+    const uint64_t STAGE_CHUNK = stage_chunk(dflt_chunk);
     size_t i = 0;
     while (i < n) {
         Chunk c{i, i, 0, 0};
@@ -793,7 +797,7 @@ int zarc_gpu_pack_batch(zarc_gpu_t *h, size_t n, const void *const *src, const s
         need += out_sz[i];
     }
     if (need > dst_cap) return ZARC_GPU_E_DSTSIZE;
-    const std::vector<Chunk> cs = make_chunks(n, in_sz, out_sz, in_sz);
+    const std::vector<Chunk> cs = make_chunks(n, in_sz, out_sz, in_sz, (uint64_t)2 << 30); // measured: 1-2 GiB chunks pack fastest (27 vs 23 GiB/s at 4 GiB)
     uint64_t max_in = 0, max_out = 0;
     for (const Chunk &c : cs) { max_in = std::max(max_in, c.in_bytes); max_out = std::max(max_out, c.out_bytes); }
     const uint64_t in_half = align_up(max_in + ZARC_GPU_PAD + 256, 256), out_half = align_up(max_out + ZARC_GPU_PAD, 256);
@@ -873,7 +877,7 @@ int zarc_gpu_unpack_batch(zarc_gpu_t *h, size_t n, const void *const *frame, con
         out_sz[i] = align_up(raw_len[i], ZARC_GPU_ALIGN);
         weight[i] = std::max(in_sz[i], out_sz[i]);
     }
-    const std::vector<Chunk> cs = make_chunks(n, in_sz, out_sz, weight);
+    const std::vector<Chunk> cs = make_chunks(n, in_sz, out_sz, weight, (uint64_t)4 << 30); // the decoder's lane-per-block stage wants many frames at once
     uint64_t max_in = 0, max_out = 0;
     for (const Chunk &c : cs) { max_in = std::max(max_in, c.in_bytes); max_out = std::max(max_out, c.out_bytes); }
     const uint64_t in_half = align_up(max_in + ZARC_GPU_PAD + 256, 256), out_half = align_up(max_out + ZARC_GPU_PAD + 256, 256);
