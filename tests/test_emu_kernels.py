@@ -66,3 +66,10 @@ def test_emu_level9_deep_finder_matches_model(emu_lib_path, oracle, corpus):
             assert dig == oracle.blake3(raw)
     finally:
         e9.close()
+
+
+def test_emu_sequence_stage_split_between_both_kernels(emu_engine, oracle, corpus, golden_frames, monkeypatch):
+    """ZARC_GPU_SEQ_LDS_FRAC sends part of the blocks to the sequence kernel that keeps its tables in LDS: same results."""
+    monkeypatch.setenv("ZARC_GPU_SEQ_LDS_FRAC", "0.5")
+    pc.check_unpack_golden(emu_engine, oracle, corpus, golden_frames)
+    pc.check_roundtrip(emu_engine, oracle, corpus, big=False)

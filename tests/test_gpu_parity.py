@@ -160,3 +160,10 @@ def test_gpu_pack_in_sub_batches(engine, oracle, corpus, libzstds, monkeypatch):
     monkeypatch.setenv("ZARC_GPU_SCRATCH_MB", "2")
     pc.check_pack(engine, oracle, corpus, libzstds, big=True)
     pc.check_roundtrip(engine, oracle, corpus, big=True)
+
+
+def test_gpu_sequence_stage_split_between_both_kernels(engine, oracle, corpus, golden_frames, monkeypatch):
+    monkeypatch.setenv("ZARC_GPU_SEQ_LDS_FRAC", "0.5")
+    pc.check_unpack_golden(engine, oracle, corpus, golden_frames)
+    pc.check_roundtrip(engine, oracle, corpus, big=True)
+    pc.check_unpack_fuzz(engine, oracle, corpus, golden_frames, 1500, seed=77)
