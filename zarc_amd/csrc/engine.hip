@@ -597,13 +597,22 @@ int zarc_gpu_unpack_batch_device(zarc_gpu_t *h, size_t n, const void *d_frames_b
         }
         if (side) { ZHIP(hipEventRecord(h->ev_join, h->stream2)); ZHIP(hipStreamWaitEvent(h->stream, h->ev_join, 0)); }
     }
-    ZHIP(hipMemsetAsync(h->d_queue.p, 0, 4, h->stream));
-    hipLaunchKernelGGL(zarc_zstd_decode, dim3((unsigned)dec_grid), dim3(64), getenv("ZARC_GPU_DEC_PADLDS") ? atoi(getenv("ZARC_GPU_DEC_PADLDS")) : 0, h->stream, (const uint8_t *)d_frames_base, h->d_frame_off.as<uint64_t>(),
-                       h->d_frame_len.as<uint64_t>(), (uint8_t *)d_dst_base, h->d_dst_off.as<uint64_t>(), h->d_raw_len.as<uint64_t>(),
-                       h->d_order.as<uint32_t>(), (uint32_t)n, h->d_declit.as<uint8_t>(), h->d_status.as<int32_t>(), h->d_stored_ck.as<uint32_t>(),
-                       getenv("ZARC_GPU_DBG_DEC") ? atoi(getenv("ZARC_GPU_DBG_DEC")) : 0, h->d_queue.as<uint32_t>(),
-                       fastpath ? h->d_fast.as<uint32_t>() : (const uint32_t *)nullptr, h->d_slot_prefix.as<uint64_t>(), h->d_zblocks.as<ZdecBlock>(),
-                       h->d_seqidx.as<uint64_t>(), h->d_seqs.as<uint64_t>(), h->d_litidx.as<uint64_t>(), h->d_lits.as<uint8_t>());
+    const int dec_dbg = getenv("ZARC_GPU_DBG_DEC") ? atoi(getenv("ZARC_GPU_DBG_DEC")) : 0;
+    ZHIP(hipMemsetAsync(h->d_queue.p, 0, 8, h->stream)); // two queues: the fast frame pass and the general decoder each walk all frames
+    if (fastpath) {
+        hipLaunchKernelGGL(zarc_zstd_frames, dim3((unsigned)dec_grid), dim3(64), 0, h->stream, (const uint8_t *)d_frames_base, h->d_frame_off.as<uint64_t>(),
+                           h->d_frame_len.as<uint64_t>(), (uint8_t *)d_dst_base, h->d_dst_off.as<uint64_t>(), h->d_raw_len.as<uint64_t>(),
+                           h->d_order.as<uint32_t>(), (uint32_t)n, h->d_status.as<int32_t>(), h->d_stored_ck.as<uint32_t>(), dec_dbg, h->d_queue.as<uint32_t>(),
+                           h->d_fast.as<uint32_t>(), h->d_slot_prefix.as<uint64_t>(), h->d_zblocks.as<ZdecBlock>(), h->d_seqidx.as<uint64_t>(),
+                           h->d_seqs.as<uint64_t>(), h->d_litidx.as<uint64_t>(), h->d_lits.as<uint8_t>());
+        ZHIP(hipGetLastError());
+    }
+    // frames the fast path turned down (or all of them when it is off) are decoded inline; with nothing to do every wave leaves at once
+    hipLaunchKernelGGL(zarc_zstd_decode, dim3((unsigned)dec_grid), dim3(64), getenv("ZARC_GPU_DEC_PADLDS") ? atoi(getenv("ZARC_GPU_DEC_PADLDS")) : 0, h->stream,
+                       (const uint8_t *)d_frames_base, h->d_frame_off.as<uint64_t>(), h->d_frame_len.as<uint64_t>(), (uint8_t *)d_dst_base,
+                       h->d_dst_off.as<uint64_t>(), h->d_raw_len.as<uint64_t>(), h->d_order.as<uint32_t>(), (uint32_t)n, h->d_declit.as<uint8_t>(),
+                       h->d_status.as<int32_t>(), h->d_stored_ck.as<uint32_t>(), dec_dbg, h->d_queue.as<uint32_t>() + 1,
+                       fastpath ? h->d_fast.as<uint32_t>() : (const uint32_t *)nullptr);
     ZHIP(hipGetLastError());
     ZHIP(t.mark(&e1));
     // verification passes over the decoded bytes (K2 + XXH64 inside libzstd in the reference)

@@ -69,7 +69,11 @@ __global__ void zarc_xxh64(const uint8_t *base, const uint64_t *off, const uint6
 __global__ void zarc_zstd_decode(const uint8_t *frames_base, const uint64_t *frame_off, const uint64_t *frame_len, uint8_t *dst_base,
                                  const uint64_t *dst_off, const uint64_t *raw_len, const uint32_t *order, uint32_t n_frames,
                                  uint8_t *lit_scratch, int32_t *status, uint32_t *stored_checksum, int dbg, uint32_t *queue,
-                                 const uint32_t *fast /* per frame: sequences are pre-decoded; may be null */, const uint64_t *slot_prefix,
+                                 const uint32_t *fast /* per frame: handled by zarc_zstd_frames; null = take every frame */);
+// frame pass of the decoder fast path: frames whose sequences and literals were decoded ahead (fast[f] != 0)
+__global__ void zarc_zstd_frames(const uint8_t *frames_base, const uint64_t *frame_off, const uint64_t *frame_len, uint8_t *dst_base,
+                                 const uint64_t *dst_off, const uint64_t *raw_len, const uint32_t *order, uint32_t n_frames, int32_t *status,
+                                 uint32_t *stored_checksum, int dbg, uint32_t *queue, const uint32_t *fast, const uint64_t *slot_prefix,
                                  const ZdecBlock *zblocks, const uint64_t *seq_index, const uint64_t *seqs, const uint64_t *lit_index,
                                  const uint8_t *lits);
 __global__ void zarc_gather(const uint8_t *src_base, const uint64_t *src_off, const uint64_t *len, const uint64_t *dense_off, uint32_t n, uint8_t *dst);

@@ -363,6 +363,12 @@ __device__ __forceinline__ void lane_stage32(uint8_t *d, const uint8_t *s, uint3
     } else if (n == 1) d[0] = s[0];
 }
 
+// LDS -> LDS, n <= 32, ranges do not overlap: same head/tail scheme
+__device__ __forceinline__ void lane_move32(uint8_t *d, const uint8_t *s, uint32_t n)
+{
+    lane_stage32(d, s, n);
+}
+
 // Huffman tree description -> weights in LDS, returns bytes consumed (or -1); lane-serial part on lane 0.
 __device__ int huf_read_weights(Lds &L, const uint8_t *src, uint32_t len, int lane, int *nweights)
 {
@@ -615,16 +621,18 @@ __device__ int build_seq_table(uint16_t *tab, int t, uint32_t mode, const uint8_
 } // namespace
 
 // One wave (64-thread workgroup) per frame.  order[] lists frame indices, largest first.
-// one frame, one wave
+// one frame, one wave.  PRE: the frame's sequences and literals were decoded ahead (fast path); the two instantiations live in
+// two kernels so that the fast one does not carry the registers of the inline decoder.
+template <bool PRE>
 __device__ __forceinline__ void decode_frame(Lds &L, const int lane, const uint32_t f, uint8_t *__restrict__ lit_buf,
                                              const uint8_t *__restrict__ frames_base, const uint64_t *__restrict__ frame_off,
                                              const uint64_t *__restrict__ frame_len, uint8_t *__restrict__ dst_base,
                                              const uint64_t *__restrict__ dst_off, const uint64_t *__restrict__ raw_len,
                                              int32_t *__restrict__ status, uint32_t *__restrict__ stored_checksum, const int dbg,
-                                             const bool use_pre /* sequences of every block are in seqs[] (fast path) */,
                                              const ZdecBlock *__restrict__ fblocks, const uint64_t *__restrict__ fseq_index,
                                              const uint64_t *__restrict__ seqs, const uint64_t *__restrict__ flit_index, const uint8_t *__restrict__ lits)
 {
+    constexpr bool use_pre = PRE;
     const uint8_t *src = frames_base + frame_off[f];
     const uint32_t slen = (uint32_t)frame_len[f];
     uint8_t *out = dst_base + dst_off[f];
@@ -829,7 +837,7 @@ __device__ __forceinline__ void decode_frame(Lds &L, const int lane, const uint3
                 const uint32_t cnt = nseq - base < SEQ_BATCH ? nseq - base : SEQ_BATCH;
                 if (dbg & 2) continue;
                 uint32_t p_ll = 0, p_ml = 0, p_off = 1;
-                if (pre) {
+                if (PRE) {
                     // every lane fetches its sequence; stage 2 already resolved the offset as far as the block alone allows, what is
                     // left refers to the history at the start of the block (rep0..2 stay fixed during a pre-decoded block)
                     bool pbad = false;
@@ -883,8 +891,8 @@ __device__ __forceinline__ void decode_frame(Lds &L, const int lane, const uint3
                 // are independent unless a match source reaches into this batch's own output ("near" matches) ----
                 {
                     const bool have = (uint32_t)lane < cnt;
-                    const uint32_t ll = !have ? 0u : (pre ? p_ll : L.seq[lane * 3]), ml = !have ? 0u : (pre ? p_ml : L.seq[lane * 3 + 1]);
-                    const uint32_t offset = !have ? 1u : (pre ? p_off : L.seq[lane * 3 + 2]);
+                    const uint32_t ll = !have ? 0u : (PRE ? p_ll : L.seq[lane * 3]), ml = !have ? 0u : (PRE ? p_ml : L.seq[lane * 3 + 1]);
+                    const uint32_t offset = !have ? 1u : (PRE ? p_off : L.seq[lane * 3 + 2]);
                     const uint32_t incl_ll = zd::wave_scan_incl(ll), incl_all = zd::wave_scan_incl(ll + ml);
                     const uint32_t tot_ll = zd::uniform(zd::shfl(incl_ll, 63)), tot_all = zd::uniform(zd::shfl(incl_all, 63));
                     if (lp + tot_ll > lit_len) { err = ZARC_FRAME_CORRUPT; break; }
@@ -896,14 +904,14 @@ __device__ __forceinline__ void decode_frame(Lds &L, const int lane, const uint3
                     if (zd::ballot(have && offset > dmat) != 0) { err = ZARC_FRAME_CORRUPT; break; }
                     const uint32_t msrc = dmat - offset;
                     const bool far = have && msrc + ml <= bpos;                // source entirely below this batch's output
-                    if (!(dbg & 1) && pre && tot_all <= OBUF) {
+                    if (!(dbg & 1) && PRE && tot_all <= OBUF) {
                         // ---- fast path: the batch's output is put together in LDS, then written out as whole lines ----
                         uint8_t *const ob = L.obuf;
                         const uint32_t o_lit = dlit - bpos, o_mat = dmat - bpos;
                         // (1) literal runs and (2) far matches (sources below this batch's output): independent of each other
                         if (lit_rle) { for (uint32_t r = 0; r < ll; r++) ob[o_lit + r] = lit_rle_byte; }
-                        else if (ll <= 32) lane_stage32(ob + o_lit, lit + slit, ll);
-                        if (far && ml <= 32) lane_stage32(ob + o_mat, out + msrc, ml);
+                        else if (ll <= 32 && !(dbg & 32)) lane_stage32(ob + o_lit, lit + slit, ll);
+                        if (far && ml <= 32 && !(dbg & 64)) lane_stage32(ob + o_mat, out + msrc, ml);
                         uint64_t longs = lit_rle ? 0ull : zd::ballot(ll > 32);
                         while (longs) {
                             const int i = zd::ctz64(longs);
@@ -919,8 +927,29 @@ __device__ __forceinline__ void decode_frame(Lds &L, const int lane, const uint3
                             for (uint32_t k = (uint32_t)lane; k < n_; k += 64) ob[d_ + k] = out[s_ + k];
                         }
                         zd::wave_sync();
-                        // (3) near matches in order: their sources are bytes of this batch (LDS) or, below its start, earlier output
-                        uint64_t near = zd::ballot(have && !far);
+                        // (3a) near matches whose source touches no other near match's output run together, one lane each.  Outputs are
+                        // ordered like the lanes, so "the near matches that start below my source's end" is a lane count (binary search
+                        // over the match positions) and only the last of them can reach up to my source's start.
+                        uint64_t near = (dbg & 8) ? 0ull : zd::ballot(have && !far);
+                        if (near && !(dbg & 128)) {
+                            const int32_t s_rel = (int32_t)o_mat - (int32_t)offset;   // source start relative to the batch
+                            const uint32_t s_end = (uint32_t)s_rel + ml;              // meaningful when s_rel >= 0
+                            const bool cand = have && !far && s_rel >= 0 && offset >= ml && ml <= 32;
+                            uint32_t jb = 0;                                          // lanes whose match starts below s_end
+#pragma unroll
+                            for (uint32_t step = 32; step; step >>= 1) {
+                                const uint32_t probe = zd::shfl(o_mat, (int)((jb + step - 1) & 63));
+                                if (probe < s_end) jb += step;
+                            }
+                            if (zd::shfl(o_mat, 63) < s_end) jb = 64;
+                            const uint64_t before = jb >= 64 ? near : (near & ((1ull << jb) - 1));
+                            const uint32_t last_end = zd::shfl(o_mat + ml, before ? 63 - __clzll((long long)before) : 0);
+                            const bool indep = cand && (before == 0 || last_end <= (uint32_t)s_rel);
+                            const uint64_t im = zd::ballot(indep);
+                            if (indep) lane_move32(ob + o_mat, ob + s_rel, ml);
+                            if (im) { zd::wave_sync(); near &= ~im; }
+                        }
+                        // (3b) the rest in order: their sources are bytes of this batch (LDS) or, below its start, earlier output
                         while (near) {
                             const int i = zd::ctz64(near);
                             near &= near - 1;
@@ -935,7 +964,7 @@ __device__ __forceinline__ void decode_frame(Lds &L, const int lane, const uint3
                             zd::wave_sync();
                         }
                         // (4) the finished bytes leave LDS 16 per lane
-                        for (uint32_t k = (uint32_t)lane * 16; k < tot_all; k += 64 * 16) {
+                        for (uint32_t k = (uint32_t)lane * 16; k < tot_all && !(dbg & 16); k += 64 * 16) {
                             if (k + 16 <= tot_all) { struct { uint64_t a, b; } v; __builtin_memcpy(&v, ob + k, 16); __builtin_memcpy(out + bpos + k, &v, 16); }
                             else for (uint32_t r = k; r < tot_all; r++) out[bpos + r] = ob[r];
                         }
@@ -996,7 +1025,7 @@ __device__ __forceinline__ void decode_frame(Lds &L, const int lane, const uint3
                 zd::wave_sync(); // L.seq is rewritten by lane 0 in the next batch
             }
             if (err) break;
-            if (pre) { // history after the block, from stage 2's symbolic summary
+            if (PRE) { // history after the block, from stage 2's symbolic summary
                 const ZdecBlock zb = fblocks[my_b];
                 uint32_t nr[3];
 #pragma unroll
@@ -1008,7 +1037,7 @@ __device__ __forceinline__ void decode_frame(Lds &L, const int lane, const uint3
                 rep0 = nr[0]; rep1 = nr[1]; rep2 = nr[2];
             }
             bool endok = true;
-            if (lane == 0 && !pre) endok = b.bitpos == 0;
+            if (lane == 0 && !PRE) endok = b.bitpos == 0;
             if (zd::ballot(!endok) != 0) { err = ZARC_FRAME_CORRUPT; break; }
         } else if (srem != 0) { err = ZARC_FRAME_CORRUPT; break; }
         // trailing literals
@@ -1038,7 +1067,8 @@ __device__ __forceinline__ void decode_frame(Lds &L, const int lane, const uint3
 
 // Persistent waves: the grid is sized to what the chip holds at once and every wave takes the next frame from a
 // queue (frames are ordered largest first), so slow and fast frames balance across XCDs whatever their order.
-// Every wave leaves as soon as the queue is empty.
+// Every wave leaves as soon as the queue is empty.  zarc_zstd_decode is the general kernel (everything decoded inline);
+// when the fast path is on it only takes the frames stage 1/2 turned down, and zarc_zstd_frames takes the others.
 __global__ void __launch_bounds__(64, 5) zarc_zstd_decode(const uint8_t *__restrict__ frames_base, const uint64_t *__restrict__ frame_off,
                                                        const uint64_t *__restrict__ frame_len, uint8_t *__restrict__ dst_base,
                                                        const uint64_t *__restrict__ dst_off, const uint64_t *__restrict__ raw_len,
@@ -1046,10 +1076,7 @@ __global__ void __launch_bounds__(64, 5) zarc_zstd_decode(const uint8_t *__restr
                                                        uint8_t *__restrict__ lit_scratch /* one block per resident wave */, int32_t *__restrict__ status,
                                                        uint32_t *__restrict__ stored_checksum /* 2 words/frame: has, value */,
                                                        int dbg /* timing-only ablations: 1 no copies, 2 no sequence decode, 4 no Huffman decode */,
-                                                       uint32_t *__restrict__ queue, const uint32_t *__restrict__ fast,
-                                                       const uint64_t *__restrict__ slot_prefix, const ZdecBlock *__restrict__ zblocks,
-                                                       const uint64_t *__restrict__ seq_index, const uint64_t *__restrict__ seqs,
-                                                       const uint64_t *__restrict__ lit_index, const uint8_t *__restrict__ lits)
+                                                       uint32_t *__restrict__ queue, const uint32_t *__restrict__ fast /* null: take every frame */)
 {
     __shared__ Lds L;
     const int lane = zd::lane_id();
@@ -1060,11 +1087,38 @@ __global__ void __launch_bounds__(64, 5) zarc_zstd_decode(const uint8_t *__restr
         slot = zd::uniform(slot); // lane 0 is the first active lane
         if (slot >= n_frames) break;
         const uint32_t f = order[slot];
-        const bool use_pre = fast != nullptr && zd::uniform(fast[f]) != 0;
-        const uint64_t first = use_pre ? slot_prefix[f] : 0;
-        decode_frame(L, lane, f, lit_buf, frames_base, frame_off, frame_len, dst_base, dst_off, raw_len, status, stored_checksum, dbg, use_pre,
-                     zblocks + first, seq_index + first, seqs, lit_index + first, lits);
+        if (fast != nullptr && zd::uniform(fast[f]) != 0) continue; // zarc_zstd_frames has it
+        decode_frame<false>(L, lane, f, lit_buf, frames_base, frame_off, frame_len, dst_base, dst_off, raw_len, status, stored_checksum, dbg, nullptr, nullptr,
+                            nullptr, nullptr, nullptr);
         zd::wave_sync_global(); // LDS tables and the literal buffer are reused by the next frame
+    }
+}
+
+// The frame pass of the fast path: same queue discipline, frames whose sequences and literals were decoded ahead.
+__global__ void __launch_bounds__(64, 5) zarc_zstd_frames(const uint8_t *__restrict__ frames_base, const uint64_t *__restrict__ frame_off,
+                                                       const uint64_t *__restrict__ frame_len, uint8_t *__restrict__ dst_base,
+                                                       const uint64_t *__restrict__ dst_off, const uint64_t *__restrict__ raw_len,
+                                                       const uint32_t *__restrict__ order, uint32_t n_frames, int32_t *__restrict__ status,
+                                                       uint32_t *__restrict__ stored_checksum,
+                                                       int dbg /* timing-only ablations: 1 no copies; 8 no near matches, 16 no flush, 32 no literal staging, 64 no far-match staging, 128 all near matches in order */,
+                                                       uint32_t *__restrict__ queue, const uint32_t *__restrict__ fast,
+                                                       const uint64_t *__restrict__ slot_prefix, const ZdecBlock *__restrict__ zblocks,
+                                                       const uint64_t *__restrict__ seq_index, const uint64_t *__restrict__ seqs,
+                                                       const uint64_t *__restrict__ lit_index, const uint8_t *__restrict__ lits)
+{
+    __shared__ Lds L;
+    const int lane = zd::lane_id();
+    for (;;) {
+        uint32_t slot = 0;
+        if (lane == 0) slot = atomicAdd(queue, 1u);
+        slot = zd::uniform(slot);
+        if (slot >= n_frames) break;
+        const uint32_t f = order[slot];
+        if (zd::uniform(fast[f]) == 0) continue; // zarc_zstd_decode has it
+        const uint64_t first = slot_prefix[f];
+        decode_frame<true>(L, lane, f, nullptr, frames_base, frame_off, frame_len, dst_base, dst_off, raw_len, status, stored_checksum, dbg,
+                           zblocks + first, seq_index + first, seqs, lit_index + first, lits);
+        zd::wave_sync_global(); // the LDS staging buffer is reused by the next frame
     }
 }
 
