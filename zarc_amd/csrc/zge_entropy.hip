@@ -300,7 +300,7 @@ __device__ int huf_build_lengths(EntLds &L, int lane)
         }
         L.h.depth[2 * n - 2] = 0;
         for (int i = 2 * n - 3; i >= 0; i--) { const int d = L.h.depth[L.h.parent[i]] + 1; L.h.depth[i] = (uint8_t)(d > 63 ? 63 : d); }
-        int num[64];
+        int *const num = (int *)&L.h.w[0]; // the merge weights are dead from here on; a local array would live in scratch (HBM)
         for (int k = 0; k < 64; k++) num[k] = 0;
         for (int i = 0; i < n; i++) num[L.h.depth[i]]++;
         for (int k = HUF_MAXBITS + 1; k < 64; k++) { num[HUF_MAXBITS] += num[k]; num[k] = 0; }
@@ -323,7 +323,7 @@ __device__ void huf_assign_codes(EntLds &L)
 {
     int maxlen = 0, last = 0;
     for (int i = 0; i < 256; i++) if (L.h.len8[i]) { if (L.h.len8[i] > maxlen) maxlen = L.h.len8[i]; last = i; }
-    uint32_t rank_start[16], rank_count[16];
+    uint32_t *const rank_start = &L.h.w[64], *const rank_count = &L.h.w[80]; // LDS, not scratch (w[] is free after the tree is built)
     for (int w = 0; w < 16; w++) rank_count[w] = 0;
     for (int i = 0; i < 256; i++) if (L.h.len8[i]) rank_count[maxlen + 1 - L.h.len8[i]]++;
     uint32_t pos = 0;
