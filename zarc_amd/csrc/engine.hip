@@ -355,6 +355,9 @@ int zarc_gpu_pack_batch_device(zarc_gpu_t *h, size_t n, const void *d_src_base, 
     if (n == 0) return ZARC_GPU_OK;
     if (!d_src_base || !src_off || !src_len || !d_dst || !dst_off || !dst_len || !digest) return ZARC_GPU_E_PARAM;
     const ZgeParams P = derive_params(h->params);
+    // the match finder has these compiled in (zge_match.hip: F_*)
+    if (P.rep_back != 256 || P.back_cap != 8 || P.lazy_delta != 5 || P.min_rep != 3 || P.rep_search != 2 || P.seg_log != 21 || P.short_window_log < 30 ||
+        P.lit_cost != 5 || P.rep_cost != 9 || P.tag_bits != 10) { h->last_error = "internal: encoder parameters differ from the compiled-in ones"; return ZARC_GPU_E_PARAM; }
     uint64_t need = 0;
     for (size_t i = 0; i < n; i++) {
         if (src_off[i] % ZARC_GPU_ALIGN) { h->last_error = "entry offset not 16-byte aligned"; return ZARC_GPU_E_PARAM; }

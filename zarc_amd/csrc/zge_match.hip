@@ -83,6 +83,9 @@ __device__ __forceinline__ uint32_t hash_short(uint64_t v, int bits, int nbytes)
 // Bit-cost model (lit_cost 5, match_cost 12, rep_cost 9: the engine's fixed defaults, so the literal cost is a
 // shift-add instead of a quarter-rate multiply; engine.hip: derive_params() sets exactly these, they are not tunable).
 constexpr int LIT_COST = 5, REP_COST = 9;
+// Parameters of the model that the engine never varies (engine.hip: derive_params sets exactly these and checks them before a
+// launch): as constants they cost no scalar registers -- the kernel keeps about a hundred uniform values alive and spills them.
+constexpr int F_REP_BACK = 256, F_BACK_CAP = 8, F_LAZY_DELTA = 5, F_MIN_REP = 3, F_SEG_LOG = 21; // rep_search 2, short window unlimited
 template <int MATCH_COST> __device__ __forceinline__ int32_t score_mc(uint32_t len, uint32_t off, bool is_rep)
 {
     const int32_t lits = (int32_t)((len << 2) + len);
@@ -104,7 +107,8 @@ struct StageWin { const uint32_t *w; int ndw; uint32_t wofs; };
 static_assert((TB_BYTES + 3) / 4 <= THREADS, "one staged dword per thread");
 __device__ __forceinline__ StageWin stage_window(const ZgeParams &P, const uint8_t *src, uint32_t n, uint32_t tile, uint32_t tend, uint32_t cap_max)
 {
-    const uint32_t before = (uint32_t)(P.rep_back < REP_BACK_MAX ? P.rep_back : REP_BACK_MAX) + 8;
+    (void)P;
+    const uint32_t before = (uint32_t)F_REP_BACK + 8;
     const uint32_t lo = tile >= before ? tile - before : 0;
     uint32_t hi = tend + cap_max + 16;
     if (hi > n + 16) hi = n + 16; // the arena is padded by ZARC_GPU_PAD
@@ -130,7 +134,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
     const int tid = (int)threadIdx.x, lane = zd::lane_id();
     const int wave = (int)zd::uniform((uint32_t)zd::wave_id()); // scalar: chunk bounds and the parse walk stay on the SALU
     const uint64_t lt = (1ull << lane) - 1;
-    const uint32_t seg_mask = (1u << P.seg_log) - 1;
+    const uint32_t seg_mask = (1u << F_SEG_LOG) - 1;
     const uint32_t cap_max = (uint32_t)(P.cap < CAP_MAX ? P.cap : CAP_MAX);
     unsigned long long tprev = ZGE_CLOCK();
     if (tid < 12) L.prof[tid] = 0;
@@ -296,7 +300,6 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
                 }
                 offs[u][0] = c0 ? p - (c0 - 1) : 0u;
                 offs[u][1] = (c1 && c1 != c0) ? p - (c1 - 1) : 0u;
-                if (P.short_window_log < 32 && offs[u][1] > (1u << P.short_window_log)) offs[u][1] = 0;
 #pragma unroll
                 for (int k = 0; k < 2; k++) // the source needs 8 bytes in front of it (frame positions 0..7 are not used as sources)
                     if (offs[u][k] + 8 > p || offs[u][k] > window || idx >= tcount || (P.dbg & 1)) offs[u][k] = 0;
@@ -312,8 +315,8 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
             // guess won), 0 = none; equal lengths keep the first.
             uint32_t rres[PER];
             {
-                const bool use0 = P.rep_search > 0 && erep0 != 0 && erep0 <= window;
-                const bool use1 = P.rep_search > 1 && erep1 != 0 && erep1 != erep0 && erep1 <= window;
+                const bool use0 = erep0 != 0 && erep0 <= window;
+                const bool use1 = erep1 != 0 && erep1 != erep0 && erep1 <= window;
 #pragma unroll
                 for (int u = 0; u < PER; u++) {
                     const uint32_t idx = ZGE_IDX(u);
@@ -323,7 +326,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
 #pragma unroll
                     for (int k = 0; k < 2; k++) {
                         const uint32_t off = k == 0 ? erep0 : erep1;
-                        if (!(k == 0 ? use0 : use1) || off > idx + (uint32_t)P.rep_back || off > p || idx >= tcount || (P.dbg & 1)) continue;
+                        if (!(k == 0 ? use0 : use1) || off > idx + (uint32_t)F_REP_BACK || off > p || idx >= tcount || (P.dbg & 1)) continue;
                         uint64_t x = zd::load_u64(tbb + (uint32_t)(p - off + wofs)) ^ p8[u];
                         uint32_t len = 0;
                         while (!x && len + 8 < cap) {
@@ -332,7 +335,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
                         }
                         len += x ? (uint32_t)(zd::ctz64(x) >> 3) : 8u;
                         if (len > cap) len = cap;
-                        if (len >= (uint32_t)P.min_rep && len > (res & 0x1FFu)) res = len | ((uint32_t)k << 9);
+                        if (len >= (uint32_t)F_MIN_REP && len > (res & 0x1FFu)) res = len | ((uint32_t)k << 9);
                     }
                     rres[u] = res;
                 }
@@ -362,7 +365,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
                     }
                     len += x ? (uint32_t)(zd::ctz64(x) >> 3) : 8u;
                     if (len > cap) len = cap;
-                    if (len < (uint32_t)(is_rep ? P.min_rep : P.min_match)) continue;
+                    if (len < (uint32_t)(is_rep ? F_MIN_REP : P.min_match)) continue;
                     const int32_t sc = score_of(P, len, off, is_rep);
                     if (sc > best_score) { best_score = sc; best_len = len; best_off = off; best_rep = is_rep; best_before = q16[u][k].lo; }
                 }
@@ -378,7 +381,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
                 if (best_len && best_score > 0) {
                     // backward-extension potential: equal bytes just before the match and its source (none next to the frame start)
                     const uint32_t q = p - best_off;
-                    uint32_t maxb = (uint32_t)P.back_cap;
+                    uint32_t maxb = (uint32_t)F_BACK_CAP;
                     if (p - bs < maxb) maxb = (uint32_t)(p - bs);
                     uint32_t back = 0;
                     if (maxb && q >= 8) { // then p - 8 and (for a guess) q - 8 are inside the staged window
@@ -460,7 +463,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
                 if (take[u] && P.lazy && idx + 1 < tcount) {
                     const uint32_t m2 = L.a1[idx + 1];
                     const uint32_t l2 = match_len(m2);
-                    if (l2 && score_of(P, l2, match_off(m2), match_rep(m2)) > score_of(P, my_len, mo[u], (mw[u] >> 24) & 1) + P.lazy_delta) take[u] = false;
+                    if (l2 && score_of(P, l2, match_off(m2), match_rep(m2)) > score_of(P, my_len, mo[u], (mw[u] >> 24) & 1) + F_LAZY_DELTA) take[u] = false;
                 }
                 nx[u] = take[u] ? idx + my_len : idx + 1;
             }
