@@ -50,6 +50,15 @@ __device__ __forceinline__ void lds_barrier()
 #endif
 }
 
+// Issue priority of this wave (s_setprio, 0..3).  A serial section that the rest of the workgroup waits for (a few waves
+// working while the others sit at a barrier) competes for issue slots with the co-resident workgroup: raise it there.
+template <int PRIO> __device__ __forceinline__ void wave_priority()
+{
+#ifndef ZARC_HIPEMU
+    __builtin_amdgcn_s_setprio(PRIO);
+#endif
+}
+
 // Same for global-memory hand-offs between lanes of one wave (store -> fence -> load by another lane):
 // the release/acquire pair at workgroup scope waits for the stores (s_waitcnt vmcnt(0)); all waves of
 // a workgroup share the CU's vector L1, so no cache maintenance is involved.

@@ -251,6 +251,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
             // ---- S2: ordered lookup + insert (wave 0); no waits between the steps on hardware ----
             // The two tables are independent: wave 0 owns the long table, wave 1 the short one.
             if (wave < 2 && !(P.dbg & 4)) {
+                zd::wave_priority<3>(); // the other six waves wait for these two: go ahead of the co-resident workgroup
                 uint32_t *tab = wave == 0 ? L.tl : L.ts;
                 uint32_t *hc = wave == 0 ? L.a0 : L.a1; // hashes in, candidates out
                 uint32_t h[CHUNKS], e[CHUNKS];
@@ -277,6 +278,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
 #pragma unroll
                 for (int k = 0; k < CHUNKS; k++) // table entry with its check bits cancelled: a hit has zero low bits and is non-zero
                     hc[k * 64 + lane] = e[k] ^ (h[k] & TAG_MASK);
+                zd::wave_priority<0>();
             }
             zd::lds_barrier();
             ZGE_PROF(3);
@@ -496,6 +498,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
             // ---- S6b/c + S7: chunk entries by a chain through ex[], path marks per chunk, emission ----
             uint64_t msel[PER], mlit[PER];
             {
+                zd::wave_priority<2>(); // a serial chain (LDS hops, then a scalar walk): latency matters here, not throughput
                 uint32_t cur = (uint32_t)((pos > tile ? pos : tile) - tile);
                 int c = 0;
 #pragma unroll
@@ -535,6 +538,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
                 }
                 // the wave that owns the last chunk knows where the path leaves the tile
                 if (wave == WAVES - 1 && lane == 0) L.ctrl[K_POS] = (uint32_t)(tile - bs) + cur;
+                zd::wave_priority<0>();
             }
             zd::lds_barrier();
             ZGE_PROF(7);
