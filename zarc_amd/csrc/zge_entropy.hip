@@ -645,14 +645,18 @@ __global__ void __launch_bounds__(64, 5) zarc_zge_entropy(uint32_t n_blocks, Zge
                 atomicAdd(&L.s.co[zd::hb32(zge_seq_ofv(s))], 1u);
             }
             zd::wave_sync();
-            if (lane == 0) {
-                choose_table(L, 0, L.s.cl, 35, nseq, E_LL_DEFAULT, 36, 6, 9);
-                choose_table(L, 1, L.s.co, 31, nseq, E_OF_DEFAULT, 29, 5, 8);
-                choose_table(L, 2, L.s.cm, 52, nseq, E_ML_DEFAULT, 53, 6, 9);
-                FseCtab tl_ = {L.s.st_ll, L.s.dnb_ll, L.s.dfs_ll, 0}, to_ = {L.s.st_of, L.s.dnb_of, L.s.dfs_of, 0}, tm_ = {L.s.st_ml, L.s.dnb_ml, L.s.dfs_ml, 0};
-                if (L.ctrl[X_MODE_L] != 1) fse_build_ctab(tl_, L.s.norm[0], L.ctrl[X_NSYM_L], L.ctrl[X_AL_L], L.cellsym);
-                if (L.ctrl[X_MODE_O] != 1) fse_build_ctab(to_, L.s.norm[1], L.ctrl[X_NSYM_O], L.ctrl[X_AL_O], L.cellsym);
-                if (L.ctrl[X_MODE_M] != 1) fse_build_ctab(tm_, L.s.norm[2], L.ctrl[X_NSYM_M], L.ctrl[X_AL_M], L.cellsym);
+            if (lane < 3) {
+                // the three tables are independent: lane 0 chooses and builds LL, lane 1 OF, lane 2 ML side by side (the wave issues
+                // the longest of the three instead of their sum).  The cell scratch of each build lies in pre[], idle until the chains.
+                const int which = lane;
+                const uint32_t *cnt = which == 0 ? L.s.cl : (which == 1 ? L.s.co : L.s.cm);
+                const int16_t *def = which == 0 ? E_LL_DEFAULT : (which == 1 ? E_OF_DEFAULT : E_ML_DEFAULT);
+                choose_table(L, which, cnt, which == 0 ? 35 : (which == 1 ? 31 : 52), nseq, def, which == 0 ? 36 : (which == 1 ? 29 : 53),
+                             which == 1 ? 5 : 6, which == 1 ? 8 : 9);
+                FseCtab tt = which == 0 ? FseCtab{L.s.st_ll, L.s.dnb_ll, L.s.dfs_ll, 0}
+                                        : (which == 1 ? FseCtab{L.s.st_of, L.s.dnb_of, L.s.dfs_of, 0} : FseCtab{L.s.st_ml, L.s.dnb_ml, L.s.dfs_ml, 0});
+                uint8_t *cells = (uint8_t *)L.s.pre + (which == 0 ? 0 : (which == 1 ? 512 : 768)); // 512 + 256 + 512 bytes
+                if (L.ctrl[X_MODE_L + which] != 1) fse_build_ctab(tt, L.s.norm[which], L.ctrl[X_NSYM_L + which], L.ctrl[X_AL_L + which], cells);
             }
             zd::wave_sync();
             ENT_PROF(4);
