@@ -609,6 +609,11 @@ typedef struct {
     uint32_t *next;          /* per-tile successor of each position on the parse path */
     uint8_t *take, *mark;
     zge_stats *st;
+    /* Cold stretches (incompressible data): `cold` counts the searched tiles in a row in which no position found a match;
+     * from the second one on, the next 1, 3, then 7 tiles are not searched at all (all literals, nothing inserted), the way
+     * libzstd's search step grows while it finds nothing.  Any match in a searched tile ends the stretch.  The state lives
+     * for the whole frame. */
+    uint32_t cold, skip_left;
 } mf_ctx;
 
 /* Resolve explicit offsets against the repcode history (RFC 8878 3.1.1.5).  The history starts UNKNOWN
@@ -653,6 +658,12 @@ static uint32_t matchfind_block(mf_ctx *c, size_t bs, size_t be, zge_seq *seq, u
         /* Table entries hold (position inside the current 2^seg_log segment + 1) << tag_bits | tag; the frame loop
          * clears the tables at every segment boundary. */
         if (pos >= tend) continue; /* whole tile already covered by a match: skip it (nothing is inserted) */
+        if (c->skip_left) { /* cold stretch: this tile is not searched */
+            c->skip_left--;
+            for (t = (uint32_t)((pos > tile ? pos : tile) - tile); t < tcount; t++) lit[lp++] = src[tile + t];
+            pos = tend;
+            continue;
+        }
         /* S2: ordered lookup + insert, 64 positions at a time (lookups of a group see inserts of earlier groups).
          * The extra tag bits of the hash reject most false candidates without touching memory. */
         for (sub = tile; sub < tend; sub += (size_t)P->sub) {
@@ -716,6 +727,15 @@ static uint32_t matchfind_block(mf_ctx *c, size_t bs, size_t be, zge_seq *seq, u
                     while (back < (uint32_t)P->back_cap && p - back > bs && p - back > best_off &&
                            src[p - back - 1] == src[p - back - 1 - best_off]) back++;
                 m->back = (uint8_t)back;
+            }
+        }
+        {
+            int any = 0;
+            for (t = 0; t < tcount; t++) any |= c->M[t].len != 0;
+            if (any) c->cold = 0;
+            else {
+                c->cold++;
+                if (c->cold >= 2) c->skip_left = c->cold >= 4 ? 7u : (1u << (c->cold - 1)) - 1;
             }
         }
         /* S4: backward propagation -- position t may start the match of t+k, k bytes earlier */
@@ -823,7 +843,7 @@ int zge_encode_frame(const zge_params *P, const void *src_, size_t n, void *dst_
         if (!single) dst[pos++] = (uint8_t)((wlog - 10) << 3);
         for (i = 0; i < fcs_bytes; i++) dst[pos++] = (uint8_t)(v >> (8 * i));
     }
-    c.P = P; c.src = src; c.n = n; c.st = st;
+    c.P = P; c.src = src; c.n = n; c.st = st; c.cold = 0; c.skip_left = 0;
     c.window = single ? (n ? n : 1) : ((size_t)1 << wlog);
     c.tl = (uint32_t *)calloc((size_t)1 << P->long_log, 4);
     c.ts = (uint32_t *)calloc((size_t)1 << P->short_log, 4);

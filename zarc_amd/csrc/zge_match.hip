@@ -157,6 +157,10 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
 
     for (int i = tid; i < (1 << TAB_LOG); i += THREADS) { L.tl[i] = 0; L.ts[i] = 0; }
     zd::lds_barrier();
+    // Cold stretches (incompressible data): `cold` counts the searched tiles in a row in which no position found a match; from the
+    // second one on, the next 1, 3, then 7 tiles are not searched at all (all literals, nothing inserted) -- the way libzstd's
+    // search step grows while it finds nothing.  Any match in a searched tile ends the stretch.  Replicated in every thread.
+    uint32_t cold = 0, skip_left = 0;
 
     for (uint32_t b = 0; b < nblocks; b++) {
         const uint32_t bs = b * ZARC_BLOCK;
@@ -205,6 +209,19 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
             ZGE_PROF(0);
             const uint32_t pos = bs + L.ctrl[K_POS];
             if (pos >= tend) continue; // whole tile already covered by a match: skip it (nothing is inserted)
+            if (skip_left) { // cold stretch: the tile is not searched -- its bytes go straight from HBM to the literals
+                skip_left--;
+                const uint32_t start = (uint32_t)((pos > tile ? pos : tile) - tile);
+#pragma unroll
+                for (int u = 0; u < PER; u++) {
+                    const uint32_t idx = ZGE_IDX(u);
+                    if (idx >= start && idx < tcount && !(P.dbg & 32)) lit_out[lp + (idx - start)] = src[tile + idx];
+                }
+                lp += tcount - start;
+                zd::lds_barrier(); // every thread has read K_POS
+                if (tid == 0) L.ctrl[K_POS] = (uint32_t)(tend - bs);
+                continue;
+            }
             const uint32_t erep0 = L.ctrl[K_REP0], erep1 = L.ctrl[K_REP1];
             if (tid == 0) L.ctrl[K_ANY] = 0; // set by any position of this tile that finds a match
 
@@ -430,8 +447,11 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
                 }
                 lp += tcount - start;
                 if (tid == 0) L.ctrl[K_POS] = (uint32_t)(tend - bs);
+                cold++;
+                if (cold >= 2) skip_left = cold >= 4 ? 7u : (1u << (cold - 1)) - 1;
                 continue;
             }
+            cold = 0;
 #pragma unroll
             for (int u = 0; u < PER; u++) {
                 const uint32_t idx = ZGE_IDX(u);
