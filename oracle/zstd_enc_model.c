@@ -399,6 +399,11 @@ static size_t encode_literals(const uint8_t *lit, size_t n, uint8_t *dst, size_t
         if (st) st->lit_rle++;
         return raw_hdr + 1;
     }
+    {   /* a flat histogram is not worth a Huffman attempt (the rule libzstd's huf_compress uses: "probably not compressible") */
+        uint32_t largest = 0;
+        for (i = 0; i < 256; i++) if (count[i] > largest) largest = count[i];
+        if ((size_t)largest <= (n >> 7) + 4) distinct = 0;
+    }
     if (n >= ZGE_MIN_HUF_LITERALS && distinct >= 2) {
         huf_ctab h;
         uint8_t desc[160];

@@ -491,9 +491,15 @@ __global__ void __launch_bounds__(64, 5) zarc_zge_entropy(uint32_t n_blocks, Zge
         uint32_t distinct = 0;
 #pragma unroll
         for (int r = 0; r < 4; r++) distinct += (uint32_t)__popcll(zd::ballot(L.h.count[r * 64 + lane] != 0));
+        // a flat histogram is not worth a Huffman attempt (the rule libzstd's huf_compress uses: "probably not compressible")
+        uint32_t largest = 0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) { const uint32_t c = L.h.count[r * 64 + lane]; largest = c > largest ? c : largest; }
+        largest = zd::uniform(zd::wave_max(largest));
+        const bool flat = largest <= (n >> 7) + 4;
         int kind = 0; // 0 raw, 1 rle, 2 huffman
         if (n >= 2 && distinct == 1) kind = 1;
-        else if (n >= MIN_HUF_LITERALS && distinct >= 2) {
+        else if (n >= MIN_HUF_LITERALS && distinct >= 2 && !flat) {
             huf_build_lengths(L, lane);
             if (lane == 0) {
                 huf_assign_codes(L);
@@ -562,7 +568,9 @@ __global__ void __launch_bounds__(64, 5) zarc_zge_entropy(uint32_t n_blocks, Zge
                 else if (raw_hdr == 2) { out[0] = (uint8_t)(0 | (1 << 2) | ((n & 15) << 4)); out[1] = (uint8_t)(n >> 4); }
                 else { out[0] = (uint8_t)(0 | (3 << 2) | ((n & 15) << 4)); out[1] = (uint8_t)(n >> 4); out[2] = (uint8_t)(n >> 12); }
             }
-            for (uint32_t i = (uint32_t)lane; i < n; i += 64) out[raw_hdr + i] = lit[i];
+            // a block without sequences whose literals stay raw cannot beat its own size: it becomes a raw block (copied from the
+            // source by the assembly pass), so the literal bytes need not be moved here
+            if (nseq != 0) for (uint32_t i = (uint32_t)lane; i < n; i += 64) out[raw_hdr + i] = lit[i];
             lsz = raw_hdr + n;
         }
     }
