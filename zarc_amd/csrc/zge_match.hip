@@ -348,9 +348,12 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
                         if (!(k == 0 ? use0 : use1) || off > idx + (uint32_t)F_REP_BACK || off > p || idx >= tcount || (P.dbg & 1)) continue;
                         uint64_t x = zd::load_u64(tbb + (uint32_t)(p - off + wofs)) ^ p8[u];
                         uint32_t len = 0;
-                        while (!x && len + 8 < cap) {
+                        while (!x && len + 8 < cap) { // 16 bytes per LDS round trip (the second half stays inside the staged window)
+                            const uint64_t a0 = zd::load_u64(tbb + (uint32_t)(p + len + 8 + wofs)), b0 = zd::load_u64(tbb + (uint32_t)(p - off + len + 8 + wofs));
+                            const uint64_t a1 = zd::load_u64(tbb + (uint32_t)(p + len + 16 + wofs)), b1 = zd::load_u64(tbb + (uint32_t)(p - off + len + 16 + wofs));
                             len += 8;
-                            x = zd::load_u64(tbb + (uint32_t)(p + len + wofs)) ^ zd::load_u64(tbb + (uint32_t)(p - off + len + wofs));
+                            x = a0 ^ b0;
+                            if (!x && len + 8 < cap) { len += 8; x = a1 ^ b1; }
                         }
                         len += x ? (uint32_t)(zd::ctz64(x) >> 3) : 8u;
                         if (len > cap) len = cap;
@@ -378,9 +381,13 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
                     uint64_t x = q16[u][k].hi ^ p8[u];
                     uint32_t len = 0;
                     // common prefix, 8 bytes per step; reads past `cap` stay inside the staged window / the padded arena
-                    while (!x && len + 8 < cap) {
+                    while (!x && len + 8 < cap) { // 16 bytes per global round trip
+                        U128 sv;
+                        __builtin_memcpy(&sv, src + (p - off + len + 8), 16);
+                        const uint64_t a0 = zd::load_u64(tbb + (uint32_t)(p + len + 8 + wofs)), a1 = zd::load_u64(tbb + (uint32_t)(p + len + 16 + wofs));
                         len += 8;
-                        x = zd::load_u64(tbb + (uint32_t)(p + len + wofs)) ^ zd::load_u64(src + (p - off + len));
+                        x = a0 ^ sv.lo;
+                        if (!x && len + 8 < cap) { len += 8; x = a1 ^ sv.hi; }
                     }
                     len += x ? (uint32_t)(zd::ctz64(x) >> 3) : 8u;
                     if (len > cap) len = cap;
