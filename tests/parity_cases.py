@@ -51,7 +51,12 @@ def encode_cases(corpus, big):
          "k2_64k": corpus.entry(6, 65536, 2), "k0_200k": corpus.entry(8, 200000, 0), "k1_131073": corpus.entry(9, 131073, 1),
          "sparse": bytes(rnd.randrange(256) if i % 7 else 0 for i in range(100000)),
          "runs": make_golden.recipe_bytes({"kind": "runs", "n": 120000, "seed": 9}, corpus),
-         "few": make_golden.recipe_bytes({"kind": "few", "n": 40000, "seed": 8}, corpus)}
+         "few": make_golden.recipe_bytes({"kind": "few", "n": 40000, "seed": 8}, corpus),
+         # cold stretches of the match finder (unsearched tiles after tiles without a match) and the way back: random | text |
+         # random | the same random again (a far repeat that starts inside an unsearched stretch) | records
+         "cold_hot": corpus.entry(21, 40000, 3) + corpus.entry(22, 30000, 0) + corpus.entry(23, 50000, 3) + corpus.entry(23, 50000, 3)
+                     + corpus.entry(24, 20000, 1),
+         "cold_tail": corpus.entry(25, 9000, 0) + corpus.entry(26, 131072 + 5000, 3)}   # stretch crosses a block boundary
     if big:
         for k in range(4):
             c["k%d_1m" % k] = corpus.entry(40 + k, 1 << 20, k)

@@ -7,6 +7,7 @@ def _cases(corpus):
     for k in range(4):
         for n in (1000, 65536, 200000):
             c["k%d_%d" % (k, n)] = corpus.entry(k + 4 * n, n, k)
+    c["cold_hot"] = corpus.entry(21, 40000, 3) + corpus.entry(22, 30000, 0) + corpus.entry(23, 50000, 3) + corpus.entry(23, 50000, 3)
     c["k0_1m"] = corpus.entry(0, 1 << 20, 0)
     c["k1_2m5"] = corpus.entry(1, (5 << 20) // 2, 1)  # > 2^21: not single-segment, window descriptor path
     return c
@@ -55,3 +56,18 @@ def test_model_level9_within_5_percent_of_libzstd_level9(oracle, corpus, libzstd
         rc, out, used = oracle.zstd_decode(frame, len(raw))
         assert rc == 0 and out == raw and used == len(frame)
         assert len(frame) <= len(z.compress(raw, 9, 1)) * 1.05, kind
+
+
+def test_model_cold_stretches_keep_the_ratio_on_mixed_content(oracle, corpus, libzstds):
+    """Unsearched tiles (zstd_enc_model.c: cold stretches) must not cost compressible neighbours: alternating incompressible and
+    compressible pieces stay within 5 % of libzstd -3, and pure random data is stored at its own size plus framing."""
+    z = next((z for z in libzstds if z.version.startswith("1.5")), None) or (libzstds[0] if libzstds else None)
+    if z is None:
+        pytest.skip("no libzstd on this box")
+    mixed = b"".join(corpus.entry(100 + i, 48000 + 1000 * i, 3 if i % 2 == 0 else (i // 2) % 3) for i in range(12))
+    frame = oracle.zge_encode(mixed)
+    rc, out, used = oracle.zstd_decode(frame, len(mixed))
+    assert rc == 0 and out == mixed and used == len(frame)
+    assert len(frame) <= len(z.compress(mixed, 3, 1)) * 1.05
+    rnd = corpus.entry(7, 1 << 20, 3)
+    assert len(oracle.zge_encode(rnd)) == len(rnd) + 4 + 1 + 4 + 3 * 8 + 4   # magic, descriptor, size, 8 raw-block headers, checksum
