@@ -113,7 +113,7 @@ struct EntLds {
             uint32_t cl[36], co[32], cm[53];
             int16_t norm[3][64];
             uint8_t desc[3][80];
-            uint64_t pre[3][64];   // LL / OF / ML of the current 64 sequences: in {dnb, dfs} of the symbol, out value | nb << 16
+            uint64_t pre[3][64];   // LL / OF / ML of the current 64 sequences: in {dnb, dfs} of the symbol, out {dnb, state before the step}
         } s;
     };
 };
@@ -705,32 +705,42 @@ __global__ void __launch_bounds__(64, 5) zarc_zge_entropy(uint32_t n_blocks, Zge
                         L.s.pre[2][lane] = (uint32_t)L.s.dnb_ml[mlc] | ((uint64_t)(uint32_t)L.s.dfs_ml[mlc] << 32);
                     }
                     zd::wave_sync();
-                    if (lane < 3) {
+                    if (lane < 3 && my_mode != 1) {
+                        // The chain does the bare minimum per step -- remember the state, find the next one (one dependent LDS access);
+                        // the bits each step emits follow from (state before, symbol constant) and are worked out by all lanes below.
                         uint64_t nxt = L.s.pre[lane][0];
-                        for (uint32_t e = 0; e < cnt; e++) {
+                        uint32_t e = 0;
+                        if (done == 0) { // first symbol coded: the state that needs no bits (fse_init_state)
+                            const int32_t d = (int32_t)(uint32_t)nxt, f = (int32_t)(uint32_t)(nxt >> 32);
+                            const int nb0 = (d + (1 << 15)) >> 16;
+                            const int value = (nb0 << 16) - d;
+                            state = ct.state_tab[(value >> nb0) + f];
+                            e = 1;
+                            if (cnt > 1) nxt = L.s.pre[lane][1];
+                        }
+                        for (; e < cnt; e++) {
                             const uint64_t cur = nxt;
                             if (e + 1 < cnt) nxt = L.s.pre[lane][e + 1]; // independent of the state: in flight during the step
-                            const int32_t d = (int32_t)(uint32_t)cur, f = (int32_t)(uint32_t)(cur >> 32);
-                            uint32_t bits = 0;
-                            if (my_mode != 1) {
-                                if (done + e == 0) { // first symbol coded: the state that needs no bits (fse_init_state)
-                                    const int nb0 = (d + (1 << 15)) >> 16;
-                                    const int value = (nb0 << 16) - d;
-                                    state = ct.state_tab[(value >> nb0) + f];
-                                } else {
-                                    const int nb_ = (int)((state + (uint32_t)d) >> 16);
-                                    bits = (state & ((1u << nb_) - 1)) | ((uint32_t)nb_ << 16);
-                                    state = ct.state_tab[(int)(state >> nb_) + f];
-                                }
-                            }
-                            ((uint32_t *)&L.s.pre[lane][e])[0] = bits; // value | nb << 16, read back by lane e
+                            const uint32_t d = (uint32_t)cur;
+                            const int32_t f = (int32_t)(uint32_t)(cur >> 32);
+                            ((uint32_t *)&L.s.pre[lane][e])[1] = state; // the state this step starts from, in place of dfs
+                            const uint32_t nb_ = (state + d) >> 16;
+                            state = ct.state_tab[(int)(state >> nb_) + f];
                         }
                     }
                     zd::wave_sync();
                     uint64_t lo = 0;
                     uint32_t hi = 0, nb = 0;
                     if ((uint32_t)lane < cnt) {
-                        const uint32_t bo = (uint32_t)L.s.pre[1][lane], bm = (uint32_t)L.s.pre[2][lane], bl = (uint32_t)L.s.pre[0][lane];
+                        // state bits of the three chains: value | nb << 16 from (state before the step, dnb of the symbol); the very first
+                        // symbol coded and tables in RLE mode emit nothing
+                        uint32_t bo = 0, bm = 0, bl = 0;
+                        const bool first = done + (uint32_t)lane == 0;
+                        if (!first) {
+                            if (mode_o != 1) { const uint64_t c = L.s.pre[1][lane]; const uint32_t sb = (uint32_t)(c >> 32), n_ = (sb + (uint32_t)c) >> 16; bo = (sb & ((1u << n_) - 1)) | (n_ << 16); }
+                            if (mode_m != 1) { const uint64_t c = L.s.pre[2][lane]; const uint32_t sb = (uint32_t)(c >> 32), n_ = (sb + (uint32_t)c) >> 16; bm = (sb & ((1u << n_) - 1)) | (n_ << 16); }
+                            if (mode_l != 1) { const uint64_t c = L.s.pre[0][lane]; const uint32_t sb = (uint32_t)(c >> 32), n_ = (sb + (uint32_t)c) >> 16; bl = (sb & ((1u << n_) - 1)) | (n_ << 16); }
+                        }
                         // order: OF state bits, ML state bits, LL state bits, LL extra, ML extra, OF extra
                         uint64_t acc = bo & 0xFFFF; uint32_t sh = bo >> 16;
                         acc |= (uint64_t)(bm & 0xFFFF) << sh; sh += bm >> 16;
