@@ -527,11 +527,14 @@ __global__ void __launch_bounds__(64, 5) zarc_zge_entropy(uint32_t n_blocks, Zge
                     if (k >= nstreams) break;
                     const uint32_t beg = k * per, cnt = single ? n : (k < 3 ? per : n - 3 * per);
                     pk.begin(L.stage, body + pos, out_cap - hdr - pos, lane);
-                    for (uint32_t j0 = 0; j0 < cnt; j0 += 128) { // two symbols per lane and step: half as many prefix sums / flushes
-                        const uint32_t j = j0 + 2 * (uint32_t)lane;
-                        uint32_t cv = 0, cl_ = 0;
-                        if (j < cnt) { const uint32_t e = L.code[lit[beg + cnt - 1 - j]]; cv = e & 0x7FF; cl_ = e >> 11; }
-                        if (j + 1 < cnt) { const uint32_t e = L.code[lit[beg + cnt - 2 - j]]; cv |= (e & 0x7FF) << cl_; cl_ += e >> 11; }
+                    for (uint32_t j0 = 0; j0 < cnt; j0 += 256) { // four symbols (<= 44 bits) per lane and step: a quarter of the prefix sums / flushes
+                        const uint32_t j = j0 + 4 * (uint32_t)lane;
+                        uint64_t cv = 0;
+                        uint32_t cl_ = 0;
+#pragma unroll
+                        for (uint32_t q = 0; q < 4; q++) {
+                            if (j + q < cnt) { const uint32_t e = L.code[lit[beg + cnt - 1 - j - q]]; cv |= (uint64_t)(e & 0x7FF) << cl_; cl_ += e >> 11; }
+                        }
                         pk.put(cv, 0, cl_, lane);
                     }
                     ssz[k] = pk.finish(lane);
