@@ -15,14 +15,15 @@
 //         in order, so a position sees every insert of earlier 64-groups with no waiting between steps
 //   S3    every position scores its candidates: one 16-byte request source[-8..8) per table candidate (first compare
 //         and backward extension), the two recent-offset guesses are scored out of LDS while those are in flight;
-//         offers for backward propagation are posted with ds_max
+//         comparisons advance 16 bytes per LDS / global round trip; offers for backward propagation are posted with ds_max
 //   S4    backward propagation: position t may start the match found at t+k, k bytes earlier
 //   S5    one-byte lazy rule -> take flag and successor next[t] for every position
 //   S6    the greedy parse IS the path from the entry cursor through next[]: per 64-position chunk the exit of
 //         every position by 6 rounds of shuffle pointer-jumping, then the chunk entries by a short chain
 //         through LDS, then each wave marks its chunk's path with v_readlane -- no workgroup barriers
 //   S7    ballot/popcount prefix sums (16-lane scan over the chunks) place literal bytes and sequences
-//   A tile in which no position found a match takes an all-literals path after S3.
+//   A tile in which no position found a match takes an all-literals path after S3; after two such tiles in a row the next
+//   1, 3, then 7 tiles are not searched at all (cold stretch: bytes go straight to the literals, nothing is inserted).
 // Output per block: packed (literal position, match length, offset) + literal bytes in HBM scratch; literal
 // lengths and repcodes are resolved by the entropy stage.  Deterministic and bit-identical to
 // oracle/zstd_enc_model.c (tests/ compare them).
