@@ -449,7 +449,7 @@ int zarc_gpu_pack_batch_device(zarc_gpu_t *h, size_t n, const void *d_src_base, 
         ZHIP(hipMemsetAsync(h->d_queue.p, 0, 256, h->stream));
         const bool deep = P.long_log == 14;
         const size_t match_grid = std::min<size_t>(m, (size_t)h->num_cus * (deep ? 1 : 2)); // two 80 KiB workgroups fit a CU, one of 145 KiB
-        hipLaunchKernelGGL(deep ? zarc_zge_match_deep : zarc_zge_match, dim3((unsigned)match_grid), dim3(512), 0, h->stream, P, base, d_off, d_len, h->d_order.as<uint32_t>(), (uint32_t)m,
+        hipLaunchKernelGGL(deep ? zarc_zge_match_deep : (P.dbg ? zarc_zge_match_diag : zarc_zge_match), dim3((unsigned)match_grid), dim3(512), 0, h->stream, P, base, d_off, d_len, h->d_order.as<uint32_t>(), (uint32_t)m,
                            h->d_block_prefix.as<uint64_t>(), h->d_blocks.as<ZgeBlock>(), h->d_seq.as<uint64_t>(), h->d_lit.as<uint8_t>(),
                            h->d_queue.as<uint32_t>());
         ZHIP(hipGetLastError());

@@ -102,6 +102,10 @@ __global__ void zarc_zge_match(ZgeParams P, const uint8_t *src_base, const uint6
                                const uint32_t *order, uint32_t n_frames, const uint64_t *block_prefix, ZgeBlock *blocks,
                                uint64_t *seq_scratch, uint8_t *lit_scratch, uint32_t *queue);
 // the deep finder (level >= 9): same arguments, 2^14-entry tables (one workgroup per CU), 4-byte short hash
+__global__ void zarc_zge_match_diag(ZgeParams P, const uint8_t *src_base, const uint64_t *src_off, const uint64_t *src_len,
+                               const uint32_t *order, uint32_t n_frames, const uint64_t *block_prefix, ZgeBlock *blocks,
+                               uint64_t *seq_scratch, uint8_t *lit_scratch, uint32_t *queue);
+// the deep finder (level >= 9): same arguments, 2^14-entry tables (one workgroup per CU), 4-byte short hash
 __global__ void zarc_zge_match_deep(ZgeParams P, const uint8_t *src_base, const uint64_t *src_off, const uint64_t *src_len,
                                     const uint32_t *order, uint32_t n_frames, const uint64_t *block_prefix, ZgeBlock *blocks,
                                     uint64_t *seq_scratch, uint8_t *lit_scratch, uint32_t *queue);

@@ -41,7 +41,7 @@ namespace {
 // going through LDS, and the chain over chunk entries hops pair by pair)
 #define ZGE_IDX(u) ((uint32_t)((wave * PER + (u)) * 64 + lane))
 // stage timing (diagnostics): ticks since the previous mark, accumulated per stage; each mark sits after a barrier
-#define ZGE_PROF(i) do { if ((P.dbg & 1024) && tid == 0) { const unsigned long long now_ = ZGE_CLOCK(); L.prof[i] += now_ - tprev; tprev = now_; } } while (0)
+#define ZGE_PROF(i) do { if ((dbg & 1024) && tid == 0) { const unsigned long long now_ = ZGE_CLOCK(); L.prof[i] += now_ - tprev; tprev = now_; } } while (0)
 
 constexpr int TILE = 1024;
 constexpr int THREADS = 512;
@@ -126,13 +126,16 @@ __device__ __forceinline__ StageWin stage_window(const ZgeParams &P, const uint8
 
 // The body is compiled twice: the level-3 finder (2^13-entry tables, 5-byte short hash, two workgroups per CU) and the deep
 // one for level >= 9 (2^14-entry tables = 128 KiB of LDS, one workgroup per CU; 4-byte short hash, cheaper matches).
-template <int TAB_LOG, int SHORT_BYTES, int MATCH_COST>
+// DIAG: the timing-only switches of ZARC_GPU_DBG are compiled into a separate instantiation, so the product kernels carry none of
+// their scalar tests
+template <int TAB_LOG, int SHORT_BYTES, int MATCH_COST, bool DIAG>
 __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgeParams &P, const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off,
                                                const uint64_t *__restrict__ src_len, const uint32_t *__restrict__ order, uint32_t n_frames,
                                                const uint64_t *__restrict__ block_prefix, ZgeBlock *__restrict__ blocks,
                                                uint64_t *__restrict__ seq_scratch, uint8_t *__restrict__ lit_scratch, uint32_t *__restrict__ queue)
 {
     const int tid = (int)threadIdx.x, lane = zd::lane_id();
+    const uint32_t dbg = DIAG ? (uint32_t)P.dbg : 0u;
     const int wave = (int)zd::uniform((uint32_t)zd::wave_id()); // scalar: chunk bounds and the parse walk stay on the SALU
     const uint64_t lt = (1ull << lane) - 1;
     const uint32_t seg_mask = (1u << F_SEG_LOG) - 1;
@@ -216,7 +219,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
 #pragma unroll
                 for (int u = 0; u < PER; u++) {
                     const uint32_t idx = ZGE_IDX(u);
-                    if (idx >= start && idx < tcount && !(P.dbg & 32)) lit_out[lp + (idx - start)] = src[tile + idx];
+                    if (idx >= start && idx < tcount && !(dbg & 32)) lit_out[lp + (idx - start)] = src[tile + idx];
                 }
                 lp += tcount - start;
                 zd::lds_barrier(); // every thread has read K_POS
@@ -255,7 +258,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
                 p8[u] = 0;
                 if (idx < tcount) {
                     p8[u] = zd::load_u64(tbb + (uint32_t)(p + wofs));
-                    if (p < hash_end && !(P.dbg & 64)) {
+                    if (p < hash_end && !(dbg & 64)) {
                         hl = hash_long(p8[u], TAB_LOG + TAG_BITS);
                         hs = hash_short(p8[u], TAB_LOG + TAG_BITS, SHORT_BYTES);
                     }
@@ -268,7 +271,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
             ZGE_PROF(2);
             // ---- S2: ordered lookup + insert (wave 0); no waits between the steps on hardware ----
             // The two tables are independent: wave 0 owns the long table, wave 1 the short one.
-            if (wave < 2 && !(P.dbg & 4)) {
+            if (wave < 2 && !(dbg & 4)) {
                 zd::wave_priority<3>(); // the other six waves wait for these two: go ahead of the co-resident workgroup
                 uint32_t *tab = wave == 0 ? L.tl : L.ts;
                 uint32_t *hc = wave == 0 ? L.a0 : L.a1; // hashes in, candidates out
@@ -313,7 +316,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
                 const uint32_t idx = ZGE_IDX(u);
                 const uint32_t p = tile + idx;
                 uint32_t c0 = 0, c1 = 0;
-                if (idx < tcount && !(P.dbg & 5)) {
+                if (idx < tcount && !(dbg & 5)) {
                     const uint32_t w0 = L.a0[idx], w1 = L.a1[idx]; // candidate position (+1): a table hit whose check bits agreed
                     c0 = (w0 && !(w0 & TAG_MASK)) ? segbase + (w0 >> TAG_BITS) : 0u;
                     c1 = (w1 && !(w1 & TAG_MASK)) ? segbase + (w1 >> TAG_BITS) : 0u;
@@ -322,7 +325,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
                 offs[u][1] = (c1 && c1 != c0) ? p - (c1 - 1) : 0u;
 #pragma unroll
                 for (int k = 0; k < 2; k++) // the source needs 8 bytes in front of it (frame positions 0..7 are not used as sources)
-                    if (offs[u][k] + 8 > p || offs[u][k] > window || idx >= tcount || (P.dbg & 1)) offs[u][k] = 0;
+                    if (offs[u][k] + 8 > p || offs[u][k] > window || idx >= tcount || (dbg & 1)) offs[u][k] = 0;
 #pragma unroll
                 for (int k = 0; k < 2; k++) { // one 16-byte request: source[-8 .. 0) for the backward extension, source[0 .. 8)
                     q16[u][k] = U128{0, 0};
@@ -346,7 +349,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
 #pragma unroll
                     for (int k = 0; k < 2; k++) {
                         const uint32_t off = k == 0 ? erep0 : erep1;
-                        if (!(k == 0 ? use0 : use1) || off > idx + (uint32_t)F_REP_BACK || off > p || idx >= tcount || (P.dbg & 1)) continue;
+                        if (!(k == 0 ? use0 : use1) || off > idx + (uint32_t)F_REP_BACK || off > p || idx >= tcount || (dbg & 1)) continue;
                         uint64_t x = zd::load_u64(tbb + (uint32_t)(p - off + wofs)) ^ p8[u];
                         uint32_t len = 0;
                         while (!x && len + 8 < cap) { // 16 bytes per LDS round trip (the second half stays inside the staged window)
@@ -435,7 +438,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
             for (int u = 0; u < PER; u++) {
                 const uint32_t idx = ZGE_IDX(u);
                 const uint32_t len = mw[u] & 0xFFFF, back = (mw[u] >> 16) & 0xFF;
-                if (len && back && !(P.dbg & 8)) {
+                if (len && back && !(dbg & 8)) {
                     const bool rep = (mw[u] >> 24) & 1;
                     for (uint32_t k = 1; k <= back && k <= idx; k++) {
                         const int32_t sc = score_of(P, len + k, mo[u], rep);
@@ -451,7 +454,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
 #pragma unroll
                 for (int u = 0; u < PER; u++) {
                     const uint32_t idx = ZGE_IDX(u);
-                    if (idx >= start && idx < tcount && !(P.dbg & 32)) lit_out[lp + (idx - start)] = (uint8_t)p8[u];
+                    if (idx >= start && idx < tcount && !(dbg & 32)) lit_out[lp + (idx - start)] = (uint8_t)p8[u];
                 }
                 lp += tcount - start;
                 if (tid == 0) L.ctrl[K_POS] = (uint32_t)(tend - bs);
@@ -545,7 +548,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
                     const uint64_t tk = zd::ballot(take[u]);
                     const uint32_t span = cend > cbase ? cend - cbase : 0u; // positions of this chunk inside the tile
                     uint64_t sel = 0, lits = 0;
-                    if (!(P.dbg & 2)) {
+                    if (!(dbg & 2)) {
                         while (cur < cend) {
                             const uint32_t rel = cur - cbase;
                             const uint64_t ahead = tk >> rel;              // take flags at or after the cursor
@@ -593,7 +596,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
             for (int u = 0; u < PER; u++) {
                 const uint32_t my_sel_idx = sel_before[u] + (uint32_t)__popcll(msel[u] & lt);
                 const uint32_t my_lit_idx = lit_before[u] + (uint32_t)__popcll(mlit[u] & lt);
-                if (P.dbg & 32) continue;
+                if (dbg & 32) continue;
                 if ((msel[u] >> lane) & 1) {
                     // the literal position stands in for the literal length (difference of neighbours, taken in stage 2)
                     seq_out[nseq + my_sel_idx] = zge_pack_seq(lp + my_lit_idx, mw[u] & 0xFFFF, mo[u]);
@@ -612,7 +615,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
         zd::lds_barrier();
     }
     } // next frame from the queue
-    if ((P.dbg & 1024) && tid < 12) atomicAdd((unsigned long long *)(queue + 2) + tid, L.prof[tid]);
+    if ((dbg & 1024) && tid < 12) atomicAdd((unsigned long long *)(queue + 2) + tid, L.prof[tid]);
 }
 #undef score_of
 
@@ -622,7 +625,17 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                                                       uint64_t *__restrict__ seq_scratch, uint8_t *__restrict__ lit_scratch, uint32_t *__restrict__ queue)
 {
     __shared__ MatchLds<13> L;
-    zge_match_body<13, 5, 12>(L, P, src_base, src_off, src_len, order, n_frames, block_prefix, blocks, seq_scratch, lit_scratch, queue);
+    zge_match_body<13, 5, 12, false>(L, P, src_base, src_off, src_len, order, n_frames, block_prefix, blocks, seq_scratch, lit_scratch, queue);
+}
+
+// the same kernel with the ZARC_GPU_DBG switches (stage clocks, timing-only ablations)
+__global__ void __launch_bounds__(512, 4) zarc_zge_match_diag(ZgeParams P, const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off,
+                                                           const uint64_t *__restrict__ src_len, const uint32_t *__restrict__ order, uint32_t n_frames,
+                                                           const uint64_t *__restrict__ block_prefix, ZgeBlock *__restrict__ blocks,
+                                                           uint64_t *__restrict__ seq_scratch, uint8_t *__restrict__ lit_scratch, uint32_t *__restrict__ queue)
+{
+    __shared__ MatchLds<13> L;
+    zge_match_body<13, 5, 12, true>(L, P, src_base, src_off, src_len, order, n_frames, block_prefix, blocks, seq_scratch, lit_scratch, queue);
 }
 
 __global__ void __launch_bounds__(512, 2) zarc_zge_match_deep(ZgeParams P, const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off,
@@ -631,5 +644,5 @@ __global__ void __launch_bounds__(512, 2) zarc_zge_match_deep(ZgeParams P, const
                                                            uint64_t *__restrict__ seq_scratch, uint8_t *__restrict__ lit_scratch, uint32_t *__restrict__ queue)
 {
     __shared__ MatchLds<14> L;
-    zge_match_body<14, 4, 10>(L, P, src_base, src_off, src_len, order, n_frames, block_prefix, blocks, seq_scratch, lit_scratch, queue);
+    zge_match_body<14, 4, 10, false>(L, P, src_base, src_off, src_len, order, n_frames, block_prefix, blocks, seq_scratch, lit_scratch, queue);
 }
