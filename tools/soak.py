@@ -54,4 +54,5 @@ while time.time() < t_end:
     eng.close()
     rounds += 1
     frames += n
+    if rounds % 50 == 0: print("... %d rounds, %d entries" % (rounds, frames), flush=True)  # the GPU runner kills silent jobs
 print("soak ok: %d rounds, %d entries, %.0f s" % (rounds, frames, budget))
