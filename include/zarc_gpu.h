@@ -77,8 +77,24 @@ enum {
     ZARC_GPU_P_STRATEGY = 107,
     ZARC_GPU_P_CONTENT_SIZE_FLAG = 200,
     ZARC_GPU_P_CHECKSUM_FLAG = 201,
-    ZARC_GPU_P_DICT_ID_FLAG = 202
+    ZARC_GPU_P_DICT_ID_FLAG = 202,
+    /* Engine tuning, not libzstd ids: how a batch is cut up, never what bytes come out (frames are identical for every value).
+     * The library reads NO environment variable; these are the only switches. */
+    ZARC_GPU_PX_SCRATCH_MB = 9001,   /* encoder scratch budget in MiB (0 = up to 64 GiB / 45 % of free HBM): batches beyond it run as sub-batches */
+    ZARC_GPU_PX_STAGE_CHUNK = 9002,  /* host-pointer entry points: content bytes per staged chunk (0 = 2 GiB pack / 4 GiB unpack; >= 4096)         */
+    ZARC_GPU_PX_STAGE_THREAD = 9003, /* 1 (default) = a helper thread moves neighbouring chunks over PCIe while the kernels run                     */
+    ZARC_GPU_PX_COPY_THREADS = 9004  /* host threads that fill / drain the pinned staging ring (default 8)                                          */
 };
+/* What the engine does with the libzstd ids (pack.rs:86-217 forwards them all):
+ *   CompressionLevel  -131072..22 accepted.  Levels <= 8 run the level-3 finder (LDS tables of 2^13 entries on an 8-byte and a
+ *                     5-byte hash, a 2^16-bucket far table in HBM, one-byte lazy evaluation from level 2 on); levels >= 9 run the
+ *                     deep finder (2^14-entry LDS tables, 4-byte short hash, 4-way far tables on both hashes).
+ *   WindowLog         honoured for the frame header / the farthest offset (10..27; default 21, level >= 9: 22).
+ *   MinMatch          4..7 honoured (3 is raised to 4); default 5, level >= 9: 4.
+ *   HashLog, ChainLog, SearchLog, TargetLength, Strategy
+ *                     ZARC_GPU_E_UNSUPPORTED for any value but 0 (= default): table sizes and the search are fixed by the kernels.
+ *   ContentSizeFlag   only 1.  ChecksumFlag honoured.  DictIdFlag accepted (zarc has no dictionaries).
+ *   LDM (160-164), NbWorkers / JobSize / OverlapLog (400-402), experimental ids: ZARC_GPU_E_UNSUPPORTED. */
 
 typedef struct {
     int level;             /* 0 => default 3 (encode.rs:62 init(0))                                  */

@@ -24,6 +24,14 @@ typedef struct {
     int short_window_log; /* reach of the short-hash table (16 when its entries are u16) */
     int rep_back; /* recent-offset guesses must start at most this many bytes before the tile */
     int tag_bits, seg_log; /* hash check bits kept in each table entry; tables restart every 2^seg_log bytes */
+    /* Far tables (HBM in the engine): same entry format as the near ones, but a tile's lookups see the inserts of all EARLIER tiles
+     * only, and only every 2^far_step_log-th position is inserted (so an entry lives 2^far_step_log times longer; any repeat of
+     * 8 + 2^far_step_log - 1 bytes still contains an inserted position).  Way w of a bucket keeps the most recent position from
+     * tiles with (tile index mod far_ways) == w: candidates of different ages without any insertion order inside a tile. */
+    int far_log;      /* 2^far_log buckets per far table; 0 = no far tables */
+    int far_ways;     /* 1, 2 or 4 */
+    int far_step_log;
+    int far_short;    /* 1 = a second far table keyed by the short hash */
 } zge_params;
 
 typedef struct { uint32_t ll, ml, off, ofv; } zge_seq;

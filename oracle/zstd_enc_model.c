@@ -619,12 +619,30 @@ typedef struct {
      * libzstd's search step grows while it finds nothing.  Any match in a searched tile ends the stretch.  The state lives
      * for the whole frame. */
     uint32_t cold, skip_left;
+    uint32_t erep0, erep1;   /* recent-offset guesses: offsets of the last two matches selected so far in the frame (0 = none) */
+    uint32_t *fl, *fs;       /* far tables (long / short hash), far_ways entries per bucket */
+    uint32_t *farc;          /* per-tile far candidates: ZGE_FAR_MAX per position, value = position+1 */
 } mf_ctx;
+#define ZGE_FAR_MAX 8 /* far_ways * (1 + far_short) <= 8 */
 
 /* Resolve explicit offsets against the repcode history (RFC 8878 3.1.1.5).  The history starts UNKNOWN
  * (0 never equals a real offset) in every block: whether the previous block ends up raw/RLE -- which leaves the
  * decoder's history untouched -- is only known after entropy coding, and blocks are coded independently.
  * The cost is at most 3 repcodes per block.  In the engine this pass runs at the start of the entropy stage. */
+/* A sequence without literals that continues the previous match at the same offset is the tail of ONE longer match: the finder
+ * caps a match at `cap` bytes per position (its compare loops are per-thread work in the kernel) and never looks past a tile's
+ * overrun window, so long matches arrive in pieces.  Joined here (the engine does it at the start of the entropy stage), match
+ * lengths reach the format's 131 074. */
+static uint32_t merge_sequences(zge_seq *seq, uint32_t nseq)
+{
+    uint32_t i, o = 0;
+    for (i = 0; i < nseq; i++) {
+        if (o > 0 && seq[i].ll == 0 && seq[i].off == seq[o - 1].off) seq[o - 1].ml += seq[i].ml;
+        else seq[o++] = seq[i];
+    }
+    return o;
+}
+
 static void resolve_repcodes(zge_seq *seq, uint32_t nseq, zge_stats *st)
 {
     uint32_t r[3] = {0, 0, 0}, i;
@@ -654,7 +672,7 @@ static uint32_t matchfind_block(mf_ctx *c, size_t bs, size_t be, zge_seq *seq, u
     const zge_params *P = c->P;
     const uint8_t *src = c->src;
     size_t pos = bs, tile, lp = 0, prev_lp = 0;
-    uint32_t nseq = 0, erep0 = 0, erep1 = 0, i;
+    uint32_t nseq = 0, erep0 = c->erep0, erep1 = c->erep1, i;
     /* positions with fewer than 8 readable bytes are never hashed */
     size_t hash_end = c->n >= 8 ? c->n - 7 : 0; /* p < hash_end is hashable */
     for (tile = bs; tile < be; tile += (size_t)P->tile) {
@@ -695,27 +713,50 @@ static uint32_t matchfind_block(mf_ctx *c, size_t bs, size_t be, zge_seq *seq, u
                 c->ts[hs >> P->tag_bits] = (code << P->tag_bits) | (hs & tmask);
             }
         }
-        /* S3: every position scores its own candidates {long, short, guess0, guess1} */
+        /* Far tables: every position of the tile is looked up (the table holds the inserts of all earlier tiles of the segment). */
+        if (P->far_log) {
+            const uint32_t tmask = (1u << P->tag_bits) - 1;
+            const size_t segbase = tile & ~(((size_t)1 << P->seg_log) - 1);
+            int w;
+            memset(c->farc, 0, sizeof(uint32_t) * ZGE_FAR_MAX * (size_t)P->tile);
+            for (p = tile; p < tend && p < hash_end; p++) {
+                uint64_t v = rd64(src + p);
+                uint32_t hf = hash_long(v, P->far_log + P->tag_bits), *fc = c->farc + (p - tile) * ZGE_FAR_MAX;
+                for (w = 0; w < P->far_ways; w++) {
+                    uint32_t e = c->fl[(size_t)(hf >> P->tag_bits) * (size_t)P->far_ways + (size_t)w];
+                    if (e && (e & tmask) == (hf & tmask)) fc[w] = (uint32_t)segbase + (e >> P->tag_bits);
+                }
+                if (P->far_short) {
+                    uint32_t hg = hash_short(v, P->far_log + P->tag_bits, P->short_bytes);
+                    for (w = 0; w < P->far_ways; w++) {
+                        uint32_t e = c->fs[(size_t)(hg >> P->tag_bits) * (size_t)P->far_ways + (size_t)w];
+                        if (e && (e & tmask) == (hg & tmask)) fc[P->far_ways + w] = (uint32_t)segbase + (e >> P->tag_bits);
+                    }
+                }
+            }
+        }
+        /* S3: every position scores its own candidates {long, short, far ..., guess0, guess1}; ties keep the earlier candidate */
         for (p = tile; p < tend; p++) {
             cand *m = &c->M[p - tile];
             uint32_t limit = (uint32_t)(be - p), cap = limit < (uint32_t)P->cap ? limit : (uint32_t)P->cap;
             uint32_t best_len = 0, best_off = 0; int best_rep = 0; int32_t best_score = -1000000;
-            uint32_t k, offs[4];
+            uint32_t k, offs[4 + ZGE_FAR_MAX];
+            const uint32_t nfar = P->far_log ? (uint32_t)(P->far_ways * (1 + (P->far_short ? 1 : 0))) : 0, ntab = 2 + nfar;
             offs[0] = m->off ? (uint32_t)p - (m->off - 1) : 0;
             offs[1] = (m->len && m->len != m->off) ? (uint32_t)p - (m->len - 1) : 0;
             if (offs[1] > ((uint32_t)1 << P->short_window_log)) offs[1] = 0;
-            offs[2] = P->rep_search > 0 ? erep0 : 0;
-            offs[3] = (P->rep_search > 1 && erep1 != erep0) ? erep1 : 0;
+            for (k = 0; k < nfar; k++) { uint32_t fc = c->farc[(p - tile) * ZGE_FAR_MAX + k]; offs[2 + k] = fc ? (uint32_t)p - (fc - 1) : 0; }
+            offs[ntab] = P->rep_search > 0 ? erep0 : 0;
+            offs[ntab + 1] = (P->rep_search > 1 && erep1 != erep0) ? erep1 : 0;
             /* recent-offset guesses are only tried when their source lies in the tile window the kernel keeps in LDS
              * (rep_back bytes before the tile): far guesses almost never match and would cost an HBM access each */
-            if (offs[2] > (uint32_t)(p - tile) + (uint32_t)P->rep_back) offs[2] = 0;
-            if (offs[3] > (uint32_t)(p - tile) + (uint32_t)P->rep_back) offs[3] = 0;
+            if (offs[ntab] > (uint32_t)(p - tile) + (uint32_t)P->rep_back) offs[ntab] = 0;
+            if (offs[ntab + 1] > (uint32_t)(p - tile) + (uint32_t)P->rep_back) offs[ntab + 1] = 0;
             /* table candidates need 8 bytes in front of their source: the kernel fetches source[-8 .. 8) in one load (the
              * first half feeds the backward extension); sources in the first 8 bytes of a frame are skipped */
-            if (offs[0] + 8 > p) offs[0] = 0;
-            if (offs[1] + 8 > p) offs[1] = 0;
+            for (k = 0; k < ntab; k++) if (offs[k] + 8 > p) offs[k] = 0;
             m->len = 0; m->off = 0;
-            for (k = 0; k < 4; k++) {
+            for (k = 0; k < ntab + 2; k++) {
                 uint32_t off = offs[k], len; int is_rep; int32_t sc;
                 if (off == 0 || off > p || off > c->window) continue;
                 is_rep = off == erep0 || off == erep1;
@@ -732,6 +773,27 @@ static uint32_t matchfind_block(mf_ctx *c, size_t bs, size_t be, zge_seq *seq, u
                     while (back < (uint32_t)P->back_cap && p - back > bs && p - back > best_off &&
                            src[p - back - 1] == src[p - back - 1 - best_off]) back++;
                 m->back = (uint8_t)back;
+            }
+        }
+        /* far inserts of this tile (after all of its lookups): every 2^far_step_log-th position, into the way of this tile; the
+         * highest position wins (atomic max in the kernel) */
+        if (P->far_log) {
+            const uint32_t tmask = (1u << P->tag_bits) - 1, smask = (1u << P->far_step_log) - 1;
+            const size_t segbase = tile & ~(((size_t)1 << P->seg_log) - 1);
+            const size_t way = (tile / (size_t)P->tile) % (size_t)P->far_ways;
+            for (p = tile; p < tend && p < hash_end; p++) {
+                uint64_t v;
+                uint32_t hf, code = (uint32_t)(p - segbase) + 1, *e;
+                if ((uint32_t)p & smask) continue;
+                v = rd64(src + p);
+                hf = hash_long(v, P->far_log + P->tag_bits);
+                e = &c->fl[(size_t)(hf >> P->tag_bits) * (size_t)P->far_ways + way];
+                if (((code << P->tag_bits) | (hf & tmask)) > *e) *e = (code << P->tag_bits) | (hf & tmask);
+                if (P->far_short) {
+                    uint32_t hg = hash_short(v, P->far_log + P->tag_bits, P->short_bytes);
+                    e = &c->fs[(size_t)(hg >> P->tag_bits) * (size_t)P->far_ways + way];
+                    if (((code << P->tag_bits) | (hg & tmask)) > *e) *e = (code << P->tag_bits) | (hg & tmask);
+                }
             }
         }
         {
@@ -794,7 +856,9 @@ static uint32_t matchfind_block(mf_ctx *c, size_t bs, size_t be, zge_seq *seq, u
         }
     }
     (void)i;
+    c->erep0 = erep0; c->erep1 = erep1;
     *nlit = lp;
+    nseq = merge_sequences(seq, nseq);
     resolve_repcodes(seq, nseq, c->st);
     return nseq;
 }
@@ -818,8 +882,10 @@ void zge_default_params(zge_params *P, int level)
     P->back_cap = 8; P->lazy = level >= 2 || level == 0 ? 1 : 0; P->lazy_delta = 5; /* engine.hip: derive_params */
     P->lit_cost = 5; P->match_cost = 12; P->rep_cost = 9;
     P->window_log = 21; P->short_window_log = 30;
+    P->far_log = 16; P->far_ways = 1; P->far_step_log = 3; P->far_short = 0;
     if (level >= 9) { /* the engine's deep finder (engine.hip: derive_params) */
         P->long_log = 14; P->short_log = 14; P->short_bytes = 4; P->min_match = 4; P->match_cost = 10; P->window_log = 22;
+        P->far_ways = 4; P->far_step_log = 1; P->far_short = 1;
     }
 }
 
@@ -848,8 +914,15 @@ int zge_encode_frame(const zge_params *P, const void *src_, size_t n, void *dst_
         if (!single) dst[pos++] = (uint8_t)((wlog - 10) << 3);
         for (i = 0; i < fcs_bytes; i++) dst[pos++] = (uint8_t)(v >> (8 * i));
     }
-    c.P = P; c.src = src; c.n = n; c.st = st; c.cold = 0; c.skip_left = 0;
+    c.P = P; c.src = src; c.n = n; c.st = st; c.cold = 0; c.skip_left = 0; c.erep0 = 0; c.erep1 = 0;
     c.window = single ? (n ? n : 1) : ((size_t)1 << wlog);
+    {
+        const size_t fw = P->far_log ? ((size_t)1 << P->far_log) * (size_t)P->far_ways : 1;
+        if (P->far_log && (P->far_ways < 1 || P->far_ways * (1 + (P->far_short ? 1 : 0)) > ZGE_FAR_MAX)) return -2;
+        c.fl = (uint32_t *)calloc(fw, 4);
+        c.fs = (uint32_t *)calloc(fw, 4);
+        c.farc = (uint32_t *)calloc((size_t)P->tile * ZGE_FAR_MAX, 4);
+    }
     c.tl = (uint32_t *)calloc((size_t)1 << P->long_log, 4);
     c.ts = (uint32_t *)calloc((size_t)1 << P->short_log, 4);
     c.M = (cand *)calloc((size_t)P->tile, sizeof(cand));
@@ -868,6 +941,10 @@ int zge_encode_frame(const zge_params *P, const void *src_, size_t n, void *dst_
         /* table positions are relative to 2^seg_log segments (multiples of the block size): at a boundary the
          * tables are cleared, so candidates never cross it (only frames larger than a segment notice) */
         if (bs > 0 && (bs & (((size_t)1 << P->seg_log) - 1)) == 0) {
+            if (P->far_log) {
+                memset(c.fl, 0, (sizeof(uint32_t) << P->far_log) * (size_t)P->far_ways);
+                memset(c.fs, 0, (sizeof(uint32_t) << P->far_log) * (size_t)P->far_ways);
+            }
             memset(c.tl, 0, sizeof(uint32_t) << P->long_log);
             memset(c.ts, 0, sizeof(uint32_t) << P->short_log);
         }
@@ -908,7 +985,7 @@ int zge_encode_frame(const zge_params *P, const void *src_, size_t n, void *dst_
         uint32_t x = (uint32_t)oracle_xxh64(src, n, 0);
         dst[pos++] = (uint8_t)x; dst[pos++] = (uint8_t)(x >> 8); dst[pos++] = (uint8_t)(x >> 16); dst[pos++] = (uint8_t)(x >> 24);
     }
-    free(c.tl); free(c.ts); free(c.M); free(c.M2); free(c.next); free(c.take); free(c.mark); free(seq); free(lit); free(blk);
+    free(c.fl); free(c.fs); free(c.farc); free(c.tl); free(c.ts); free(c.M); free(c.M2); free(c.next); free(c.take); free(c.mark); free(seq); free(lit); free(blk);
     *out_len = pos;
     return 0;
 }

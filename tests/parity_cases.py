@@ -56,12 +56,19 @@ def encode_cases(corpus, big):
          # random | the same random again (a far repeat that starts inside an unsearched stretch) | records
          "cold_hot": corpus.entry(21, 40000, 3) + corpus.entry(22, 30000, 0) + corpus.entry(23, 50000, 3) + corpus.entry(23, 50000, 3)
                      + corpus.entry(24, 20000, 1),
-         "cold_tail": corpus.entry(25, 9000, 0) + corpus.entry(26, 131072 + 5000, 3)}   # stretch crosses a block boundary
+         "cold_tail": corpus.entry(25, 9000, 0) + corpus.entry(26, 131072 + 5000, 3),   # stretch crosses a block boundary
+         # one match per block once the 256-byte pieces are joined (runs of several hundred pieces: many rounds of the join pass)
+         "periodic": bytes(range(200)) * 1500,
+         # a repeat 120 KB back: long forgotten by the LDS tables, found through the far table in HBM; joined pieces across tiles
+         "far_repeat": corpus.entry(27, 60000, 0) + corpus.entry(28, 60000, 1) + corpus.entry(27, 60000, 0) + corpus.entry(28, 30000, 1),
+         "far_text": corpus.entry(29, 150000, 0) + corpus.entry(29, 150000, 0)[777:90000]}
     if big:
         for k in range(4):
             c["k%d_1m" % k] = corpus.entry(40 + k, 1 << 20, k)
         c["k1_2m5"] = corpus.entry(1, (5 << 20) // 2, 1)   # > 2^21: window-descriptor frame
         c["k0_4m"] = corpus.entry(12, 4 << 20, 0)
+        c["periodic_4m"] = bytes(range(200)) * 20000   # crosses the 2 MiB table segment: the recent-offset guess carries the match over
+        c["far_2m3"] = corpus.entry(13, 1 << 20, 0) + corpus.entry(14, 300000, 2) + corpus.entry(13, 1 << 20, 0)
     return c
 
 
@@ -175,6 +182,11 @@ def check_params(engine):
         engine.set_parameter(_lib.P_COMPRESSION_LEVEL, 23)
     with pytest.raises(ZarcGpuError):
         engine.set_parameter(400, 4)      # NbWorkers: known to libzstd, unsupported here
+    for pid in (_lib.P_HASH_LOG, _lib.P_CHAIN_LOG, _lib.P_SEARCH_LOG, _lib.P_TARGET_LENGTH, _lib.P_STRATEGY):
+        engine.set_parameter(pid, 0)      # "use the default" is the one value the fixed-size kernels can honour
+        with pytest.raises(ZarcGpuError) as ei:
+            engine.set_parameter(pid, 7)
+        assert ei.value.code == _lib.E_UNSUPPORTED
     with pytest.raises(ZarcGpuError):
         engine.set_parameter(31337, 1)    # unknown id
     assert engine.params().checksum_flag == 1

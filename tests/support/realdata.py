@@ -1,0 +1,51 @@
+"""Deterministic "real data" inputs built from files every copy of the image carries (test infrastructure only).
+
+The synthetic corpus (zarc_amd/csrc/corpus.h) is the benchmark's input; the ratio contract ("within 5 % of libzstd") also has to
+hold on ordinary data.  Each item is a tar-like concatenation (512-byte name header + content padded to 512) of sorted files, cut
+at a fixed size, or a slice of a large binary, or a generated periodic buffer.  Items whose source is missing on a box are skipped
+by name (the tests say so loudly).
+"""
+import glob
+import os
+
+
+def _tarlike(paths, limit):
+    out = bytearray()
+    for p in paths:
+        try:
+            with open(p, "rb") as f:
+                data = f.read()
+        except OSError:
+            continue
+        hdr = os.path.basename(p).encode()[:100].ljust(100, b"\0") + b"0000644\0" + ("%011o\0" % len(data)).encode()
+        out += hdr.ljust(512, b"\0") + data + b"\0" * (-len(data) % 512)
+        if len(out) >= limit:
+            break
+    return bytes(out[:limit])
+
+
+def _slice(path, off, n):
+    with open(path, "rb") as f:
+        f.seek(off)
+        return f.read(n)
+
+
+def items():
+    """name -> bytes (or None when the source is absent here)"""
+    out = {}
+    py = sorted(glob.glob("/usr/lib/python3.10/*.py"))
+    out["py_stdlib_4m"] = _tarlike(py, 4 << 20) if len(py) > 100 else None
+    hdrs = sorted(glob.glob("/opt/rocm/include/**/*.h", recursive=True))
+    out["rocm_headers_4m"] = _tarlike(hdrs, 4 << 20) if len(hdrs) > 100 else None
+    js = sorted(glob.glob("/opt/conda/conda-meta/*.json"))
+    out["json_2m"] = _tarlike(js, 2 << 20) if len(js) > 20 else None
+    elf = "/opt/rocm/lib/libMIOpen.so.1"
+    if os.path.exists(elf) and os.path.getsize(elf) > (600 << 20):
+        out["elf_head_4m"] = _slice(elf, 0, 4 << 20)
+        out["elf_mid_4m"] = _slice(elf, 512 << 20, 4 << 20)
+    else:
+        out["elf_head_4m"] = out["elf_mid_4m"] = None
+    out["periodic_4m"] = bytes(range(200)) * 20000
+    md = sorted(glob.glob("/opt/skills/guides/*.md"))
+    out["guides_md"] = _tarlike(md, 1 << 20) if md else None
+    return out

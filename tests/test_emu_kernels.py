@@ -2,6 +2,7 @@
 same C ABI, checked against the oracle.  Catches logic errors, divergent barriers and (with the asan target)
 out-of-bounds accesses before any GPU time is spent.  Small inputs: the emulator is slow."""
 import parity_cases as pc
+from zarc_amd import _lib
 
 
 def test_emu_blake3(emu_engine, oracle, corpus):
@@ -37,20 +38,26 @@ def test_emu_unpack_fuzz_agrees_with_oracle(emu_engine, oracle, corpus, golden_f
     assert bad > 40 and ok >= 0
 
 
-def test_emu_host_staging_in_chunks(emu_engine, oracle, corpus, golden_frames, monkeypatch):
+def test_emu_host_staging_in_chunks(emu_engine, oracle, corpus, golden_frames):
     """The host-pointer entry points cut a batch into chunks and overlap their copies: with a tiny chunk size every
     batch below runs through many chunks, double-buffered arenas and the helper thread; results must not change."""
-    monkeypatch.setenv("ZARC_GPU_STAGE_CHUNK", "20000")
-    pc.check_roundtrip(emu_engine, oracle, corpus, big=False)
-    pc.check_unpack_errors(emu_engine, oracle, corpus, golden_frames)
-    pc.check_store(emu_engine, oracle, corpus, [])
+    emu_engine.set_parameter(_lib.PX_STAGE_CHUNK, 20000)
+    try:
+        pc.check_roundtrip(emu_engine, oracle, corpus, big=False)
+        pc.check_unpack_errors(emu_engine, oracle, corpus, golden_frames)
+        pc.check_store(emu_engine, oracle, corpus, [])
+    finally:
+        emu_engine.set_parameter(_lib.PX_STAGE_CHUNK, 0)
 
 
-def test_emu_pack_in_sub_batches(emu_engine, oracle, corpus, libzstds, monkeypatch):
+def test_emu_pack_in_sub_batches(emu_engine, oracle, corpus, libzstds):
     """A batch whose encoder scratch does not fit the budget is packed in several sub-batches (scratch reused between them):
     frames must not change."""
-    monkeypatch.setenv("ZARC_GPU_SCRATCH_MB", "1")
-    pc.check_pack(emu_engine, oracle, corpus, libzstds, big=False)
+    emu_engine.set_parameter(_lib.PX_SCRATCH_MB, 1)
+    try:
+        pc.check_pack(emu_engine, oracle, corpus, libzstds, big=False)
+    finally:
+        emu_engine.set_parameter(_lib.PX_SCRATCH_MB, 0)
 
 
 def test_emu_level9_deep_finder_matches_model(emu_lib_path, oracle, corpus):
@@ -61,6 +68,7 @@ def test_emu_level9_deep_finder_matches_model(emu_lib_path, oracle, corpus):
         e9.set_parameter(_lib.P_CHECKSUM_FLAG, 1)
         e9.set_parameter(_lib.P_COMPRESSION_LEVEL, 9)
         raws = [corpus.entry(9100 + i, n, i & 3) for i, n in enumerate((0, 70000, 200000, 300001))]
+        raws += [bytes(range(200)) * 700, corpus.entry(27, 60000, 0) + corpus.entry(28, 90000, 1) + corpus.entry(27, 60000, 0)]  # joined pieces, far tables (4 ways)
         for raw, (frame, dig) in zip(raws, e9.pack(raws)):
             assert frame == oracle.zge_encode(raw, oracle.params(level=9))
             assert dig == oracle.blake3(raw)
@@ -69,7 +77,7 @@ def test_emu_level9_deep_finder_matches_model(emu_lib_path, oracle, corpus):
 
 
 def test_emu_sequence_stage_split_between_both_kernels(emu_engine, oracle, corpus, golden_frames, monkeypatch):
-    """ZARC_GPU_SEQ_LDS_FRAC sends part of the blocks to the sequence kernel that keeps its tables in LDS: same results."""
+    """ZARC_GPU_SEQ_LDS_FRAC (diagnostic builds only; the emulator library is one) sends part of the blocks to the sequence kernel that keeps its tables in LDS: same results."""
     monkeypatch.setenv("ZARC_GPU_SEQ_LDS_FRAC", "0.5")
     pc.check_unpack_golden(emu_engine, oracle, corpus, golden_frames)
     pc.check_roundtrip(emu_engine, oracle, corpus, big=False)

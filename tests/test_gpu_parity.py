@@ -146,24 +146,33 @@ def test_gpu_unpack_fuzz_agrees_with_oracle(engine, oracle, corpus, golden_frame
     assert tot_bad > 1000
 
 
-def test_gpu_host_staging_in_chunks(engine, oracle, corpus, golden_frames, libzstds, monkeypatch):
+def test_gpu_host_staging_in_chunks(engine, oracle, corpus, golden_frames, libzstds):
     """Host-pointer entry points with many small chunks (double-buffered arenas, helper thread copies overlapping the kernels)."""
-    monkeypatch.setenv("ZARC_GPU_STAGE_CHUNK", "300000")
-    pc.check_roundtrip(engine, oracle, corpus, big=True)
-    pc.check_unpack_errors(engine, oracle, corpus, golden_frames)
-    pc.check_store(engine, oracle, corpus, libzstds)
-    pc.check_pack(engine, oracle, corpus, libzstds, big=True)
+    engine.set_parameter(_lib.PX_STAGE_CHUNK, 300000)
+    try:
+        pc.check_roundtrip(engine, oracle, corpus, big=True)
+        pc.check_unpack_errors(engine, oracle, corpus, golden_frames)
+        pc.check_store(engine, oracle, corpus, libzstds)
+        pc.check_pack(engine, oracle, corpus, libzstds, big=True)
+    finally:
+        engine.set_parameter(_lib.PX_STAGE_CHUNK, 0)
 
 
-def test_gpu_pack_in_sub_batches(engine, oracle, corpus, libzstds, monkeypatch):
+def test_gpu_pack_in_sub_batches(engine, oracle, corpus, libzstds):
     """Encoder scratch budget of 2 MiB: every few blocks form their own sub-batch (scratch reuse, per-sub-batch queues)."""
-    monkeypatch.setenv("ZARC_GPU_SCRATCH_MB", "2")
-    pc.check_pack(engine, oracle, corpus, libzstds, big=True)
-    pc.check_roundtrip(engine, oracle, corpus, big=True)
+    engine.set_parameter(_lib.PX_SCRATCH_MB, 2)
+    try:
+        pc.check_pack(engine, oracle, corpus, libzstds, big=True)
+        pc.check_roundtrip(engine, oracle, corpus, big=True)
+    finally:
+        engine.set_parameter(_lib.PX_SCRATCH_MB, 0)
 
 
-def test_gpu_sequence_stage_split_between_both_kernels(engine, oracle, corpus, golden_frames, monkeypatch):
-    monkeypatch.setenv("ZARC_GPU_SEQ_LDS_FRAC", "0.5")
-    pc.check_unpack_golden(engine, oracle, corpus, golden_frames)
-    pc.check_roundtrip(engine, oracle, corpus, big=True)
-    pc.check_unpack_fuzz(engine, oracle, corpus, golden_frames, 1500, seed=77)
+def test_gpu_environment_cannot_change_the_frames(engine, oracle, corpus, libzstds, monkeypatch):
+    """The product library reads no environment variable: with last round's debug / steering switches set, frames are still
+    bit-identical to the model and decode (the switches only exist in the diagnostic build, make DIAG=1)."""
+    for k, v in (("ZARC_GPU_DBG", "7"), ("ZARC_GPU_CAP", "16"), ("ZARC_GPU_DBG_DEC", "1"), ("ZARC_GPU_DEC_FAST", "0"),
+                 ("ZARC_GPU_SEQ_LANES", "16"), ("ZARC_GPU_SEQ_LDS_FRAC", "0.5"), ("ZARC_GPU_SCRATCH_MB", "1"), ("ZARC_GPU_STAGE_CHUNK", "4096")):
+        monkeypatch.setenv(k, v)
+    pc.check_pack(engine, oracle, corpus, libzstds, big=False)
+    pc.check_roundtrip(engine, oracle, corpus, big=False)

@@ -58,7 +58,7 @@ struct zarc_gpu {
     // hashing
     DevBuf d_cvs, d_cvs_tmp, d_digests, d_xxh, d_expect;
     // encoder
-    DevBuf d_blocks, d_seq, d_lit, d_out;
+    DevBuf d_blocks, d_seq, d_lit, d_out, d_far;
     // decoder
     DevBuf d_declit, d_status, d_stored_ck;
     DevBuf d_slot_prefix, d_zblocks, d_nseq, d_fast, d_seqidx, d_seqs, d_ztables, d_litidx, d_lits; // decoder fast path (sequences decoded ahead)
@@ -68,7 +68,10 @@ struct zarc_gpu {
     DevBuf d_arena_in, d_arena_out;
     hipEvent_t ev[16] = {};
     float ms[ZARC_GPU_T_COUNT];
-    size_t scratch_budget = 0; // 0 = derive from free memory
+    size_t scratch_budget = 0; // 0 = derive from free memory (ZARC_GPU_PX_SCRATCH_MB)
+    uint64_t stage_chunk = 0;  // 0 = default per entry point (ZARC_GPU_PX_STAGE_CHUNK)
+    int stage_thread = 1;      // ZARC_GPU_PX_STAGE_THREAD
+    int copy_threads = 8;      // ZARC_GPU_PX_COPY_THREADS
 };
 
 namespace {
@@ -84,6 +87,16 @@ namespace {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Timing ablations and kernel-steering switches exist only in the diagnostic build (make DIAG=1 -> libzarc_gpu_diag.so, used by
+// tools/): the product library never reads them, so no environment variable can change the bytes it produces.
+#ifdef ZARC_GPU_DIAG
+inline int diag_env(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
+inline double diag_env_f(const char *name, double dflt) { const char *e = getenv(name); return e ? atof(e) : dflt; }
+#else
+inline int diag_env(const char *, int dflt) { return dflt; }
+inline double diag_env_f(const char *, double dflt) { return dflt; }
+#endif
+
 ZgeParams derive_params(const zarc_gpu_params &p)
 {
     ZgeParams z{};
@@ -97,13 +110,16 @@ ZgeParams derive_params(const zarc_gpu_params &p)
     // lower match cost -- within 5 % of libzstd -9 on the corpus, at about half the speed of the level-3 finder
     const bool deep = level >= 9;
     z.long_log = deep ? 14 : 13; z.short_log = z.long_log; z.short_bytes = deep ? 4 : 5; z.tag_bits = 10; z.seg_log = 21; z.rep_back = 256;
-    z.tile = 1024; z.sub = 64; z.cap = getenv("ZARC_GPU_CAP") ? atoi(getenv("ZARC_GPU_CAP")) : 256;
+    z.tile = 1024; z.sub = 64; z.cap = diag_env("ZARC_GPU_CAP", 256);
     z.min_match = p.min_match >= 4 && p.min_match <= 7 ? p.min_match : (deep ? 4 : 5);
     z.min_rep = 3; z.rep_search = 2; z.back_cap = 8;
     z.lazy = level >= 2 ? 1 : 0; z.lazy_delta = 5;
     z.lit_cost = 5; z.match_cost = deep ? 10 : 12; z.rep_cost = 9;
     z.short_window_log = 30;
-    { const char *d = getenv("ZARC_GPU_DBG"); z.dbg = d ? atoi(d) : 0; } // timing-only ablations (outputs invalid when set)
+    // far tables in HBM (zge_match.hip): 2^16 buckets; level 3: one way on the long hash, every 8th position inserted;
+    // level >= 9: four ways on both hashes, every 2nd position
+    z.far_log = 16; z.far_ways = deep ? 4 : 1; z.far_step_log = deep ? 1 : 3; z.far_short = deep ? 1 : 0;
+    z.dbg = diag_env("ZARC_GPU_DBG", 0); // timing-only ablations (outputs invalid when set): diagnostic build only
     return z;
 }
 
@@ -219,7 +235,7 @@ void zarc_gpu_destroy(zarc_gpu_t *h)
     (void)hipStreamSynchronize(h->stream);
     DevBuf *all[] = {&h->d_off, &h->d_len, &h->d_chunk_prefix, &h->d_block_prefix, &h->d_order, &h->d_dst_off, &h->d_dst_len, &h->d_raw_len,
                      &h->d_frame_off, &h->d_frame_len, &h->d_cvs, &h->d_cvs_tmp, &h->d_digests, &h->d_xxh, &h->d_expect, &h->d_blocks, &h->d_seq,
-                     &h->d_lit, &h->d_out, &h->d_declit, &h->d_status, &h->d_stored_ck, &h->d_arena_in, &h->d_arena_out, &h->d_queue,
+                     &h->d_lit, &h->d_out, &h->d_far, &h->d_declit, &h->d_status, &h->d_stored_ck, &h->d_arena_in, &h->d_arena_out, &h->d_queue,
                      &h->d_slot_prefix, &h->d_zblocks, &h->d_nseq, &h->d_fast, &h->d_seqidx, &h->d_seqs, &h->d_ztables, &h->d_litidx, &h->d_lits};
     for (DevBuf *b : all) b->release();
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
@@ -245,16 +261,22 @@ int zarc_gpu_set_parameter(zarc_gpu_t *h, int id, int value)
     case ZARC_GPU_P_WINDOW_LOG:
         if (value != 0 && (value < 10 || value > 27)) return ZARC_GPU_E_PARAM;
         h->params.window_log = value; return ZARC_GPU_OK;
-    case ZARC_GPU_P_HASH_LOG: h->params.hash_log = value; return ZARC_GPU_OK;       // accepted; table sizes are fixed by LDS
-    case ZARC_GPU_P_CHAIN_LOG: h->params.chain_log = value; return ZARC_GPU_OK;     // accepted, ignored
-    case ZARC_GPU_P_SEARCH_LOG: h->params.search_log = value; return ZARC_GPU_OK;   // accepted, ignored
+    case ZARC_GPU_P_HASH_LOG: case ZARC_GPU_P_CHAIN_LOG: case ZARC_GPU_P_SEARCH_LOG: case ZARC_GPU_P_TARGET_LENGTH: case ZARC_GPU_P_STRATEGY:
+        // table sizes, search depth and strategy are fixed by the kernels: 0 (= libzstd's "use the default") is the only value taken
+        return value == 0 ? ZARC_GPU_OK : ZARC_GPU_E_UNSUPPORTED;
     case ZARC_GPU_P_MIN_MATCH:
         if (value != 0 && (value < 3 || value > 7)) return ZARC_GPU_E_PARAM;
         h->params.min_match = value; return ZARC_GPU_OK;
-    case ZARC_GPU_P_TARGET_LENGTH: h->params.target_length = value; return ZARC_GPU_OK;
-    case ZARC_GPU_P_STRATEGY:
-        if (value < 0 || value > 9) return ZARC_GPU_E_PARAM;
-        h->params.strategy = value; return ZARC_GPU_OK;
+    case ZARC_GPU_PX_SCRATCH_MB:
+        if (value < 0) return ZARC_GPU_E_PARAM;
+        h->scratch_budget = (size_t)value << 20; return ZARC_GPU_OK;
+    case ZARC_GPU_PX_STAGE_CHUNK:
+        if (value != 0 && value < 4096) return ZARC_GPU_E_PARAM;
+        h->stage_chunk = (uint64_t)value; return ZARC_GPU_OK;
+    case ZARC_GPU_PX_STAGE_THREAD: h->stage_thread = value ? 1 : 0; return ZARC_GPU_OK;
+    case ZARC_GPU_PX_COPY_THREADS:
+        if (value < 1 || value > 64) return ZARC_GPU_E_PARAM;
+        h->copy_threads = value; return ZARC_GPU_OK;
     case ZARC_GPU_P_CONTENT_SIZE_FLAG:
         if (value != 1) return ZARC_GPU_E_UNSUPPORTED; // frames always carry their content size
         return ZARC_GPU_OK;
@@ -357,7 +379,8 @@ int zarc_gpu_pack_batch_device(zarc_gpu_t *h, size_t n, const void *d_src_base, 
     const ZgeParams P = derive_params(h->params);
     // the match finder has these compiled in (zge_match.hip: F_*)
     if (P.rep_back != 256 || P.back_cap != 8 || P.lazy_delta != 5 || P.min_rep != 3 || P.rep_search != 2 || P.seg_log != 21 || P.short_window_log < 30 ||
-        P.lit_cost != 5 || P.rep_cost != 9 || P.tag_bits != 10) { h->last_error = "internal: encoder parameters differ from the compiled-in ones"; return ZARC_GPU_E_PARAM; }
+        P.lit_cost != 5 || P.rep_cost != 9 || P.tag_bits != 10 || P.far_log != 16 || P.far_ways != (P.long_log == 14 ? 4 : 1) ||
+        P.far_step_log != (P.long_log == 14 ? 1 : 3) || (P.far_short != 0) != (P.long_log == 14)) { h->last_error = "internal: encoder parameters differ from the compiled-in ones"; return ZARC_GPU_E_PARAM; }
     uint64_t need = 0;
     for (size_t i = 0; i < n; i++) {
         if (src_off[i] % ZARC_GPU_ALIGN) { h->last_error = "entry offset not 16-byte aligned"; return ZARC_GPU_E_PARAM; }
@@ -414,7 +437,6 @@ int zarc_gpu_pack_batch_device(zarc_gpu_t *h, size_t n, const void *d_src_base, 
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return src_len[a] > src_len[b]; });
     const size_t per_block = (size_t)ZARC_MAX_SEQ * 8 + (ZARC_BLOCK + 64) + (ZARC_BLOCK + 1024) + sizeof(ZgeBlock);
     size_t budget = h->scratch_budget;
-    if (const char *e = getenv("ZARC_GPU_SCRATCH_MB")) budget = (size_t)std::max(1, atoi(e)) << 20; // tests force several sub-batches
     if (!budget) {
         // up to 64 GiB of scratch (BASELINE configs[1] needs 46 GiB to run as ONE launch per kernel), at most 45 % of what is free
         size_t free_b = 0, total_b = 0;
@@ -449,9 +471,14 @@ int zarc_gpu_pack_batch_device(zarc_gpu_t *h, size_t n, const void *d_src_base, 
         ZHIP(hipMemsetAsync(h->d_queue.p, 0, 256, h->stream));
         const bool deep = P.long_log == 14;
         const size_t match_grid = std::min<size_t>(m, (size_t)h->num_cus * (deep ? 1 : 2)); // two 80 KiB workgroups fit a CU, one of 145 KiB
-        hipLaunchKernelGGL(deep ? zarc_zge_match_deep : (P.dbg ? zarc_zge_match_diag : zarc_zge_match), dim3((unsigned)match_grid), dim3(512), 0, h->stream, P, base, d_off, d_len, h->d_order.as<uint32_t>(), (uint32_t)m,
+        ZHIP(h->d_far.reserve(match_grid * zge_far_words(P) * 4 + 16)); // one far-table slab per resident workgroup (cleared by the kernel per frame)
+        auto match_kernel = deep ? zarc_zge_match_deep : zarc_zge_match;
+#ifdef ZARC_GPU_DIAG
+        if (!deep && P.dbg) match_kernel = zarc_zge_match_diag;
+#endif
+        hipLaunchKernelGGL(match_kernel, dim3((unsigned)match_grid), dim3(512), 0, h->stream, P, base, d_off, d_len, h->d_order.as<uint32_t>(), (uint32_t)m,
                            h->d_block_prefix.as<uint64_t>(), h->d_blocks.as<ZgeBlock>(), h->d_seq.as<uint64_t>(), h->d_lit.as<uint8_t>(),
-                           h->d_queue.as<uint32_t>());
+                           h->d_queue.as<uint32_t>(), h->d_far.as<uint32_t>());
         ZHIP(hipGetLastError());
         ZHIP(t.mark(&b));
         hipLaunchKernelGGL(zarc_zge_entropy, dim3((unsigned)nb), dim3(64), 0, h->stream, (uint32_t)nb, h->d_blocks.as<ZgeBlock>(),
@@ -532,7 +559,7 @@ int zarc_gpu_unpack_batch_device(zarc_gpu_t *h, size_t n, const void *d_frames_b
     int e0, e1, e2, e3;
     ZHIP(t.mark(&e0));
     // ---- fast path: block scan (lane per frame), then sequence entropy decoding with one lane per block ----
-    bool fastpath = !(getenv("ZARC_GPU_DEC_FAST") && atoi(getenv("ZARC_GPU_DEC_FAST")) == 0);
+    bool fastpath = diag_env("ZARC_GPU_DEC_FAST", 1) != 0;
     std::vector<uint64_t> slot_prefix(n + 1, 0);
     for (size_t i = 0; i < n; i++) slot_prefix[i + 1] = slot_prefix[i] + raw_len[i] / ZARC_BLOCK + 2; // blocks a well-formed frame needs, plus slack
     const size_t nslots = (size_t)slot_prefix[n];
@@ -562,7 +589,7 @@ int zarc_gpu_unpack_batch_device(zarc_gpu_t *h, size_t n, const void *d_frames_b
         ZHIP(h->d_seqs.reserve(std::max<uint64_t>(total, 1) * 8));
         ZHIP(h->d_lits.reserve(std::max<uint64_t>(lit_total, 1) + 64));
         // the literal and the sequence kernels are independent and neither fills the chip: they run side by side
-        const bool side = lit_total && total && !(getenv("ZARC_GPU_DEC_SIDE") && atoi(getenv("ZARC_GPU_DEC_SIDE")) == 0);
+        const bool side = lit_total && total && diag_env("ZARC_GPU_DEC_SIDE", 1) != 0;
         if (side) { ZHIP(hipEventRecord(h->ev_fork, h->stream)); ZHIP(hipStreamWaitEvent(h->stream2, h->ev_fork, 0)); }
         if (lit_total) {
             hipLaunchKernelGGL(zarc_zdec_literals, dim3((unsigned)((nslots + ZDEC_LIT_GROUP - 1) / ZDEC_LIT_GROUP)), dim3(64), 0, side ? h->stream2 : h->stream, (const uint8_t *)d_frames_base,
@@ -574,11 +601,11 @@ int zarc_gpu_unpack_batch_device(zarc_gpu_t *h, size_t n, const void *d_frames_b
             // Each lane is a long serial chain (about one L2/HBM round trip and 340 instructions per sequence).  Partly filled
             // waves (more waves to interleave) were measured and are slower: 35 ms with 64 lanes per wave, 54 ms with 16
             // (ZARC_GPU_SEQ_LANES reproduces it) -- the waves' own instruction issue dominates, not exposed waits.
-            int seq_lanes = getenv("ZARC_GPU_SEQ_LANES") ? atoi(getenv("ZARC_GPU_SEQ_LANES")) : 64;
+            int seq_lanes = diag_env("ZARC_GPU_SEQ_LANES", 64);
             if (seq_lanes != 8 && seq_lanes != 16 && seq_lanes != 32 && seq_lanes != 64) seq_lanes = 64;
             // The two sequence kernels stress different things (zarc_zdec_seqs: HBM / MALL bandwidth; zarc_zdec_seqs_lds: nothing
             // but its own serial chains, one wave per SIMD), so the slots are split between them and they run side by side.
-            double frac = getenv("ZARC_GPU_SEQ_LDS_FRAC") ? atof(getenv("ZARC_GPU_SEQ_LDS_FRAC")) : 0.0;
+            double frac = diag_env_f("ZARC_GPU_SEQ_LDS_FRAC", 0.0);
             if (frac < 0) frac = 0;
             if (frac > 1) frac = 1;
             const uint64_t split = frac <= 0 ? (uint64_t)nslots : (uint64_t)((double)nslots * (1.0 - frac)) / 64 * 64; // slots [0, split): tables in HBM scratch; [split, nslots): in LDS
@@ -600,7 +627,7 @@ int zarc_gpu_unpack_batch_device(zarc_gpu_t *h, size_t n, const void *d_frames_b
         }
         if (side) { ZHIP(hipEventRecord(h->ev_join, h->stream2)); ZHIP(hipStreamWaitEvent(h->stream, h->ev_join, 0)); }
     }
-    const int dec_dbg = getenv("ZARC_GPU_DBG_DEC") ? atoi(getenv("ZARC_GPU_DBG_DEC")) : 0;
+    const int dec_dbg = diag_env("ZARC_GPU_DBG_DEC", 0);
     ZHIP(hipMemsetAsync(h->d_queue.p, 0, 8, h->stream)); // two queues: the fast frame pass and the general decoder each walk all frames
     if (fastpath) {
         hipLaunchKernelGGL(zarc_zstd_frames, dim3((unsigned)dec_grid), dim3(64), 0, h->stream, (const uint8_t *)d_frames_base, h->d_frame_off.as<uint64_t>(),
@@ -611,7 +638,7 @@ int zarc_gpu_unpack_batch_device(zarc_gpu_t *h, size_t n, const void *d_frames_b
         ZHIP(hipGetLastError());
     }
     // frames the fast path turned down (or all of them when it is off) are decoded inline; with nothing to do every wave leaves at once
-    hipLaunchKernelGGL(zarc_zstd_decode, dim3((unsigned)dec_grid), dim3(64), getenv("ZARC_GPU_DEC_PADLDS") ? atoi(getenv("ZARC_GPU_DEC_PADLDS")) : 0, h->stream,
+    hipLaunchKernelGGL(zarc_zstd_decode, dim3((unsigned)dec_grid), dim3(64), (size_t)diag_env("ZARC_GPU_DEC_PADLDS", 0), h->stream,
                        (const uint8_t *)d_frames_base, h->d_frame_off.as<uint64_t>(), h->d_frame_len.as<uint64_t>(), (uint8_t *)d_dst_base,
                        h->d_dst_off.as<uint64_t>(), h->d_raw_len.as<uint64_t>(), h->d_order.as<uint32_t>(), (uint32_t)n, h->d_declit.as<uint8_t>(),
                        h->d_status.as<int32_t>(), h->d_stored_ck.as<uint32_t>(), dec_dbg, h->d_queue.as<uint32_t>() + 1,
@@ -636,7 +663,7 @@ int zarc_gpu_unpack_batch_device(zarc_gpu_t *h, size_t n, const void *d_frames_b
     ZHIP(hipMemcpyAsync(status, h->d_status.p, n * 4, hipMemcpyDeviceToHost, h->stream));
     ZHIP(hipMemcpyAsync(digest, h->d_digests.p, n * 32, hipMemcpyDeviceToHost, h->stream));
     ZHIP(hipStreamSynchronize(h->stream));
-    if (fastpath && getenv("ZARC_GPU_DEC_STATS")) { // diagnostics: how many frames had their sequences decoded ahead
+    if (fastpath && diag_env("ZARC_GPU_DEC_STATS", 0)) { // diagnostics: how many frames had their sequences decoded ahead
         std::vector<uint32_t> fl(n);
         ZHIP(hipMemcpy(fl.data(), h->d_fast.p, n * 4, hipMemcpyDeviceToHost));
         size_t nf = 0;
@@ -674,11 +701,9 @@ int pin_ring(zarc_gpu *h)
 
 // copy the parts of `segs` (sorted by .dev, non-overlapping) that fall into device range [lo, hi) between the caller's memory
 // and `pinned` (which mirrors [lo, hi)), with several threads: the single-thread memcpy rate is far below PCIe
-void piece_copy(const std::vector<Seg> &segs, size_t first_seg, uint64_t lo, uint64_t hi, uint8_t *pinned, bool to_pinned)
+void piece_copy(const std::vector<Seg> &segs, size_t first_seg, uint64_t lo, uint64_t hi, uint8_t *pinned, bool to_pinned, unsigned want)
 {
     unsigned nt = std::thread::hardware_concurrency();
-    unsigned want = 8; // ZARC_GPU_COPY_THREADS overrides
-    if (const char *e = getenv("ZARC_GPU_COPY_THREADS")) want = (unsigned)std::max(1, atoi(e));
     nt = nt < 2 ? 1 : (nt > want ? want : nt);
     if (hi - lo < ((uint64_t)1 << 20)) nt = 1;
     auto work = [&](uint64_t a, uint64_t b) {
@@ -710,7 +735,7 @@ int staged_h2d(zarc_gpu *h, hipStream_t stream, const std::vector<Seg> &segs, ui
         const uint64_t hi = std::min<uint64_t>(total, lo + zarc_gpu::PIN_PIECE);
         while (first < segs.size() && segs[first].dev + segs[first].len <= lo) first++;
         ZHIP(hipEventSynchronize(h->pin_ev[slot])); // the transfer that last used this slot is over
-        piece_copy(segs, first, lo, hi, h->pin[slot], true);
+        piece_copy(segs, first, lo, hi, h->pin[slot], true, (unsigned)h->copy_threads);
         ZHIP(hipMemcpyAsync(dev_base + lo, h->pin[slot], hi - lo, hipMemcpyHostToDevice, stream));
         ZHIP(hipEventRecord(h->pin_ev[slot], stream));
     }
@@ -732,32 +757,21 @@ int staged_d2h(zarc_gpu *h, hipStream_t stream, const std::vector<Seg> &segs, co
         while (first < segs.size() && segs[first].dev + segs[first].len <= lo) first++;
         ZHIP(hipMemcpyAsync(h->pin[slot], dev_base + lo, hi - lo, hipMemcpyDeviceToHost, stream));
         ZHIP(hipEventRecord(h->pin_ev[slot], stream));
-        if (have_prev) { ZHIP(hipEventSynchronize(h->pin_ev[prev.slot])); piece_copy(segs, prev.first, prev.lo, prev.hi, h->pin[prev.slot], false); }
+        if (have_prev) { ZHIP(hipEventSynchronize(h->pin_ev[prev.slot])); piece_copy(segs, prev.first, prev.lo, prev.hi, h->pin[prev.slot], false, (unsigned)h->copy_threads); }
         prev = Piece{lo, hi, slot, first};
         have_prev = true;
     }
-    if (have_prev) { ZHIP(hipEventSynchronize(h->pin_ev[prev.slot])); piece_copy(segs, prev.first, prev.lo, prev.hi, h->pin[prev.slot], false); }
+    if (have_prev) { ZHIP(hipEventSynchronize(h->pin_ev[prev.slot])); piece_copy(segs, prev.first, prev.lo, prev.hi, h->pin[prev.slot], false, (unsigned)h->copy_threads); }
     return 0;
-}
-
-// bytes of (uncompressed) content per chunk; ZARC_GPU_STAGE_CHUNK overrides it (tests force many small chunks)
-uint64_t stage_chunk(uint64_t dflt)
-{
-    const char *e = getenv("ZARC_GPU_STAGE_CHUNK");
-    const long long v = e ? atoll(e) : 0;
-    return v >= 4096 ? (uint64_t)v : dflt;
 }
 
 struct Chunk { size_t i0, i1; uint64_t in_bytes, out_bytes; };
 
-// cut [0, n) into chunks of about stage_chunk(default) content bytes (at least one entry each)
-bool stage_threaded() { const char *e = getenv("ZARC_GPU_STAGE_THREAD"); return !(e && atoi(e) == 0); }
-
+// cut [0, n) into chunks of about STAGE_CHUNK content bytes (at least one entry each)
 std::vector<Chunk> make_chunks(size_t n, const std::vector<uint64_t> &in_sz, const std::vector<uint64_t> &out_sz, const std::vector<uint64_t> &weight,
-                               uint64_t dflt_chunk)
+                               uint64_t STAGE_CHUNK)
 {
     std::vector<Chunk> cs;
-    const uint64_t STAGE_CHUNK = stage_chunk(dflt_chunk);
     size_t i = 0;
     while (i < n) {
         Chunk c{i, i, 0, 0};
@@ -809,7 +823,7 @@ int zarc_gpu_pack_batch(zarc_gpu_t *h, size_t n, const void *const *src, const s
         need += out_sz[i];
     }
     if (need > dst_cap) return ZARC_GPU_E_DSTSIZE;
-    const std::vector<Chunk> cs = make_chunks(n, in_sz, out_sz, in_sz, (uint64_t)2 << 30); // measured: 1-2 GiB chunks pack fastest (27 vs 23 GiB/s at 4 GiB)
+    const std::vector<Chunk> cs = make_chunks(n, in_sz, out_sz, in_sz, h->stage_chunk ? h->stage_chunk : (uint64_t)2 << 30); // measured: 1-2 GiB chunks pack fastest (27 vs 23 GiB/s at 4 GiB)
     uint64_t max_in = 0, max_out = 0;
     for (const Chunk &c : cs) { max_in = std::max(max_in, c.in_bytes); max_out = std::max(max_out, c.out_bytes); }
     const uint64_t in_half = align_up(max_in + ZARC_GPU_PAD + 256, 256), out_half = align_up(max_out + ZARC_GPU_PAD, 256);
@@ -855,7 +869,7 @@ int zarc_gpu_pack_batch(zarc_gpu_t *h, size_t n, const void *const *src, const s
             if (hipStreamSynchronize(side) != hipSuccess) helper_rc = ZARC_GPU_E_DEVICE;
         };
         std::thread helper;
-        if (stage_threaded()) helper = std::thread(moves); else moves();
+        if (h->stage_thread) helper = std::thread(moves); else moves();
         const size_t m = cs[c].i1 - cs[c].i0, i0 = cs[c].i0;
         std::vector<uint64_t> off(m);
         uint64_t at = 0;
@@ -889,7 +903,7 @@ int zarc_gpu_unpack_batch(zarc_gpu_t *h, size_t n, const void *const *frame, con
         out_sz[i] = align_up(raw_len[i], ZARC_GPU_ALIGN);
         weight[i] = std::max(in_sz[i], out_sz[i]);
     }
-    const std::vector<Chunk> cs = make_chunks(n, in_sz, out_sz, weight, (uint64_t)4 << 30); // the decoder's lane-per-block stage wants many frames at once
+    const std::vector<Chunk> cs = make_chunks(n, in_sz, out_sz, weight, h->stage_chunk ? h->stage_chunk : (uint64_t)4 << 30); // the decoder's lane-per-block stage wants many frames at once
     uint64_t max_in = 0, max_out = 0;
     for (const Chunk &c : cs) { max_in = std::max(max_in, c.in_bytes); max_out = std::max(max_out, c.out_bytes); }
     const uint64_t in_half = align_up(max_in + ZARC_GPU_PAD + 256, 256), out_half = align_up(max_out + ZARC_GPU_PAD + 256, 256);
@@ -927,7 +941,7 @@ int zarc_gpu_unpack_batch(zarc_gpu_t *h, size_t n, const void *const *frame, con
             if (hipStreamSynchronize(side) != hipSuccess) helper_rc = ZARC_GPU_E_DEVICE;
         };
         std::thread helper;
-        if (stage_threaded()) helper = std::thread(moves); else moves();
+        if (h->stage_thread) helper = std::thread(moves); else moves();
         const size_t m = cs[c].i1 - cs[c].i0, i0 = cs[c].i0;
         std::vector<uint64_t> foff(m), doff(m);
         uint64_t fa = 0, da = 0;

@@ -99,6 +99,33 @@ __device__ __forceinline__ uint32_t shfl_up(uint32_t v, unsigned d) { return (ui
 __device__ __forceinline__ uint32_t shfl_down(uint32_t v, unsigned d) { return (uint32_t)__shfl_down((int)v, d, 64); }
 __device__ __forceinline__ uint32_t shfl_xor(uint32_t v, int m) { return (uint32_t)__shfl_xor((int)v, m, 64); }
 
+// Global-memory words that one workgroup updates with atomics and reads back later (the match finder's far tables).  Atomics
+// execute in L2; a plain load may be served by the CU's vector L1 and miss them, so the read-back is an agent-scope atomic load
+// (global_load ... sc1: served by L2).  The atomic has no return value (fire and forget).
+__device__ __forceinline__ uint32_t load_l2_u32(const uint32_t *p)
+{
+#ifdef ZARC_HIPEMU
+    return *p;
+#else
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+__device__ __forceinline__ void atomic_max_l2(uint32_t *p, uint32_t v)
+{
+#ifdef ZARC_HIPEMU
+    if (*p < v) *p = v;
+#else
+    (void)__hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+// wait until every vector-memory operation this wave has issued (loads, stores, atomics) is complete
+__device__ __forceinline__ void wait_vmem()
+{
+#ifndef ZARC_HIPEMU
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+
 // a store whose data is not read again by this kernel (non-temporal: does not displace what the caches should keep)
 __device__ __forceinline__ void store_streaming(uint64_t *p, uint64_t v)
 {

@@ -15,8 +15,11 @@ constexpr uint32_t ZARC_MAX_SEQ = ZARC_BLOCK / 3 + 8; // sequences per block (ev
 // ---- encoder tuning (mirrors oracle/zge_model.h zge_params; plain ints so the struct can be passed by value)
 struct ZgeParams {
     int level, checksum, window_log, long_log, short_log, short_bytes, tile, sub, cap, min_match, min_rep, rep_search,
-        back_cap, lazy, lazy_delta, lit_cost, match_cost, rep_cost, short_window_log, rep_back, tag_bits, seg_log, dbg;
+        back_cap, lazy, lazy_delta, lit_cost, match_cost, rep_cost, short_window_log, rep_back, tag_bits, seg_log,
+        far_log, far_ways, far_step_log, far_short, dbg;
 };
+// words of far-table scratch one match-finder workgroup needs (HBM): 2^far_log buckets x ways, once or twice
+__host__ __device__ inline size_t zge_far_words(const ZgeParams &P) { return P.far_log ? (((size_t)P.far_ways << P.far_log) * (P.far_short ? 2 : 1)) : 0; }
 
 // Per-block record written by the match finder and completed by the entropy coder.
 struct ZgeBlock {
@@ -100,15 +103,15 @@ __global__ void zarc_corpus_fill(uint8_t *base, const uint64_t *off, const uint6
 // encoder
 __global__ void zarc_zge_match(ZgeParams P, const uint8_t *src_base, const uint64_t *src_off, const uint64_t *src_len,
                                const uint32_t *order, uint32_t n_frames, const uint64_t *block_prefix, ZgeBlock *blocks,
-                               uint64_t *seq_scratch, uint8_t *lit_scratch, uint32_t *queue);
+                               uint64_t *seq_scratch, uint8_t *lit_scratch, uint32_t *queue, uint32_t *far_scratch);
 // the deep finder (level >= 9): same arguments, 2^14-entry tables (one workgroup per CU), 4-byte short hash
 __global__ void zarc_zge_match_diag(ZgeParams P, const uint8_t *src_base, const uint64_t *src_off, const uint64_t *src_len,
                                const uint32_t *order, uint32_t n_frames, const uint64_t *block_prefix, ZgeBlock *blocks,
-                               uint64_t *seq_scratch, uint8_t *lit_scratch, uint32_t *queue);
+                               uint64_t *seq_scratch, uint8_t *lit_scratch, uint32_t *queue, uint32_t *far_scratch);
 // the deep finder (level >= 9): same arguments, 2^14-entry tables (one workgroup per CU), 4-byte short hash
 __global__ void zarc_zge_match_deep(ZgeParams P, const uint8_t *src_base, const uint64_t *src_off, const uint64_t *src_len,
                                     const uint32_t *order, uint32_t n_frames, const uint64_t *block_prefix, ZgeBlock *blocks,
-                                    uint64_t *seq_scratch, uint8_t *lit_scratch, uint32_t *queue);
+                                    uint64_t *seq_scratch, uint8_t *lit_scratch, uint32_t *queue, uint32_t *far_scratch);
 __global__ void zarc_zge_entropy(uint32_t n_blocks, ZgeBlock *blocks, uint64_t *seq_scratch, const uint8_t *lit_scratch,
                                  uint8_t *out_scratch, unsigned long long *prof);
 __global__ void zarc_zge_assemble(ZgeParams P, const uint8_t *src_base, const uint64_t *src_off, const uint64_t *src_len,

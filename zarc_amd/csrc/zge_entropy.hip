@@ -462,7 +462,8 @@ __global__ void __launch_bounds__(64, 5) zarc_zge_entropy(uint32_t n_blocks, Zge
     if (bi >= n_blocks) return;
     ZgeBlock *rec = blocks + bi;
     if (rec->type == 1) return; // RLE block: nothing to code
-    const uint32_t nlit = rec->nlit, nseq = rec->nseq, src_len = rec->src_len;
+    const uint32_t nlit = rec->nlit, src_len = rec->src_len;
+    uint32_t nseq = rec->nseq;
     uint64_t *seq = seq_scratch + (uint64_t)bi * ZARC_MAX_SEQ;
     const uint8_t *lit = lit_scratch + (uint64_t)bi * (ZARC_BLOCK + 64);
     uint8_t *out = out_scratch + (uint64_t)bi * (ZARC_BLOCK + 1024);
@@ -590,6 +591,47 @@ __global__ void __launch_bounds__(64, 5) zarc_zge_entropy(uint32_t n_blocks, Zge
     //   r1_i = keep1_i ? r1_{i-1} : o_{i-1}          keep1 = literals present and o_i == r0
     //   r2_i = keep2_i ? r2_{i-1} : r1_{i-1}         keep2 = o_i hits r0/r1 (with literals) or r1 (without)
     // "the value at the last position that did not keep" is a ballot + count-leading-zeros per lane.
+    // Before that, pieces of one long match are joined: a sequence without literals that continues its predecessor at the same
+    // offset (the finder caps a match at 256 bytes per position and at its tile's overrun window) is added to the predecessor's
+    // length, so match lengths reach the format's 131 074 (model: merge_sequences).  64 sequences per round, compacted in place:
+    // a head's length is a difference of the round's prefix sums; the last head of a round stays pending in scalar registers
+    // because its run may go on in the next round.
+    if (nseq > 1) {
+        const uint64_t lt = (1ull << lane) - 1;
+        uint32_t out = 0;                       // heads so far, including the pending one
+        uint32_t pend_lp = 0, pend_ml = 0, pend_o = 0, c_lp = 0, c_o = 0; // pending head; literal position / offset of the previous round's last sequence
+        bool have_pend = false;
+        for (uint32_t base = 0; base < nseq; base += 64) {
+            const uint32_t cnt = nseq - base < 64 ? nseq - base : 64;
+            const bool valid = (uint32_t)lane < cnt;
+            const uint64_t s = valid ? seq[base + (uint32_t)lane] : 0;
+            const uint32_t lp = zge_seq_ll(s), ml = valid ? zge_seq_ml(s) : 0u, o = zge_seq_ofv(s);
+            uint32_t plp = zd::shfl_up(lp, 1), po = zd::shfl_up(o, 1);
+            if (lane == 0) { plp = c_lp; po = c_o; }
+            const bool cont = valid && (base + (uint32_t)lane) > 0 && lp == plp && o == po;
+            const uint64_t hm = zd::ballot(valid && !cont);
+            const uint32_t psum = zd::wave_scan_incl(ml); // inclusive prefix sums of the match lengths
+            const uint32_t first = hm ? (uint32_t)zd::ctz64(hm) : cnt; // lanes before the first head continue the pending head
+            if (first > 0) pend_ml += zd::readlane(psum, first - 1);
+            if (hm) {
+                if (have_pend && lane == 0) seq[out - 1] = zge_pack_seq(pend_lp, pend_ml, pend_o);
+                const uint32_t nh = (uint32_t)__popcll(hm), last = 63u - (uint32_t)__clzll((long long)hm);
+                // my run ends in front of the next head (or with the round)
+                const uint64_t above = lane == 63 ? 0ull : (hm >> (lane + 1)) << (lane + 1);
+                const uint32_t stop = above ? (uint32_t)zd::ctz64(above) : cnt;  // first lane that is not mine
+                const uint32_t run = zd::shfl(psum, (int)stop - 1) - psum + ml;
+                const uint32_t rank = (uint32_t)__popcll(hm & lt);
+                if (((hm >> lane) & 1) && (uint32_t)lane != last) seq[out + rank] = zge_pack_seq(lp, run, o);
+                pend_lp = zd::readlane(lp, last); pend_ml = zd::readlane(run, last); pend_o = zd::readlane(o, last);
+                have_pend = true;
+                out += nh;
+            }
+            c_lp = zd::readlane(lp, cnt - 1); c_o = zd::readlane(o, cnt - 1);
+        }
+        if (have_pend && lane == 0) seq[out - 1] = zge_pack_seq(pend_lp, pend_ml, pend_o);
+        nseq = out;
+        zd::wave_sync_global(); // the pass below reads what other lanes wrote here
+    }
     {
         uint32_t r0 = 0, r1 = 0, r2 = 0, carry = 0; // wave-uniform history / literal position carried between rounds
         for (uint32_t base = 0; base < nseq; base += 64) {

@@ -16,6 +16,10 @@
 //   S3    every position scores its candidates: one 16-byte request source[-8..8) per table candidate (first compare
 //         and backward extension), the two recent-offset guesses are scored out of LDS while those are in flight;
 //         comparisons advance 16 bytes per LDS / global round trip; offers for backward propagation are posted with ds_max
+//   far   a third (level >= 9: up to eight more) candidate per position comes from far tables in HBM (one slab per workgroup):
+//         same entry format, but only every 2^far_step_log-th position is inserted (entries live that much longer) and a tile's
+//         lookups see the inserts of EARLIER tiles only -- lookups are issued in S1 and land during S2, inserts are fire-and-forget
+//         atomic max after S3, so neither is on the tile's critical path and no order inside a tile is needed
 //   S4    backward propagation: position t may start the match found at t+k, k bytes earlier
 //   S5    one-byte lazy rule -> take flag and successor next[t] for every position
 //   S6    the greedy parse IS the path from the entry cursor through next[]: per 64-position chunk the exit of
@@ -68,17 +72,18 @@ template <int TAB_LOG> struct MatchLds {
 enum { K_POS = 0, K_REP0 = 1, K_REP1 = 2, K_FLAG = 3, K_SLOT = 4, K_ANY = 5 };
 
 // Hashes from 32-bit multiplies only (a 64-bit multiply is four quarter-rate VALU ops on gfx950).
-__device__ __forceinline__ uint32_t hash_long(uint64_t v, int bits)
+// The near and the far tables index with different numbers of top bits of the SAME 32-bit product.
+__device__ __forceinline__ uint32_t hash_long32(uint64_t v)
 {
     const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-    return (lo * 0x9E3779B1u + hi * 0x85EBCA77u) >> (32 - bits);
+    return lo * 0x9E3779B1u + hi * 0x85EBCA77u;
 }
-__device__ __forceinline__ uint32_t hash_short(uint64_t v, int bits, int nbytes)
+__device__ __forceinline__ uint32_t hash_short32(uint64_t v, int nbytes)
 {
     uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
     if (nbytes < 8) hi &= (nbytes > 4) ? ((1u << (8 * (nbytes - 4))) - 1) : 0u;
     if (nbytes < 4) lo &= (1u << (8 * nbytes)) - 1;
-    return (lo * 0xC2B2AE3Du + hi * 0x27D4EB2Fu) >> (32 - bits);
+    return lo * 0xC2B2AE3Du + hi * 0x27D4EB2Fu;
 }
 
 // Bit-cost model (lit_cost 5, match_cost 12, rep_cost 9: the engine's fixed defaults, so the literal cost is a
@@ -87,6 +92,7 @@ constexpr int LIT_COST = 5, REP_COST = 9;
 // Parameters of the model that the engine never varies (engine.hip: derive_params sets exactly these and checks them before a
 // launch): as constants they cost no scalar registers -- the kernel keeps about a hundred uniform values alive and spills them.
 constexpr int F_REP_BACK = 256, F_BACK_CAP = 8, F_LAZY_DELTA = 5, F_MIN_REP = 3, F_SEG_LOG = 21; // rep_search 2, short window unlimited
+constexpr int F_FAR_LOG = 16; // buckets per far table
 template <int MATCH_COST> __device__ __forceinline__ int32_t score_mc(uint32_t len, uint32_t off, bool is_rep)
 {
     const int32_t lits = (int32_t)((len << 2) + len);
@@ -128,12 +134,21 @@ __device__ __forceinline__ StageWin stage_window(const ZgeParams &P, const uint8
 // one for level >= 9 (2^14-entry tables = 128 KiB of LDS, one workgroup per CU; 4-byte short hash, cheaper matches).
 // DIAG: the timing-only switches of ZARC_GPU_DBG are compiled into a separate instantiation, so the product kernels carry none of
 // their scalar tests
-template <int TAB_LOG, int SHORT_BYTES, int MATCH_COST, bool DIAG>
+// FAR_WAYS / FAR_SHORT / FAR_STEP_LOG: the far tables (0 ways = none); the engine checks that P carries the same values.
+template <int TAB_LOG, int SHORT_BYTES, int MATCH_COST, int FAR_WAYS, bool FAR_SHORT, int FAR_STEP_LOG, bool DIAG>
 __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgeParams &P, const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off,
                                                const uint64_t *__restrict__ src_len, const uint32_t *__restrict__ order, uint32_t n_frames,
                                                const uint64_t *__restrict__ block_prefix, ZgeBlock *__restrict__ blocks,
-                                               uint64_t *__restrict__ seq_scratch, uint8_t *__restrict__ lit_scratch, uint32_t *__restrict__ queue)
+                                               uint64_t *__restrict__ seq_scratch, uint8_t *__restrict__ lit_scratch, uint32_t *__restrict__ queue,
+                                               uint32_t *__restrict__ far_scratch)
 {
+    constexpr int NFAR = FAR_WAYS * (FAR_SHORT ? 2 : 1); // far candidates per position
+    constexpr int NTAB = 2 + NFAR;                       // table candidates per position (near long, near short, far ...)
+    constexpr int far_shift = 32 - (F_FAR_LOG + TAG_BITS); // far bucket | tag = top bits of the 32-bit hash product
+    constexpr uint32_t far_words = (uint32_t)(((size_t)FAR_WAYS << F_FAR_LOG) * (FAR_SHORT ? 2 : 1));
+    uint32_t *const far_l = far_scratch + (size_t)blockIdx.x * far_words;  // this workgroup's slab: long-hash table, then short-hash table
+    uint32_t *const far_s = far_l + ((size_t)FAR_WAYS << F_FAR_LOG);
+    constexpr uint32_t far_smask = (1u << FAR_STEP_LOG) - 1;
     const int tid = (int)threadIdx.x, lane = zd::lane_id();
     const uint32_t dbg = DIAG ? (uint32_t)P.dbg : 0u;
     const int wave = (int)zd::uniform((uint32_t)zd::wave_id()); // scalar: chunk bounds and the parse walk stay on the SALU
@@ -160,6 +175,12 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
     const uint32_t nblocks = (uint32_t)(block_prefix[slot + 1] - first_block);
 
     for (int i = tid; i < (1 << TAB_LOG); i += THREADS) { L.tl[i] = 0; L.ts[i] = 0; }
+    if (NFAR) { // the slab still holds the previous frame (whose last inserts were waited for in its last tile)
+        uint4 *f4 = (uint4 *)far_l;
+        for (uint32_t i = (uint32_t)tid; i < far_words / 4; i += THREADS) f4[i] = make_uint4(0, 0, 0, 0);
+        zd::wait_vmem(); // the zeros are in L2 before any wave passes the barrier and looks something up
+    }
+    if (tid == 0) { L.ctrl[K_REP0] = 0; L.ctrl[K_REP1] = 0; } // recent-offset guesses live for the whole frame
     zd::lds_barrier();
     // Cold stretches (incompressible data): `cold` counts the searched tiles in a row in which no position found a match; from the
     // second one on, the next 1, 3, then 7 tiles are not searched at all (all literals, nothing inserted) -- the way libzstd's
@@ -176,11 +197,16 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
 
         if (bs > 0 && (bs & seg_mask) == 0) { // new 2^seg_log segment (a multiple of the block size): table positions restart
             for (int i = tid; i < (1 << TAB_LOG); i += THREADS) { L.tl[i] = 0; L.ts[i] = 0; }
+            if (NFAR) {
+                uint4 *f4 = (uint4 *)far_l;
+                for (uint32_t i = (uint32_t)tid; i < far_words / 4; i += THREADS) f4[i] = make_uint4(0, 0, 0, 0);
+                zd::wait_vmem();
+            }
         }
         // ---- RLE block detection: every byte equals the first one (8 bytes per load; blocks start 16-byte aligned).  Nearly
         // every block is cleared by a look at its first KiB; only a block that passes that look is read in full here, so the
         // input is not fetched twice ----
-        if (tid == 0) { L.ctrl[K_FLAG] = 0; L.ctrl[K_POS] = 0; L.ctrl[K_REP0] = 0; L.ctrl[K_REP1] = 0; }
+        if (tid == 0) { L.ctrl[K_FLAG] = 0; L.ctrl[K_POS] = 0; }
         zd::lds_barrier();
         const uint8_t first = blen ? src[bs] : 0;
         const uint64_t pat = 0x0101010101010101ull * first;
@@ -250,17 +276,29 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
             ZGE_PROF(1);
             // ---- S1: hashes (index << TAG_BITS | tag) ----
             uint64_t p8[PER]; // first 8 bytes at each of this thread's positions
+            uint32_t fe[PER][NFAR ? NFAR : 1]; // far-table entries with their check bits cancelled (a hit: non-zero, low bits zero)
 #pragma unroll
             for (int u = 0; u < PER; u++) {
                 const uint32_t idx = ZGE_IDX(u);
                 const uint32_t p = tile + idx;
                 uint32_t hl = 0xFFFFFFFFu, hs = 0xFFFFFFFFu;
                 p8[u] = 0;
+#pragma unroll
+                for (int k = 0; k < (NFAR ? NFAR : 1); k++) fe[u][k] = 0;
                 if (idx < tcount) {
                     p8[u] = zd::load_u64(tbb + (uint32_t)(p + wofs));
                     if (p < hash_end && !(dbg & 64)) {
-                        hl = hash_long(p8[u], TAB_LOG + TAG_BITS);
-                        hs = hash_short(p8[u], TAB_LOG + TAG_BITS, SHORT_BYTES);
+                        const uint32_t h32l = hash_long32(p8[u]), h32s = hash_short32(p8[u], SHORT_BYTES);
+                        hl = h32l >> (32 - (TAB_LOG + TAG_BITS));
+                        hs = h32s >> (32 - (TAB_LOG + TAG_BITS));
+                        if (NFAR) { // requested now, used in S3: the round trip to L2 / HBM passes during S2
+                            const uint32_t hf = h32l >> far_shift, hg = h32s >> far_shift;
+#pragma unroll
+                            for (int w = 0; w < FAR_WAYS; w++) {
+                                fe[u][w] = zd::load_l2_u32(far_l + ((size_t)(hf >> TAG_BITS) * FAR_WAYS + w)) ^ (hf & TAG_MASK);
+                                if (FAR_SHORT) fe[u][FAR_WAYS + w] = zd::load_l2_u32(far_s + ((size_t)(hg >> TAG_BITS) * FAR_WAYS + w)) ^ (hg & TAG_MASK);
+                            }
+                        }
                     }
                 }
                 L.a0[idx] = hl;
@@ -309,8 +347,8 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
             // Phase A requests the first 8 source bytes of every candidate of BOTH positions, phase B scores them and loads more
             // only for candidates that match 8 bytes. ----
             uint32_t mo[PER], mw[PER];
-            uint32_t offs[PER][2];
-            U128 q16[PER][2];
+            uint32_t offs[PER][NTAB];
+            U128 q16[PER][NTAB];
 #pragma unroll
             for (int u = 0; u < PER; u++) {
                 const uint32_t idx = ZGE_IDX(u);
@@ -324,10 +362,19 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
                 offs[u][0] = c0 ? p - (c0 - 1) : 0u;
                 offs[u][1] = (c1 && c1 != c0) ? p - (c1 - 1) : 0u;
 #pragma unroll
-                for (int k = 0; k < 2; k++) // the source needs 8 bytes in front of it (frame positions 0..7 are not used as sources)
+                for (int k = 0; k < NFAR; k++) { // far entries were requested in S1
+                    const uint32_t e = fe[u][k];
+                    uint32_t o = (e && !(e & TAG_MASK)) ? p - (segbase + (e >> TAG_BITS) - 1) : 0u;
+#pragma unroll
+                    for (int j = 0; j < 2 + k; j++) // a candidate another table has already offered costs no second request
+                        if (o == offs[u][j]) o = 0;
+                    offs[u][2 + k] = o;
+                }
+#pragma unroll
+                for (int k = 0; k < NTAB; k++) // the source needs 8 bytes in front of it (frame positions 0..7 are not used as sources)
                     if (offs[u][k] + 8 > p || offs[u][k] > window || idx >= tcount || (dbg & 1)) offs[u][k] = 0;
 #pragma unroll
-                for (int k = 0; k < 2; k++) { // one 16-byte request: source[-8 .. 0) for the backward extension, source[0 .. 8)
+                for (int k = 0; k < NTAB; k++) { // one 16-byte request: source[-8 .. 0) for the backward extension, source[0 .. 8)
                     q16[u][k] = U128{0, 0};
                     if (offs[u][k]) __builtin_memcpy(&q16[u][k], src + (p - offs[u][k] - 8), 16);
                 }
@@ -378,7 +425,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
                 int32_t best_score = -1000000;
                 uint64_t best_before = 0; // the 8 bytes in front of the best candidate's source
 #pragma unroll
-                for (int k = 0; k < 2; k++) {
+                for (int k = 0; k < NTAB; k++) {
                     const uint32_t off = offs[u][k];
                     if (!off) continue;
                     const bool is_rep = off == erep0 || off == erep1;
@@ -448,6 +495,25 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
             }
             zd::lds_barrier(); // own matches (a0) and offers (ex) are complete
             ZGE_PROF(4);
+            if (NFAR) {
+                // far inserts of this tile: every wave has used its lookups (they fed S3), so none of them can see these.  Every
+                // 2^far_step_log-th position, into the way of this tile; atomic max = the highest position wins, whatever the order.
+                const uint32_t way = (tile / TILE) & (uint32_t)(FAR_WAYS - 1);
+#pragma unroll
+                for (int u = 0; u < PER; u++) {
+                    const uint32_t idx = ZGE_IDX(u);
+                    const uint32_t p = tile + idx;
+                    if (idx < tcount && p < hash_end && !(p & far_smask) && !(dbg & 64)) {
+                        const uint32_t code = ((uint32_t)(tile - segbase) + idx + 1) << TAG_BITS;
+                        const uint32_t hf = hash_long32(p8[u]) >> far_shift;
+                        zd::atomic_max_l2(far_l + ((size_t)(hf >> TAG_BITS) * FAR_WAYS + way), code | (hf & TAG_MASK));
+                        if (FAR_SHORT) {
+                            const uint32_t hg = hash_short32(p8[u], SHORT_BYTES) >> far_shift;
+                            zd::atomic_max_l2(far_s + ((size_t)(hg >> TAG_BITS) * FAR_WAYS + way), code | (hg & TAG_MASK));
+                        }
+                    }
+                }
+            }
             if (L.ctrl[K_ANY] == 0) {
                 // no match anywhere in the tile (incompressible data): the path is all literals, nothing to parse
                 const uint32_t start = (uint32_t)((pos > tile ? pos : tile) - tile);
@@ -460,6 +526,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
                 if (tid == 0) L.ctrl[K_POS] = (uint32_t)(tend - bs);
                 cold++;
                 if (cold >= 2) skip_left = cold >= 4 ? 7u : (1u << (cold - 1)) - 1;
+                if (NFAR) zd::wait_vmem(); // the far inserts above are in L2 before the next tile's lookups (rare path: a searched tile without any match)
                 continue;
             }
             cold = 0;
@@ -573,6 +640,10 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
             }
             zd::lds_barrier();
             ZGE_PROF(7);
+            // The far inserts of this tile (issued after S3, a third of a tile ago) must be in L2 before the next tile's lookups: every wave
+            // waits for its own here -- ahead of the stores below, which nobody waits for -- and the barrier at the top of the next tile
+            // does the rest.
+            if (NFAR) zd::wait_vmem();
             // counts of the chunks before mine: a 16-lane scan of the packed per-chunk counts (every wave repeats it)
             uint32_t sel_total, lit_total, sel_before[PER], lit_before[PER];
             {
@@ -622,27 +693,33 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
 __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off,
                                                       const uint64_t *__restrict__ src_len, const uint32_t *__restrict__ order, uint32_t n_frames,
                                                       const uint64_t *__restrict__ block_prefix, ZgeBlock *__restrict__ blocks,
-                                                      uint64_t *__restrict__ seq_scratch, uint8_t *__restrict__ lit_scratch, uint32_t *__restrict__ queue)
+                                                      uint64_t *__restrict__ seq_scratch, uint8_t *__restrict__ lit_scratch, uint32_t *__restrict__ queue,
+                                                      uint32_t *__restrict__ far_scratch)
 {
     __shared__ MatchLds<13> L;
-    zge_match_body<13, 5, 12, false>(L, P, src_base, src_off, src_len, order, n_frames, block_prefix, blocks, seq_scratch, lit_scratch, queue);
+    zge_match_body<13, 5, 12, 1, false, 3, false>(L, P, src_base, src_off, src_len, order, n_frames, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
 }
 
-// the same kernel with the ZARC_GPU_DBG switches (stage clocks, timing-only ablations)
+#ifdef ZARC_GPU_DIAG
+// the same kernel with the ZARC_GPU_DBG switches (stage clocks, timing-only ablations): only in the diagnostic build of the
+// library (make DIAG=1 -> libzarc_gpu_diag.so, used by tools/); the product library has no such code
 __global__ void __launch_bounds__(512, 4) zarc_zge_match_diag(ZgeParams P, const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off,
                                                            const uint64_t *__restrict__ src_len, const uint32_t *__restrict__ order, uint32_t n_frames,
                                                            const uint64_t *__restrict__ block_prefix, ZgeBlock *__restrict__ blocks,
-                                                           uint64_t *__restrict__ seq_scratch, uint8_t *__restrict__ lit_scratch, uint32_t *__restrict__ queue)
+                                                           uint64_t *__restrict__ seq_scratch, uint8_t *__restrict__ lit_scratch, uint32_t *__restrict__ queue,
+                                                           uint32_t *__restrict__ far_scratch)
 {
     __shared__ MatchLds<13> L;
-    zge_match_body<13, 5, 12, true>(L, P, src_base, src_off, src_len, order, n_frames, block_prefix, blocks, seq_scratch, lit_scratch, queue);
+    zge_match_body<13, 5, 12, 1, false, 3, true>(L, P, src_base, src_off, src_len, order, n_frames, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
 }
+#endif
 
 __global__ void __launch_bounds__(512, 2) zarc_zge_match_deep(ZgeParams P, const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off,
                                                            const uint64_t *__restrict__ src_len, const uint32_t *__restrict__ order, uint32_t n_frames,
                                                            const uint64_t *__restrict__ block_prefix, ZgeBlock *__restrict__ blocks,
-                                                           uint64_t *__restrict__ seq_scratch, uint8_t *__restrict__ lit_scratch, uint32_t *__restrict__ queue)
+                                                           uint64_t *__restrict__ seq_scratch, uint8_t *__restrict__ lit_scratch, uint32_t *__restrict__ queue,
+                                                           uint32_t *__restrict__ far_scratch)
 {
     __shared__ MatchLds<14> L;
-    zge_match_body<14, 4, 10, false>(L, P, src_base, src_off, src_len, order, n_frames, block_prefix, blocks, seq_scratch, lit_scratch, queue);
+    zge_match_body<14, 4, 10, 4, true, 1, false>(L, P, src_base, src_off, src_len, order, n_frames, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
 }
