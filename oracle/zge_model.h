@@ -30,8 +30,12 @@ typedef struct {
      * tiles with (tile index mod far_ways) == w: candidates of different ages without any insertion order inside a tile. */
     int far_log;      /* 2^far_log buckets per far table; 0 = no far tables */
     int far_ways;     /* 1, 2 or 4 */
-    int far_step_log;
+    int far_step_log; /* positions p with (p mod 2^far_step_log) < 2^far_res_log are inserted ...                              */
+    int far_res_log;  /* ... and positions with p mod 2^far_res_log == 0 are looked up: of 2^far_res_log inserted neighbours
+                         exactly one lands on a looked-up position, whatever the offset of the repeat                          */
     int far_short;    /* 1 = a second far table keyed by the short hash */
+    int far_back;     /* backward-extension cap of far candidates (they are found up to 2^far_step_log + 2^far_res_log - 2
+                         positions into a repeat) */
 } zge_params;
 
 typedef struct { uint32_t ll, ml, off, ofv; } zge_seq;

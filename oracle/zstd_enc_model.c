@@ -575,6 +575,14 @@ static uint32_t hash_long(uint64_t v, int bits)
     uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
     return (lo * 0x9E3779B1u + hi * 0x85EBCA77u) >> (32 - bits);
 }
+/* far long-hash table: 12 bytes (the 8 at the position and the next 4).  Far offsets are expensive to code, so only repeats of
+ * some length are worth finding there, and a table keyed by 12 bytes is not crowded by the short repeats of text-like data. */
+static uint32_t hash_far(uint64_t v, uint32_t w, int bits)
+{
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    return (lo * 0x9E3779B1u + hi * 0x85EBCA77u + w * 0xC2B2AE3Du) >> (32 - bits);
+}
+static uint32_t rd32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; }
 static uint32_t hash_short(uint64_t v, int bits, int nbytes)
 {
     uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
@@ -622,8 +630,10 @@ typedef struct {
     uint32_t erep0, erep1;   /* recent-offset guesses: offsets of the last two matches selected so far in the frame (0 = none) */
     uint32_t *fl, *fs;       /* far tables (long / short hash), far_ways entries per bucket */
     uint32_t *farc;          /* per-tile far candidates: ZGE_FAR_MAX per position, value = position+1 */
+    size_t far_pending;      /* start of the most recent searched tile whose far inserts are still to be made (ZGE_NO_TILE = none) */
 } mf_ctx;
 #define ZGE_FAR_MAX 8 /* far_ways * (1 + far_short) <= 8 */
+#define ZGE_NO_TILE ((size_t)-1)
 
 /* Resolve explicit offsets against the repcode history (RFC 8878 3.1.1.5).  The history starts UNKNOWN
  * (0 never equals a real offset) in every block: whether the previous block ends up raw/RLE -- which leaves the
@@ -664,6 +674,36 @@ static void resolve_repcodes(zge_seq *seq, uint32_t nseq, zge_stats *st)
     }
 }
 
+/* Far inserts of the searched tile starting at `tile`: every 2^far_step_log-th position, into the way of this tile; the highest
+ * position wins (atomic max in the kernel). */
+static void far_insert_tile(mf_ctx *c, size_t tile)
+{
+    const zge_params *P = c->P;
+    const uint8_t *src = c->src;
+    const uint32_t tmask = (1u << P->tag_bits) - 1, smask = (1u << P->far_step_log) - 1;
+    const size_t segbase = tile & ~(((size_t)1 << P->seg_log) - 1);
+    const size_t way = (tile / (size_t)P->tile) % (size_t)P->far_ways;
+    const size_t far_end = c->n >= 12 ? c->n - 11 : 0;
+    /* a tile never straddles a block: its end is the block's (or the frame's) */
+    size_t tend = tile + (size_t)P->tile, bend = (tile / ZGE_BLOCK + 1) * (size_t)ZGE_BLOCK, p;
+    if (tend > bend) tend = bend;
+    if (tend > c->n) tend = c->n;
+    for (p = tile; p < tend && p < far_end; p++) {
+        uint64_t v;
+        uint32_t hf, code = (uint32_t)(p - segbase) + 1, *e;
+        if (((uint32_t)p & smask) >= (1u << P->far_res_log)) continue;
+        v = rd64(src + p);
+        hf = hash_far(v, rd32(src + p + 8), P->far_log + P->tag_bits);
+        e = &c->fl[(size_t)(hf >> P->tag_bits) * (size_t)P->far_ways + way];
+        if (((code << P->tag_bits) | (hf & tmask)) > *e) *e = (code << P->tag_bits) | (hf & tmask);
+        if (P->far_short) {
+            uint32_t hg = hash_short(v, P->far_log + P->tag_bits, P->short_bytes);
+            e = &c->fs[(size_t)(hg >> P->tag_bits) * (size_t)P->far_ways + way];
+            if (((code << P->tag_bits) | (hg & tmask)) > *e) *e = (code << P->tag_bits) | (hg & tmask);
+        }
+    }
+}
+
 /* Process one block [bs, be): fills seq[] (ll, ml, off) and lit[]; returns nseq, *nlit.
  * Every step below is a data-parallel operation over the positions of a 1024-position tile, except the
  * ordered table update (64 positions at a time) and the tile-to-tile carry of the parse cursor. */
@@ -675,6 +715,7 @@ static uint32_t matchfind_block(mf_ctx *c, size_t bs, size_t be, zge_seq *seq, u
     uint32_t nseq = 0, erep0 = c->erep0, erep1 = c->erep1, i;
     /* positions with fewer than 8 readable bytes are never hashed */
     size_t hash_end = c->n >= 8 ? c->n - 7 : 0; /* p < hash_end is hashable */
+    size_t far_end = c->n >= 12 ? c->n - 11 : 0; /* the far tables' long hash reads 12 bytes */
     for (tile = bs; tile < be; tile += (size_t)P->tile) {
         size_t tend = tile + (size_t)P->tile < be ? tile + (size_t)P->tile : be, p, sub;
         uint32_t tcount = (uint32_t)(tend - tile), t;
@@ -713,15 +754,19 @@ static uint32_t matchfind_block(mf_ctx *c, size_t bs, size_t be, zge_seq *seq, u
                 c->ts[hs >> P->tag_bits] = (code << P->tag_bits) | (hs & tmask);
             }
         }
-        /* Far tables: every position of the tile is looked up (the table holds the inserts of all earlier tiles of the segment). */
+        /* Far tables: every position of the tile is looked up.  The kernel requests a tile's entries while it works on the tile before
+         * (the round trip to HBM is off the critical path that way), ahead of that tile's own inserts: a lookup sees the inserts of
+         * every searched tile except the one directly in front of it. */
         if (P->far_log) {
             const uint32_t tmask = (1u << P->tag_bits) - 1;
             const size_t segbase = tile & ~(((size_t)1 << P->seg_log) - 1);
             int w;
+            if (c->far_pending != ZGE_NO_TILE && c->far_pending + (size_t)P->tile != tile) { far_insert_tile(c, c->far_pending); c->far_pending = ZGE_NO_TILE; }
             memset(c->farc, 0, sizeof(uint32_t) * ZGE_FAR_MAX * (size_t)P->tile);
-            for (p = tile; p < tend && p < hash_end; p++) {
+            for (p = tile; p < tend && p < far_end; p++) {
                 uint64_t v = rd64(src + p);
-                uint32_t hf = hash_long(v, P->far_log + P->tag_bits), *fc = c->farc + (p - tile) * ZGE_FAR_MAX;
+                uint32_t hf = hash_far(v, rd32(src + p + 8), P->far_log + P->tag_bits), *fc = c->farc + (p - tile) * ZGE_FAR_MAX;
+                if ((uint32_t)p & ((1u << P->far_res_log) - 1)) continue;
                 for (w = 0; w < P->far_ways; w++) {
                     uint32_t e = c->fl[(size_t)(hf >> P->tag_bits) * (size_t)P->far_ways + (size_t)w];
                     if (e && (e & tmask) == (hf & tmask)) fc[w] = (uint32_t)segbase + (e >> P->tag_bits);
@@ -735,17 +780,18 @@ static uint32_t matchfind_block(mf_ctx *c, size_t bs, size_t be, zge_seq *seq, u
                 }
             }
         }
-        /* S3: every position scores its own candidates {long, short, far ..., guess0, guess1}; ties keep the earlier candidate */
+        /* S3: every position scores its own candidates {near (long, else short), far ..., guess0, guess1}; ties keep the earlier candidate */
         for (p = tile; p < tend; p++) {
             cand *m = &c->M[p - tile];
             uint32_t limit = (uint32_t)(be - p), cap = limit < (uint32_t)P->cap ? limit : (uint32_t)P->cap;
-            uint32_t best_len = 0, best_off = 0; int best_rep = 0; int32_t best_score = -1000000;
+            uint32_t best_len = 0, best_off = 0; int best_rep = 0, best_far = 0; int32_t best_score = -1000000;
             uint32_t k, offs[4 + ZGE_FAR_MAX];
-            const uint32_t nfar = P->far_log ? (uint32_t)(P->far_ways * (1 + (P->far_short ? 1 : 0))) : 0, ntab = 2 + nfar;
-            offs[0] = m->off ? (uint32_t)p - (m->off - 1) : 0;
-            offs[1] = (m->len && m->len != m->off) ? (uint32_t)p - (m->len - 1) : 0;
-            if (offs[1] > ((uint32_t)1 << P->short_window_log)) offs[1] = 0;
-            for (k = 0; k < nfar; k++) { uint32_t fc = c->farc[(p - tile) * ZGE_FAR_MAX + k]; offs[2 + k] = fc ? (uint32_t)p - (fc - 1) : 0; }
+            const uint32_t nfar = P->far_log ? (uint32_t)(P->far_ways * (1 + (P->far_short ? 1 : 0))) : 0, ntab = 1 + nfar;
+            /* one near candidate: the long table's when it has a hit, the short table's only otherwise (measured: with a long-hash hit
+             * at hand the short-hash candidate changes 0.003 % of the output, and it costs a source fetch per position) */
+            offs[0] = m->off ? (uint32_t)p - (m->off - 1) : (m->len ? (uint32_t)p - (m->len - 1) : 0);
+            if (!m->off && offs[0] > ((uint32_t)1 << P->short_window_log)) offs[0] = 0;
+            for (k = 0; k < nfar; k++) { uint32_t fc = c->farc[(p - tile) * ZGE_FAR_MAX + k]; offs[1 + k] = fc ? (uint32_t)p - (fc - 1) : 0; }
             offs[ntab] = P->rep_search > 0 ? erep0 : 0;
             offs[ntab + 1] = (P->rep_search > 1 && erep1 != erep0) ? erep1 : 0;
             /* recent-offset guesses are only tried when their source lies in the tile window the kernel keeps in LDS
@@ -763,38 +809,22 @@ static uint32_t matchfind_block(mf_ctx *c, size_t bs, size_t be, zge_seq *seq, u
                 len = match_len(src, p, p - off, cap);
                 if (len < (uint32_t)(is_rep ? P->min_rep : P->min_match)) continue;
                 sc = score_of(P, len, off, is_rep);
-                if (sc > best_score) { best_score = sc; best_len = len; best_off = off; best_rep = is_rep; }
+                if (sc > best_score) { best_score = sc; best_len = len; best_off = off; best_rep = is_rep; best_far = k >= 1 && k < ntab; }
             }
             if (best_len && best_score > 0) {
-                uint32_t back = 0;
+                uint32_t back = 0, back_cap = best_far ? (uint32_t)P->far_back : (uint32_t)P->back_cap;
                 m->len = best_len; m->off = best_off; m->is_rep = (uint8_t)best_rep;
                 /* backward extension potential: equal bytes just before the match and its source */
-                if (p - best_off >= 8) /* same rule for recent-offset guesses: no extension next to the frame start */
-                    while (back < (uint32_t)P->back_cap && p - back > bs && p - back > best_off &&
+                if (p - best_off >= back_cap) /* same rule for recent-offset guesses: no extension next to the frame start */
+                    while (back < back_cap && p - back > bs && p - back > best_off &&
                            src[p - back - 1] == src[p - back - 1 - best_off]) back++;
                 m->back = (uint8_t)back;
             }
         }
-        /* far inserts of this tile (after all of its lookups): every 2^far_step_log-th position, into the way of this tile; the
-         * highest position wins (atomic max in the kernel) */
+        /* far inserts: the tile in front of this one (if it was searched) now, this tile's after the next tile's lookups */
         if (P->far_log) {
-            const uint32_t tmask = (1u << P->tag_bits) - 1, smask = (1u << P->far_step_log) - 1;
-            const size_t segbase = tile & ~(((size_t)1 << P->seg_log) - 1);
-            const size_t way = (tile / (size_t)P->tile) % (size_t)P->far_ways;
-            for (p = tile; p < tend && p < hash_end; p++) {
-                uint64_t v;
-                uint32_t hf, code = (uint32_t)(p - segbase) + 1, *e;
-                if ((uint32_t)p & smask) continue;
-                v = rd64(src + p);
-                hf = hash_long(v, P->far_log + P->tag_bits);
-                e = &c->fl[(size_t)(hf >> P->tag_bits) * (size_t)P->far_ways + way];
-                if (((code << P->tag_bits) | (hf & tmask)) > *e) *e = (code << P->tag_bits) | (hf & tmask);
-                if (P->far_short) {
-                    uint32_t hg = hash_short(v, P->far_log + P->tag_bits, P->short_bytes);
-                    e = &c->fs[(size_t)(hg >> P->tag_bits) * (size_t)P->far_ways + way];
-                    if (((code << P->tag_bits) | (hg & tmask)) > *e) *e = (code << P->tag_bits) | (hg & tmask);
-                }
-            }
+            if (c->far_pending != ZGE_NO_TILE) far_insert_tile(c, c->far_pending);
+            c->far_pending = tile;
         }
         {
             int any = 0;
@@ -810,7 +840,7 @@ static uint32_t matchfind_block(mf_ctx *c, size_t bs, size_t be, zge_seq *seq, u
             cand best = c->M[t];
             int32_t best_score = best.len ? score_of(P, best.len, best.off, best.is_rep) : 0;
             uint32_t k;
-            for (k = 1; k <= (uint32_t)P->back_cap && t + k < tcount; k++) {
+            for (k = 1; k <= (uint32_t)(P->far_back > P->back_cap ? P->far_back : P->back_cap) && t + k < tcount; k++) {
                 const cand *nb = &c->M[t + k];
                 int32_t sc;
                 if (!nb->len || nb->back < k) continue;
@@ -882,10 +912,10 @@ void zge_default_params(zge_params *P, int level)
     P->back_cap = 8; P->lazy = level >= 2 || level == 0 ? 1 : 0; P->lazy_delta = 5; /* engine.hip: derive_params */
     P->lit_cost = 5; P->match_cost = 12; P->rep_cost = 9;
     P->window_log = 21; P->short_window_log = 30;
-    P->far_log = 16; P->far_ways = 1; P->far_step_log = 3; P->far_short = 0;
+    P->far_log = 16; P->far_ways = 1; P->far_step_log = 4; P->far_res_log = 2; P->far_short = 0; P->far_back = 16;
     if (level >= 9) { /* the engine's deep finder (engine.hip: derive_params) */
         P->long_log = 14; P->short_log = 14; P->short_bytes = 4; P->min_match = 4; P->match_cost = 10; P->window_log = 22;
-        P->far_ways = 4; P->far_step_log = 1; P->far_short = 1;
+        P->far_log = 16; P->far_ways = 4; P->far_step_log = 1; P->far_res_log = 0; P->far_short = 1; P->far_back = 8;
     }
 }
 
@@ -914,7 +944,7 @@ int zge_encode_frame(const zge_params *P, const void *src_, size_t n, void *dst_
         if (!single) dst[pos++] = (uint8_t)((wlog - 10) << 3);
         for (i = 0; i < fcs_bytes; i++) dst[pos++] = (uint8_t)(v >> (8 * i));
     }
-    c.P = P; c.src = src; c.n = n; c.st = st; c.cold = 0; c.skip_left = 0; c.erep0 = 0; c.erep1 = 0;
+    c.P = P; c.src = src; c.n = n; c.st = st; c.cold = 0; c.skip_left = 0; c.erep0 = 0; c.erep1 = 0; c.far_pending = ZGE_NO_TILE;
     c.window = single ? (n ? n : 1) : ((size_t)1 << wlog);
     {
         const size_t fw = P->far_log ? ((size_t)1 << P->far_log) * (size_t)P->far_ways : 1;
@@ -942,6 +972,7 @@ int zge_encode_frame(const zge_params *P, const void *src_, size_t n, void *dst_
          * tables are cleared, so candidates never cross it (only frames larger than a segment notice) */
         if (bs > 0 && (bs & (((size_t)1 << P->seg_log) - 1)) == 0) {
             if (P->far_log) {
+                c.far_pending = ZGE_NO_TILE; /* inserts of the old segment's last tile die with its tables */
                 memset(c.fl, 0, (sizeof(uint32_t) << P->far_log) * (size_t)P->far_ways);
                 memset(c.fs, 0, (sizeof(uint32_t) << P->far_log) * (size_t)P->far_ways);
             }

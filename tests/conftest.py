@@ -33,6 +33,25 @@ def libzstds():
 
 
 @pytest.fixture(scope="session")
+def libzstd15(libzstds):
+    """A libzstd 1.5.x build (the reference pins 1.5.5): the ratio yardstick.  The image carries one; a box without any libzstd
+    fails the ratio and cross-decoding tests loudly instead of passing them vacuously."""
+    assert libzstds, "no libzstd found on this box (looked at %s)" % (harness.LIBZSTD_CANDIDATES,)
+    return next((z for z in libzstds if z.version.startswith("1.5")), libzstds[0])
+
+
+@pytest.fixture(scope="session")
+def real_items():
+    import realdata
+    items = realdata.items()
+    missing = [k for k, v in items.items() if v is None]
+    if missing:
+        print("realdata: sources missing on this box, items skipped: %s" % missing)
+    assert sum(v is not None for v in items.values()) >= 3, "hardly any real-data source on this box: %s" % missing
+    return {k: v for k, v in items.items() if v is not None}
+
+
+@pytest.fixture(scope="session")
 def golden_frames():
     d = os.path.join(ROOT, "tests", "golden", "zstd_frames")
     m = json.load(open(os.path.join(d, "manifest.json")))

@@ -71,3 +71,26 @@ def test_model_cold_stretches_keep_the_ratio_on_mixed_content(oracle, corpus, li
     assert len(frame) <= len(z.compress(mixed, 3, 1)) * 1.05
     rnd = corpus.entry(7, 1 << 20, 3)
     assert len(oracle.zge_encode(rnd)) == len(rnd) + 4 + 1 + 4 + 3 * 8 + 4   # magic, descriptor, size, 8 raw-block headers, checksum
+
+
+def test_model_ratio_on_real_data(oracle, libzstd15, libzstds, real_items):
+    """The ratio contract off the synthetic corpus: source text, C headers, JSON, machine code, a periodic buffer -- built from
+    files of the image (tests/support/realdata.py).  Level 3 within 5 % of libzstd -3 on every item; level 9 within the bounds
+    realdata.BOUND documents.  Every frame decodes under the oracle decoder and every libzstd on the box."""
+    import realdata
+    for name, raw in real_items.items():
+        for level in (3, 9):
+            frame = oracle.zge_encode(raw, oracle.params(level=level))
+            rc, out, used = oracle.zstd_decode(frame, len(raw))
+            assert rc == 0 and out == raw and used == len(frame), (name, level)
+            for z in libzstds:
+                assert z.decompress(frame, len(raw))[0] == raw, (name, level, z.version)
+            ref = len(libzstd15.compress(raw, level, 1))
+            assert len(frame) <= ref * realdata.bound(name, level), (name, level, len(frame), ref, len(frame) / ref)
+
+
+def test_model_joins_the_pieces_of_long_matches(oracle):
+    """4 MB of period 200: one sequence per block once the 256-byte pieces are joined (round 1 emitted 15 166 sequences, 28x libzstd)."""
+    raw = bytes(range(200)) * 20000
+    frame, st = oracle.zge_encode(raw, stats=True)
+    assert st.seqs == st.blk_comp == 31 and len(frame) < 700

@@ -64,7 +64,7 @@ template <int TAB_LOG> struct MatchLds {
     uint32_t ts[1 << TAB_LOG];
     uint32_t a0[TILE], a1[TILE]; // S1: hashes -> S2: candidates (pos+1) -> S3: a0 = own match (match_pack) -> S4: a1 = final match
     uint32_t ex[TILE];            // S4: best backward offer per position; S6: first position outside its chunk reached from each position
-    uint32_t tb[(TB_BYTES + 3) / 4];
+    uint32_t tb[2][(TB_BYTES + 3) / 4]; // the window of a tile lives in buffer (tile / TILE) & 1: the current tile's and the next one's
     uint32_t wcnt[CHUNKS];       // S6: selected matches << 16 | literals of each chunk
     uint32_t ctrl[16];
     unsigned long long prof[12]; // ZARC_GPU_DBG & 1024: shader-clock ticks per stage, workgroup view from thread 0
@@ -78,6 +78,9 @@ __device__ __forceinline__ uint32_t hash_long32(uint64_t v)
     const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
     return lo * 0x9E3779B1u + hi * 0x85EBCA77u;
 }
+// far long-hash table: 12 bytes (the 8 at the position and the next 4): far offsets are expensive to code, so only repeats of some
+// length are worth finding there, and a table keyed by 12 bytes is not crowded by the short repeats of text-like data
+__device__ __forceinline__ uint32_t hash_far32(uint64_t v, uint32_t w) { return hash_long32(v) + w * 0xC2B2AE3Du; }
 __device__ __forceinline__ uint32_t hash_short32(uint64_t v, int nbytes)
 {
     uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
@@ -86,13 +89,12 @@ __device__ __forceinline__ uint32_t hash_short32(uint64_t v, int nbytes)
     return lo * 0xC2B2AE3Du + hi * 0x27D4EB2Fu;
 }
 
-// Bit-cost model (lit_cost 5, match_cost 12, rep_cost 9: the engine's fixed defaults, so the literal cost is a
+// Bit-cost model (lit_cost 5, match_cost 12 (level >= 9: 10), rep_cost 9: the engine's fixed defaults, so the literal cost is a
 // shift-add instead of a quarter-rate multiply; engine.hip: derive_params() sets exactly these, they are not tunable).
 constexpr int LIT_COST = 5, REP_COST = 9;
 // Parameters of the model that the engine never varies (engine.hip: derive_params sets exactly these and checks them before a
 // launch): as constants they cost no scalar registers -- the kernel keeps about a hundred uniform values alive and spills them.
 constexpr int F_REP_BACK = 256, F_BACK_CAP = 8, F_LAZY_DELTA = 5, F_MIN_REP = 3, F_SEG_LOG = 21; // rep_search 2, short window unlimited
-constexpr int F_FAR_LOG = 16; // buckets per far table
 template <int MATCH_COST> __device__ __forceinline__ int32_t score_mc(uint32_t len, uint32_t off, bool is_rep)
 {
     const int32_t lits = (int32_t)((len << 2) + len);
@@ -128,14 +130,26 @@ __device__ __forceinline__ StageWin stage_window(const ZgeParams &P, const uint8
     return s;
 }
 
+// end of the tile that starts at `tile`: tiles never straddle a block
+__device__ __forceinline__ uint32_t tile_end(uint32_t tile, uint32_t n)
+{
+    uint32_t e = tile + TILE;
+    const uint32_t be = (tile / ZARC_BLOCK + 1) * ZARC_BLOCK;
+    if (e > be) e = be;
+    return e > n ? n : e;
+}
+
 } // namespace
 
 // The body is compiled twice: the level-3 finder (2^13-entry tables, 5-byte short hash, two workgroups per CU) and the deep
 // one for level >= 9 (2^14-entry tables = 128 KiB of LDS, one workgroup per CU; 4-byte short hash, cheaper matches).
 // DIAG: the timing-only switches of ZARC_GPU_DBG are compiled into a separate instantiation, so the product kernels carry none of
 // their scalar tests
-// FAR_WAYS / FAR_SHORT / FAR_STEP_LOG: the far tables (0 ways = none); the engine checks that P carries the same values.
-template <int TAB_LOG, int SHORT_BYTES, int MATCH_COST, int FAR_WAYS, bool FAR_SHORT, int FAR_STEP_LOG, bool DIAG>
+// F_FAR_LOG / FAR_WAYS / FAR_SHORT / FAR_STEP_LOG / FAR_RES_LOG / FAR_BACK: the far tables (0 ways = none); the engine checks that
+// P carries the same values.  Positions p with p mod 2^FAR_STEP_LOG < 2^FAR_RES_LOG are inserted, positions with
+// p mod 2^FAR_RES_LOG == 0 are looked up: of 2^FAR_RES_LOG inserted neighbours exactly one lands on a looked-up position whatever the
+// offset of the repeat -- the memory requests per tile (what the far tables cost) go down by that factor.
+template <int TAB_LOG, int SHORT_BYTES, int MATCH_COST, int F_FAR_LOG, int FAR_WAYS, bool FAR_SHORT, int FAR_STEP_LOG, int FAR_RES_LOG, int FAR_BACK, bool DIAG>
 __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgeParams &P, const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off,
                                                const uint64_t *__restrict__ src_len, const uint32_t *__restrict__ order, uint32_t n_frames,
                                                const uint64_t *__restrict__ block_prefix, ZgeBlock *__restrict__ blocks,
@@ -143,12 +157,13 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
                                                uint32_t *__restrict__ far_scratch)
 {
     constexpr int NFAR = FAR_WAYS * (FAR_SHORT ? 2 : 1); // far candidates per position
-    constexpr int NTAB = 2 + NFAR;                       // table candidates per position (near long, near short, far ...)
+    constexpr int NTAB = 1 + NFAR;                       // table candidates per position: near (long table, else short table), far ...
     constexpr int far_shift = 32 - (F_FAR_LOG + TAG_BITS); // far bucket | tag = top bits of the 32-bit hash product
     constexpr uint32_t far_words = (uint32_t)(((size_t)FAR_WAYS << F_FAR_LOG) * (FAR_SHORT ? 2 : 1));
     uint32_t *const far_l = far_scratch + (size_t)blockIdx.x * far_words;  // this workgroup's slab: long-hash table, then short-hash table
     uint32_t *const far_s = far_l + ((size_t)FAR_WAYS << F_FAR_LOG);
-    constexpr uint32_t far_smask = (1u << FAR_STEP_LOG) - 1;
+    constexpr uint32_t far_smask = (1u << FAR_STEP_LOG) - 1, far_rmask = (1u << FAR_RES_LOG) - 1;
+    static_assert(FAR_BACK == 8 || FAR_BACK == 16, "backward extension of far candidates");
     const int tid = (int)threadIdx.x, lane = zd::lane_id();
     const uint32_t dbg = DIAG ? (uint32_t)P.dbg : 0u;
     const int wave = (int)zd::uniform((uint32_t)zd::wave_id()); // scalar: chunk bounds and the parse walk stay on the SALU
@@ -170,6 +185,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
     const uint32_t n = (uint32_t)src_len[f]; // the engine rejects entries of 4 GiB or more: positions are 32-bit
     const uint32_t window = n <= (1u << P.window_log) ? (n ? n : 1u) : (1u << P.window_log);
     const uint32_t hash_end = n >= 8 ? n - 7 : 0;
+    const uint32_t far_end = n >= 12 ? n - 11 : 0; // the far tables' long hash reads 12 bytes
     // block records / scratch slots are numbered within the sub-batch: block_prefix is indexed by queue slot
     const uint64_t first_block = block_prefix[slot];
     const uint32_t nblocks = (uint32_t)(block_prefix[slot + 1] - first_block);
@@ -186,6 +202,25 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
     // second one on, the next 1, 3, then 7 tiles are not searched at all (all literals, nothing inserted) -- the way libzstd's
     // search step grows while it finds nothing.  Any match in a searched tile ends the stretch.  Replicated in every thread.
     uint32_t cold = 0, skip_left = 0;
+    // Far lookups run one tile ahead: while a tile is in S3 the entries of the NEXT tile's positions are requested (hashes straight
+    // from 12 bytes of global memory), so their round trip to L2 / HBM is over when that tile starts and its far sources can be
+    // requested in S1 already, ahead of S2.  They are requested before this tile's own inserts go out: a lookup sees the inserts
+    // of every searched tile except the one directly in front of it (model: far_pending).
+    // With FAR_RES_LOG > 0 only every 2^FAR_RES_LOG-th position is looked up: the wave's 128 >> FAR_RES_LOG lookups are made by its
+    // first lanes (lane l asks for position wave * 128 + (l << FAR_RES_LOG), one pass instead of two mostly idle ones) and handed to
+    // the lanes that own those positions by a shuffle at the top of the next tile.
+    constexpr bool FAR_COMPACT = FAR_RES_LOG > 0;
+    constexpr int FNEXT_ROWS = FAR_COMPACT ? 1 : PER;
+    uint32_t fnext[FNEXT_ROWS][NFAR ? NFAR : 1];
+    uint32_t pf_far_tile = 0xFFFFFFFFu; // the tile fnext[] belongs to
+    // Tile windows are staged two tiles ahead: at the top of tile T the window of T+1 goes to the other LDS buffer (it was requested
+    // during T-1 and sits in a register) and the window of T+2 is requested.  S1 hashes the next tile's positions out of that buffer.
+    uint32_t pf_word = 0, pf_tile = 0xFFFFFFFFu;            // this thread's dword of the window of tile `pf_tile`
+    uint32_t lds_tile[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};     // the tile whose window each LDS buffer holds (uniform)
+#pragma unroll
+    for (int u = 0; u < FNEXT_ROWS; u++)
+#pragma unroll
+        for (int k = 0; k < (NFAR ? NFAR : 1); k++) fnext[u][k] = 0;
 
     for (uint32_t b = 0; b < nblocks; b++) {
         const uint32_t bs = b * ZARC_BLOCK;
@@ -201,6 +236,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
                 uint4 *f4 = (uint4 *)far_l;
                 for (uint32_t i = (uint32_t)tid; i < far_words / 4; i += THREADS) f4[i] = make_uint4(0, 0, 0, 0);
                 zd::wait_vmem();
+                pf_far_tile = 0xFFFFFFFFu; // entries requested ahead came from the old segment's tables
             }
         }
         // ---- RLE block detection: every byte equals the first one (8 bytes per load; blocks start 16-byte aligned).  Nearly
@@ -229,7 +265,6 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
         if (all_same && blen >= 2) { zd::lds_barrier(); continue; } // nothing is inserted for RLE blocks (same rule as the model)
 
         uint32_t nseq = 0, lp = 0; // replicated in every thread
-        uint32_t pf_word = 0, pf_tile = 0xFFFFFFFFu; // S0 prefetch: this thread's dword of the window of tile `pf_tile`
 
         for (uint32_t tile = bs; tile < be; tile += TILE) {
             const uint32_t tend = be - tile > TILE ? tile + TILE : be;
@@ -257,26 +292,47 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
 
             // ---- S0: tile bytes (8 before .. cap+16 after) -> LDS ----
             // frame position `pos` of the staged window [lo, hi) lives at LDS byte tbb[pos + wofs] (u32 arithmetic)
-            const uint8_t *const tbb = (const uint8_t *)L.tb;
+            const uint32_t bsel = (tile / TILE) & 1u;
+            const uint8_t *const tbb = (const uint8_t *)L.tb[bsel];
+            const uint8_t *const tbn = (const uint8_t *)L.tb[bsel ^ 1u]; // the next tile's window
             const StageWin sw = stage_window(P, src, n, tile, tend, cap_max);
             const uint32_t wofs = sw.wofs;
+            const uint32_t ntile = tile + TILE; // may be the first tile of the next block
+            uint32_t wofs_n = 0;
             {
-                uint32_t v = pf_word;
-                if (pf_tile != tile && tid < sw.ndw) v = sw.w[tid]; // not prefetched (first tile of a block, or after skipped tiles)
-                if (tid < sw.ndw) L.tb[tid] = v;
-                // request the next tile's window now: it arrives while this tile is being worked on
-                const uint32_t ntile = tile + TILE;
-                if (ntile < be) {
-                    const StageWin nw = stage_window(P, src, n, ntile, be - ntile > TILE ? ntile + TILE : be, cap_max);
-                    if (tid < nw.ndw) pf_word = nw.w[tid];
-                    pf_tile = ntile;
+                // this tile's window: normally staged while the previous tile was worked on
+                if (lds_tile[bsel] != tile) {
+                    uint32_t v = pf_word;
+                    if (pf_tile != tile && tid < sw.ndw) v = sw.w[tid]; // first tile of a frame, or after skipped tiles
+                    if (tid < sw.ndw) L.tb[bsel][tid] = v;
+                    lds_tile[bsel] = tile;
+                }
+                if (ntile < n) {
+                    const StageWin nw = stage_window(P, src, n, ntile, tile_end(ntile, n), cap_max);
+                    wofs_n = nw.wofs;
+                    uint32_t v = pf_word;
+                    if (pf_tile != ntile && tid < nw.ndw) v = nw.w[tid];
+                    if (tid < nw.ndw) L.tb[bsel ^ 1u][tid] = v;
+                    lds_tile[bsel ^ 1u] = ntile;
+                    // request the window of the tile after that now: it arrives while this tile is being worked on
+                    const uint32_t n2 = ntile + TILE;
+                    if (n2 < n) {
+                        const StageWin w2 = stage_window(P, src, n, n2, tile_end(n2, n), cap_max);
+                        if (tid < w2.ndw) pf_word = w2.w[tid];
+                        pf_tile = n2;
+                    }
                 }
             }
             zd::lds_barrier();
             ZGE_PROF(1);
             // ---- S1: hashes (index << TAG_BITS | tag) ----
             uint64_t p8[PER]; // first 8 bytes at each of this thread's positions
-            uint32_t fe[PER][NFAR ? NFAR : 1]; // far-table entries with their check bits cancelled (a hit: non-zero, low bits zero)
+            // far-table entries (requested during the previous tile; only a tile that follows unsearched ones asks here and waits in
+            // S3), the check bits they must carry, and -- entries at hand -- the far candidates' sources, requested now: ahead of S2
+            uint32_t fe[PER][NFAR ? NFAR : 1], ftag[PER][FAR_SHORT ? 2 : 1];
+            uint32_t foffs[PER][NFAR ? NFAR : 1];
+            uint64_t qf[PER][NFAR ? NFAR : 1]; // far candidates: source[0 .. 8) only (registers); a far winner fetches the 8 bytes in front later
+            const bool far_ahead = NFAR && pf_far_tile == tile; // uniform
 #pragma unroll
             for (int u = 0; u < PER; u++) {
                 const uint32_t idx = ZGE_IDX(u);
@@ -284,19 +340,42 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
                 uint32_t hl = 0xFFFFFFFFu, hs = 0xFFFFFFFFu;
                 p8[u] = 0;
 #pragma unroll
-                for (int k = 0; k < (NFAR ? NFAR : 1); k++) fe[u][k] = 0;
+                for (int k = 0; k < (NFAR ? NFAR : 1); k++) {
+                    if (FAR_COMPACT) { // from the lane that asked for this position (only looked-up positions read a meaningful value)
+                        const uint32_t got = zd::shfl(fnext[0][k], (int)(((uint32_t)u * 64u + (uint32_t)lane) >> FAR_RES_LOG));
+                        fe[u][k] = (far_ahead && !(idx & far_rmask)) ? got : 0u;
+                    } else fe[u][k] = far_ahead ? fnext[FAR_COMPACT ? 0 : u][k] : 0u;
+                    foffs[u][k] = 0; qf[u][k] = 0;
+                }
+                ftag[u][0] = 0xFFFFFFFFu; // matches no entry
+                if (FAR_SHORT) ftag[u][1] = 0xFFFFFFFFu;
                 if (idx < tcount) {
                     p8[u] = zd::load_u64(tbb + (uint32_t)(p + wofs));
                     if (p < hash_end && !(dbg & 64)) {
                         const uint32_t h32l = hash_long32(p8[u]), h32s = hash_short32(p8[u], SHORT_BYTES);
                         hl = h32l >> (32 - (TAB_LOG + TAG_BITS));
                         hs = h32s >> (32 - (TAB_LOG + TAG_BITS));
-                        if (NFAR) { // requested now, used in S3: the round trip to L2 / HBM passes during S2
-                            const uint32_t hf = h32l >> far_shift, hg = h32s >> far_shift;
+                        if (NFAR && p < far_end && !(p & far_rmask) && !(dbg & 2048)) {
+                            const uint32_t hf = (h32l + zd::load_u32(tbb + (uint32_t)(p + 8 + wofs)) * 0xC2B2AE3Du) >> far_shift, hg = h32s >> far_shift;
+                            ftag[u][0] = hf & TAG_MASK;
+                            if (FAR_SHORT) ftag[u][1] = hg & TAG_MASK;
+                            if (!far_ahead) {
 #pragma unroll
-                            for (int w = 0; w < FAR_WAYS; w++) {
-                                fe[u][w] = zd::load_l2_u32(far_l + ((size_t)(hf >> TAG_BITS) * FAR_WAYS + w)) ^ (hf & TAG_MASK);
-                                if (FAR_SHORT) fe[u][FAR_WAYS + w] = zd::load_l2_u32(far_s + ((size_t)(hg >> TAG_BITS) * FAR_WAYS + w)) ^ (hg & TAG_MASK);
+                                for (int w = 0; w < FAR_WAYS; w++) {
+                                    fe[u][w] = zd::load_l2_u32(far_l + ((size_t)(hf >> TAG_BITS) * FAR_WAYS + w));
+                                    if (FAR_SHORT) fe[u][FAR_WAYS + w] = zd::load_l2_u32(far_s + ((size_t)(hg >> TAG_BITS) * FAR_WAYS + w));
+                                }
+                            } else {
+#pragma unroll
+                                for (int k = 0; k < NFAR; k++) {
+                                    const uint32_t e = fe[u][k];
+                                    uint32_t o = (e && (e & TAG_MASK) == ftag[u][k / (FAR_WAYS ? FAR_WAYS : 1)] && !(dbg & 4096)) ? p - (segbase + (e >> TAG_BITS) - 1) : 0u;
+#pragma unroll
+                                    for (int j = 0; j < k; j++) if (o == foffs[u][j]) o = 0;
+                                    if (o + 8 > p || o > window || (dbg & 1)) o = 0;
+                                    foffs[u][k] = o;
+                                    if (o) qf[u][k] = zd::load_u64(src + (p - o));
+                                }
                             }
                         }
                     }
@@ -304,6 +383,28 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
                 L.a0[idx] = hl;
                 L.a1[idx] = hs;
                 L.ex[idx] = 0; // S4 offers start empty (the previous tile's walk is over)
+            }
+            if (NFAR) {
+                // the NEXT tile's far entries: hashes out of its window in the other LDS buffer; the requests have S2 and S3 to come back
+#pragma unroll
+                for (int u = 0; u < FNEXT_ROWS; u++) {
+                    const uint32_t idxn = FAR_COMPACT ? (uint32_t)wave * 128u + ((uint32_t)lane << FAR_RES_LOG) : ZGE_IDX(u);
+                    const uint32_t pn = ntile + idxn;
+                    const bool mine = !FAR_COMPACT || (uint32_t)lane < (128u >> FAR_RES_LOG);
+                    if (mine && pn < far_end && !(pn & far_rmask) && !(dbg & 2048)) {
+                        const uint64_t v = zd::load_u64(tbn + (uint32_t)(pn + wofs_n));
+                        const uint32_t hf = hash_far32(v, zd::load_u32(tbn + (uint32_t)(pn + 8 + wofs_n))) >> far_shift, hg = hash_short32(v, SHORT_BYTES) >> far_shift;
+#pragma unroll
+                        for (int w = 0; w < FAR_WAYS; w++) {
+                            fnext[u][w] = zd::load_l2_u32(far_l + ((size_t)(hf >> TAG_BITS) * FAR_WAYS + w));
+                            if (FAR_SHORT) fnext[u][FAR_WAYS + w] = zd::load_l2_u32(far_s + ((size_t)(hg >> TAG_BITS) * FAR_WAYS + w));
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < NFAR; k++) fnext[u][k] = 0;
+                    }
+                }
+                pf_far_tile = ntile;
             }
             zd::lds_barrier();
             ZGE_PROF(2);
@@ -348,36 +449,41 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
             // only for candidates that match 8 bytes. ----
             uint32_t mo[PER], mw[PER];
             uint32_t offs[PER][NTAB];
-            U128 q16[PER][NTAB];
+            U128 q16[PER];                    // near candidate: source[-8 .. 8)
 #pragma unroll
             for (int u = 0; u < PER; u++) {
                 const uint32_t idx = ZGE_IDX(u);
                 const uint32_t p = tile + idx;
-                uint32_t c0 = 0, c1 = 0;
+                uint32_t cn = 0;
                 if (idx < tcount && !(dbg & 5)) {
-                    const uint32_t w0 = L.a0[idx], w1 = L.a1[idx]; // candidate position (+1): a table hit whose check bits agreed
-                    c0 = (w0 && !(w0 & TAG_MASK)) ? segbase + (w0 >> TAG_BITS) : 0u;
-                    c1 = (w1 && !(w1 & TAG_MASK)) ? segbase + (w1 >> TAG_BITS) : 0u;
+                    // candidate position (+1): a table hit whose check bits agreed.  One near candidate: the long table's when it has a
+                    // hit, the short table's only otherwise (with a long-hash hit at hand the short-hash candidate changes 0.003 % of the
+                    // output and would cost a source fetch per position)
+                    const uint32_t w0 = L.a0[idx], w1 = L.a1[idx];
+                    const uint32_t wn = (w0 && !(w0 & TAG_MASK)) ? w0 : w1;
+                    cn = (wn && !(wn & TAG_MASK)) ? segbase + (wn >> TAG_BITS) : 0u;
                 }
-                offs[u][0] = c0 ? p - (c0 - 1) : 0u;
-                offs[u][1] = (c1 && c1 != c0) ? p - (c1 - 1) : 0u;
+                uint32_t on = cn ? p - (cn - 1) : 0u;
+                // the source needs 8 bytes in front of it (frame positions 0..7 are not used as sources)
+                if (on + 8 > p || on > window || idx >= tcount || (dbg & 1)) on = 0;
+                offs[u][0] = on;
+                // one 16-byte request: source[-8 .. 0) for the backward extension, source[0 .. 8)
+                q16[u] = U128{0, 0};
+                if (on) __builtin_memcpy(&q16[u], src + (p - on - 8), 16);
+                if (NFAR && !far_ahead) { // entries asked for in S1 of this very tile: their sources can only be requested now
 #pragma unroll
-                for (int k = 0; k < NFAR; k++) { // far entries were requested in S1
-                    const uint32_t e = fe[u][k];
-                    uint32_t o = (e && !(e & TAG_MASK)) ? p - (segbase + (e >> TAG_BITS) - 1) : 0u;
+                    for (int k = 0; k < NFAR; k++) {
+                        const uint32_t e = fe[u][k];
+                        uint32_t o = (e && (e & TAG_MASK) == ftag[u][k / (FAR_WAYS ? FAR_WAYS : 1)] && !(dbg & 4096)) ? p - (segbase + (e >> TAG_BITS) - 1) : 0u;
 #pragma unroll
-                    for (int j = 0; j < 2 + k; j++) // a candidate another table has already offered costs no second request
-                        if (o == offs[u][j]) o = 0;
-                    offs[u][2 + k] = o;
+                        for (int j = 0; j < k; j++) if (o == foffs[u][j]) o = 0;
+                        if (o + 8 > p || o > window || idx >= tcount || (dbg & 1)) o = 0;
+                        foffs[u][k] = o;
+                        if (o) qf[u][k] = zd::load_u64(src + (p - o));
+                    }
                 }
 #pragma unroll
-                for (int k = 0; k < NTAB; k++) // the source needs 8 bytes in front of it (frame positions 0..7 are not used as sources)
-                    if (offs[u][k] + 8 > p || offs[u][k] > window || idx >= tcount || (dbg & 1)) offs[u][k] = 0;
-#pragma unroll
-                for (int k = 0; k < NTAB; k++) { // one 16-byte request: source[-8 .. 0) for the backward extension, source[0 .. 8)
-                    q16[u][k] = U128{0, 0};
-                    if (offs[u][k]) __builtin_memcpy(&q16[u][k], src + (p - offs[u][k] - 8), 16);
-                }
+                for (int k = 0; k < NFAR; k++) offs[u][1 + k] = foffs[u][k] == on ? 0u : foffs[u][k]; // the near table has offered it already
             }
             ZGE_PROF(9);
             // while those loads are in flight: the two recent-offset guesses of both positions.  Both sides are inside the staged
@@ -424,12 +530,13 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
                 bool best_rep = false;
                 int32_t best_score = -1000000;
                 uint64_t best_before = 0; // the 8 bytes in front of the best candidate's source
+                bool best_far = false;    // ... still to be fetched (far candidates are requested without them)
 #pragma unroll
                 for (int k = 0; k < NTAB; k++) {
                     const uint32_t off = offs[u][k];
                     if (!off) continue;
                     const bool is_rep = off == erep0 || off == erep1;
-                    uint64_t x = q16[u][k].hi ^ p8[u];
+                    uint64_t x = (k < 1 ? q16[u].hi : qf[u][k < 1 ? 0 : k - 1]) ^ p8[u];
                     uint32_t len = 0;
                     // common prefix, 8 bytes per step; reads past `cap` stay inside the staged window / the padded arena
                     while (!x && len + 8 < cap) { // 16 bytes per global round trip
@@ -444,7 +551,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
                     if (len > cap) len = cap;
                     if (len < (uint32_t)(is_rep ? F_MIN_REP : P.min_match)) continue;
                     const int32_t sc = score_of(P, len, off, is_rep);
-                    if (sc > best_score) { best_score = sc; best_len = len; best_off = off; best_rep = is_rep; best_before = q16[u][k].lo; }
+                    if (sc > best_score) { best_score = sc; best_len = len; best_off = off; best_rep = is_rep; best_far = k >= 1; if (k < 1) best_before = q16[u].lo; }
                 }
                 bool from_guess = false;
                 { // the recent-offset guesses rank after the table candidates (ties keep the earlier candidate)
@@ -452,19 +559,26 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
                     if (r) {
                         const uint32_t len = r & 0x1FFu;
                         const int32_t sc = score_of(P, len, 1, true);
-                        if (sc > best_score) { best_score = sc; best_len = len; best_off = (r >> 9) ? erep1 : erep0; best_rep = true; from_guess = true; }
+                        if (sc > best_score) { best_score = sc; best_len = len; best_off = (r >> 9) ? erep1 : erep0; best_rep = true; from_guess = true; best_far = false; }
                     }
                 }
                 if (best_len && best_score > 0) {
-                    // backward-extension potential: equal bytes just before the match and its source (none next to the frame start)
+                    // backward-extension potential: equal bytes just before the match and its source (none next to the frame start).  Far
+                    // candidates, found up to 2^FAR_STEP_LOG + 2^FAR_RES_LOG - 2 positions into a repeat, may go back FAR_BACK bytes.
                     const uint32_t q = p - best_off;
-                    uint32_t maxb = (uint32_t)F_BACK_CAP;
+                    const uint32_t bcap = (NFAR && best_far) ? (uint32_t)FAR_BACK : (uint32_t)F_BACK_CAP;
+                    uint32_t maxb = bcap;
                     if (p - bs < maxb) maxb = (uint32_t)(p - bs);
                     uint32_t back = 0;
-                    if (maxb && q >= 8) { // then p - 8 and (for a guess) q - 8 are inside the staged window
+                    if (maxb && q >= bcap) { // then p - bcap and (for a guess) q - 8 are inside the staged window
                         if (from_guess) best_before = zd::load_u64(tbb + (uint32_t)(q - 8 + wofs));
+                        if (NFAR && best_far) best_before = zd::load_u64(src + (q - 8));
                         const uint64_t x = zd::load_u64(tbb + (uint32_t)(p - 8 + wofs)) ^ best_before;
                         back = x ? (uint32_t)(__clzll((long long)x) >> 3) : 8u;
+                        if (NFAR && FAR_BACK > 8 && best_far && back == 8 && maxb > 8) {
+                            const uint64_t x2 = zd::load_u64(tbb + (uint32_t)(p - 16 + wofs)) ^ zd::load_u64(src + (q - 16));
+                            back += x2 ? (uint32_t)(__clzll((long long)x2) >> 3) : 8u;
+                        }
                         if (back > maxb) back = maxb;
                     }
                     mo[u] = best_off;
@@ -479,7 +593,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
             for (int u = 0; u < PER; u++) L.a0[ZGE_IDX(u)] = match_pack(mo[u], mw[u] & 0xFFFF, (mw[u] >> 24) & 1);
             if (mo[0] | mo[1]) L.ctrl[K_ANY] = 1; // benign race: every writer stores 1
             // ---- S4: backward propagation.  A position whose match extends b bytes backwards offers it to the b
-            // positions before it (ds_max of score << 4 | 8-k: best score wins, then the nearest source); every position
+            // positions before it (ds_max of score << 5 | 16-k: best score wins, then the nearest source); every position
             // then adopts the best offer if it beats its own match.  Same result as scanning the 8 following positions.
 #pragma unroll
             for (int u = 0; u < PER; u++) {
@@ -489,10 +603,11 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
                     const bool rep = (mw[u] >> 24) & 1;
                     for (uint32_t k = 1; k <= back && k <= idx; k++) {
                         const int32_t sc = score_of(P, len + k, mo[u], rep);
-                        if (sc > 0) atomicMax(&L.ex[idx - k], ((uint32_t)sc << 4) | (8u - k));
+                        if (sc > 0) atomicMax(&L.ex[idx - k], ((uint32_t)sc << 5) | (16u - k));
                     }
                 }
             }
+            if (NFAR) zd::wait_vmem(); // the next tile's entries are in registers before any wave sends this tile's inserts
             zd::lds_barrier(); // own matches (a0) and offers (ex) are complete
             ZGE_PROF(4);
             if (NFAR) {
@@ -503,9 +618,9 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
                 for (int u = 0; u < PER; u++) {
                     const uint32_t idx = ZGE_IDX(u);
                     const uint32_t p = tile + idx;
-                    if (idx < tcount && p < hash_end && !(p & far_smask) && !(dbg & 64)) {
+                    if (idx < tcount && p < far_end && (p & far_smask) <= far_rmask && !(dbg & (64 | 8192))) {
                         const uint32_t code = ((uint32_t)(tile - segbase) + idx + 1) << TAG_BITS;
-                        const uint32_t hf = hash_long32(p8[u]) >> far_shift;
+                        const uint32_t hf = hash_far32(p8[u], zd::load_u32(tbb + (uint32_t)(p + 8 + wofs))) >> far_shift;
                         zd::atomic_max_l2(far_l + ((size_t)(hf >> TAG_BITS) * FAR_WAYS + way), code | (hf & TAG_MASK));
                         if (FAR_SHORT) {
                             const uint32_t hg = hash_short32(p8[u], SHORT_BYTES) >> far_shift;
@@ -538,8 +653,8 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
                 bool brep = (mw[u] >> 24) & 1;
                 if (offer) {
                     const int32_t own = blen_ ? score_of(P, blen_, boff, brep) : 0;
-                    if ((int32_t)(offer >> 4) > own) {
-                        const uint32_t k = 8u - (offer & 15u);
+                    if ((int32_t)(offer >> 5) > own) {
+                        const uint32_t k = 16u - (offer & 31u);
                         const uint32_t nm = L.a0[idx + k];
                         boff = match_off(nm);
                         blen_ = match_len(nm) + k;
@@ -697,7 +812,7 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                                                       uint32_t *__restrict__ far_scratch)
 {
     __shared__ MatchLds<13> L;
-    zge_match_body<13, 5, 12, 1, false, 3, false>(L, P, src_base, src_off, src_len, order, n_frames, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
+    zge_match_body<13, 5, 12, 16, 1, false, 4, 2, 16, false>(L, P, src_base, src_off, src_len, order, n_frames, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
 }
 
 #ifdef ZARC_GPU_DIAG
@@ -710,7 +825,7 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match_diag(ZgeParams P, const
                                                            uint32_t *__restrict__ far_scratch)
 {
     __shared__ MatchLds<13> L;
-    zge_match_body<13, 5, 12, 1, false, 3, true>(L, P, src_base, src_off, src_len, order, n_frames, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
+    zge_match_body<13, 5, 12, 16, 1, false, 4, 2, 16, true>(L, P, src_base, src_off, src_len, order, n_frames, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
 }
 #endif
 
@@ -721,5 +836,5 @@ __global__ void __launch_bounds__(512, 2) zarc_zge_match_deep(ZgeParams P, const
                                                            uint32_t *__restrict__ far_scratch)
 {
     __shared__ MatchLds<14> L;
-    zge_match_body<14, 4, 10, 4, true, 1, false>(L, P, src_base, src_off, src_len, order, n_frames, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
+    zge_match_body<14, 4, 10, 16, 4, true, 1, 0, 8, false>(L, P, src_base, src_off, src_len, order, n_frames, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
 }
