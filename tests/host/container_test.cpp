@@ -151,6 +151,37 @@ int main(int argc, char **argv)
         try { zarc::ArchiveReader r((const uint8_t *)b.data(), b.size()); } catch (const zarc::Error &) { threw = true; }
         CHECK(threw);
     }
+    { // crafted trailers: a directory offset inside the last 62 bytes used to make the frame length wrap around; a
+      // consistent check byte is recomputed so that only the offset test can reject it
+        auto with_offset = [&](int64_t off) {
+            std::string b = image;
+            uint8_t *e = (uint8_t *)&b[b.size() - 22];
+            for (int i = 0; i < 8; i++) e[1 + i] = (uint8_t)((uint64_t)off >> (8 * i));
+            e[17] = 0;
+            uint8_t x = 0 ^ e[0];
+            for (size_t i = b.size() - 54; i < b.size(); i++) x ^= (uint8_t)b[i];
+            e[17] = x;
+            return b;
+        };
+        CHECK(open_fails(with_offset(-30), "directory offset"));
+        CHECK(open_fails(with_offset(-61), "directory offset"));
+        CHECK(open_fails(with_offset((int64_t)image.size() - 10), "directory offset"));
+        CHECK(open_fails(with_offset(3), "directory offset"));
+    }
+    { // directory records that point outside the file or wrap around u64 are refused before anything is staged
+        zarc::FrameReader fr(0);
+        zarc::Frame f;
+        f.offset = ~0ull - 5; f.length = 100; f.uncompressed = 10;
+        bool threw = false;
+        try { fr.read_content_frames((const uint8_t *)image.data(), image.size(), {f}); } catch (const zarc::Error &) { threw = true; }
+        CHECK(threw);
+        f.offset = 12; f.length = ~0ull; threw = false;
+        try { fr.read_content_frames((const uint8_t *)image.data(), image.size(), {f}); } catch (const zarc::Error &) { threw = true; }
+        CHECK(threw);
+        f.offset = 12; f.length = 20; f.uncompressed = (uint64_t)1 << 40; threw = false;
+        try { fr.read_content_frames((const uint8_t *)image.data(), image.size(), {f}); } catch (const zarc::Error &) { threw = true; }
+        CHECK(threw);
+    }
     std::printf("container OK: %zu files, %zu frames, %zu bytes, directory %llu bytes\n", rd.files().size(), rd.frames().size(), image.size(),
                 (unsigned long long)rd.trailer().directory_uncompressed_size);
     return 0;

@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <numeric>
 #include <string>
@@ -53,6 +54,8 @@ struct zarc_gpu {
     DevBuf d_dense, d_goff, d_glen, d_gdense; // gather of the frames of a chunk before they cross PCIe
     zarc_gpu_params params{};
     std::string last_error;
+    std::mutex err_mu; // last_error is also written by the staging helper thread of the host-pointer entry points
+    hipStream_t stream_stage = nullptr; // PCIe staging of the host-pointer entry points: its copies never queue behind side kernels
     // descriptors
     DevBuf d_off, d_len, d_chunk_prefix, d_block_prefix, d_order, d_dst_off, d_dst_len, d_raw_len, d_frame_off, d_frame_len;
     // hashing
@@ -80,12 +83,14 @@ namespace {
     do {                                                                                            \
         hipError_t e_ = (call);                                                                     \
         if (e_ != hipSuccess) {                                                                     \
+            std::lock_guard<std::mutex> g_(h->err_mu);                                              \
             h->last_error = std::string(#call) + ": " + hipGetErrorString(e_);                      \
             return e_ == hipErrorOutOfMemory ? ZARC_GPU_E_NOMEM : ZARC_GPU_E_DEVICE;                \
         }                                                                                           \
     } while (0)
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+inline void set_error(zarc_gpu *h, const char *msg) { std::lock_guard<std::mutex> g(h->err_mu); h->last_error = msg; }
 
 // Timing ablations and kernel-steering switches exist only in the diagnostic build (make DIAG=1 -> libzarc_gpu_diag.so, used by
 // tools/): the product library never reads them, so no environment variable can change the bytes it produces.
@@ -192,7 +197,7 @@ float elapsed(zarc_gpu *h, int a, int b)
 int check_common(zarc_gpu *h, size_t n)
 {
     if (!h) return ZARC_GPU_E_PARAM;
-    if (n > 0x7FFFFFFFu) { h->last_error = "batch too large"; return ZARC_GPU_E_PARAM; }
+    if (n > 0x7FFFFFFFu) { set_error(h, "batch too large"); return ZARC_GPU_E_PARAM; }
     ZHIP(hipSetDevice(h->device));
     for (int i = 0; i < ZARC_GPU_T_COUNT; i++) h->ms[i] = -1.f;
     return 0;
@@ -213,7 +218,7 @@ int zarc_gpu_create(zarc_gpu_t **out, int device)
     zarc_gpu *h = new (std::nothrow) zarc_gpu();
     if (!h) return ZARC_GPU_E_NOMEM;
     h->device = device;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess || hipStreamCreate(&h->stream2) != hipSuccess || hipStreamCreate(&h->stream3) != hipSuccess ||
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess || hipStreamCreate(&h->stream2) != hipSuccess || hipStreamCreate(&h->stream3) != hipSuccess || hipStreamCreate(&h->stream_stage) != hipSuccess ||
         hipEventCreate(&h->ev_fork3) != hipSuccess || hipEventCreate(&h->ev_join3) != hipSuccess ||
         hipEventCreate(&h->ev_fork) != hipSuccess || hipEventCreate(&h->ev_join) != hipSuccess) { delete h; return ZARC_GPU_E_DEVICE; }
     for (auto &e : h->ev)
@@ -243,6 +248,7 @@ void zarc_gpu_destroy(zarc_gpu_t *h)
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->stream3) (void)hipStreamDestroy(h->stream3);
+    if (h->stream_stage) (void)hipStreamDestroy(h->stream_stage);
     if (h->ev_fork3) (void)hipEventDestroy(h->ev_fork3);
     if (h->ev_join3) (void)hipEventDestroy(h->ev_join3);
     for (int i = 0; i < zarc_gpu::PIN_SLOTS; i++) { if (h->pin[i]) (void)hipHostFree(h->pin[i]); if (h->pin_ev[i]) (void)hipEventDestroy(h->pin_ev[i]); }
@@ -336,7 +342,7 @@ int zarc_gpu_blake3_batch_device(zarc_gpu_t *h, size_t n, const void *d_base, co
     if (rc) return rc;
     if (n == 0) return ZARC_GPU_OK;
     if (!d_base || !off || !len || !digest) return ZARC_GPU_E_PARAM;
-    for (size_t i = 0; i < n; i++) if (off[i] % ZARC_GPU_ALIGN) { h->last_error = "entry offset not 16-byte aligned"; return ZARC_GPU_E_PARAM; }
+    for (size_t i = 0; i < n; i++) if (off[i] % ZARC_GPU_ALIGN) { set_error(h, "entry offset not 16-byte aligned"); return ZARC_GPU_E_PARAM; }
     if ((rc = upload_u64(h, h->d_off, off, n))) return rc;
     if ((rc = upload_u64(h, h->d_len, len, n))) return rc;
     Timer t{h};
@@ -356,7 +362,7 @@ int zarc_gpu_xxh64_batch_device(zarc_gpu_t *h, size_t n, const void *d_base, con
     if (rc) return rc;
     if (n == 0) return ZARC_GPU_OK;
     if (!d_base || !off || !len || !out) return ZARC_GPU_E_PARAM;
-    for (size_t i = 0; i < n; i++) if (off[i] % ZARC_GPU_ALIGN) { h->last_error = "entry offset not 16-byte aligned"; return ZARC_GPU_E_PARAM; }
+    for (size_t i = 0; i < n; i++) if (off[i] % ZARC_GPU_ALIGN) { set_error(h, "entry offset not 16-byte aligned"); return ZARC_GPU_E_PARAM; }
     if ((rc = upload_u64(h, h->d_off, off, n))) return rc;
     if ((rc = upload_u64(h, h->d_len, len, n))) return rc;
     Timer t{h};
@@ -382,11 +388,11 @@ int zarc_gpu_pack_batch_device(zarc_gpu_t *h, size_t n, const void *d_src_base, 
     if (P.rep_back != 256 || P.back_cap != 8 || P.lazy_delta != 5 || P.min_rep != 3 || P.rep_search != 2 || P.seg_log != 21 || P.short_window_log < 30 ||
         P.lit_cost != 5 || P.rep_cost != 9 || P.tag_bits != 10 || P.far_log != 16 || P.match_cost != (P.long_log == 14 ? 10 : 12) || P.far_ways != (P.long_log == 14 ? 4 : 1) ||
         P.far_step_log != (P.long_log == 14 ? 1 : 4) || P.far_res_log != (P.long_log == 14 ? 0 : 2) || (P.far_short != 0) != (P.long_log == 14) ||
-        P.far_back != (P.long_log == 14 ? 8 : 16)) { h->last_error = "internal: encoder parameters differ from the compiled-in ones"; return ZARC_GPU_E_PARAM; }
+        P.far_back != (P.long_log == 14 ? 8 : 16)) { set_error(h, "internal: encoder parameters differ from the compiled-in ones"); return ZARC_GPU_E_PARAM; }
     uint64_t need = 0;
     for (size_t i = 0; i < n; i++) {
-        if (src_off[i] % ZARC_GPU_ALIGN) { h->last_error = "entry offset not 16-byte aligned"; return ZARC_GPU_E_PARAM; }
-        if (src_len[i] >= 0xFFFFFFF0ull) { h->last_error = "entries of 4 GiB or more are not supported"; return ZARC_GPU_E_UNSUPPORTED; }
+        if (src_off[i] % ZARC_GPU_ALIGN) { set_error(h, "entry offset not 16-byte aligned"); return ZARC_GPU_E_PARAM; }
+        if (src_len[i] >= 0xFFFFFFF0ull) { set_error(h, "entries of 4 GiB or more are not supported"); return ZARC_GPU_E_UNSUPPORTED; }
         dst_off[i] = need;
         need += zarc_gpu_bound((size_t)src_len[i]);
     }
@@ -537,8 +543,8 @@ int zarc_gpu_unpack_batch_device(zarc_gpu_t *h, size_t n, const void *d_frames_b
     if (n == 0) return ZARC_GPU_OK;
     if (!d_frames_base || !frame_off || !frame_len || !d_dst_base || !dst_off || !raw_len || !digest || !status) return ZARC_GPU_E_PARAM;
     for (size_t i = 0; i < n; i++) {
-        if (dst_off[i] % ZARC_GPU_ALIGN) { h->last_error = "output offset not 16-byte aligned"; return ZARC_GPU_E_PARAM; }
-        if (frame_len[i] >= 0xFFFFFFF0ull || raw_len[i] >= 0xFFFFFFF0ull) { h->last_error = "frames of 4 GiB or more are not supported"; return ZARC_GPU_E_UNSUPPORTED; }
+        if (dst_off[i] % ZARC_GPU_ALIGN) { set_error(h, "output offset not 16-byte aligned"); return ZARC_GPU_E_PARAM; }
+        if (frame_len[i] >= 0xFFFFFFF0ull || raw_len[i] >= 0xFFFFFFF0ull) { set_error(h, "frames of 4 GiB or more are not supported"); return ZARC_GPU_E_UNSUPPORTED; }
     }
     if ((rc = upload_u64(h, h->d_frame_off, frame_off, n))) return rc;
     if ((rc = upload_u64(h, h->d_frame_len, frame_len, n))) return rc;
@@ -818,6 +824,7 @@ int zarc_gpu_pack_batch(zarc_gpu_t *h, size_t n, const void *const *src, const s
     uint64_t need = 0;
     for (size_t i = 0; i < n; i++) {
         if (src_len[i] && !src[i]) return ZARC_GPU_E_PARAM;
+        if ((uint64_t)src_len[i] >= 0xFFFFFFF0ull) { set_error(h, "entries of 4 GiB or more are not supported"); return ZARC_GPU_E_UNSUPPORTED; } // before any size arithmetic or staging
         l64[i] = src_len[i];
         in_sz[i] = align_up(src_len[i], ZARC_GPU_ALIGN);
         out_sz[i] = zarc_gpu_bound(src_len[i]);
@@ -833,7 +840,7 @@ int zarc_gpu_pack_batch(zarc_gpu_t *h, size_t n, const void *const *src, const s
     ZHIP(h->d_arena_out.reserve(2 * out_half));
     uint8_t *const ain = h->d_arena_in.as<uint8_t>(), *const aout = h->d_arena_out.as<uint8_t>();
     const int device = h->device;
-    hipStream_t side = h->stream2;
+    hipStream_t side = h->stream_stage;
     std::vector<uint64_t> doff(n), dlen(n);
     auto copy_in = [&](size_t c) -> int { // entries of chunk c -> input half c & 1
         std::vector<Seg> segs;
@@ -900,6 +907,7 @@ int zarc_gpu_unpack_batch(zarc_gpu_t *h, size_t n, const void *const *frame, con
     std::vector<uint64_t> in_sz(n), out_sz(n), weight(n), flen(n), rlen(n);
     for (size_t i = 0; i < n; i++) {
         if ((frame_len[i] && !frame[i]) || (raw_len[i] && !dst[i])) return ZARC_GPU_E_PARAM;
+        if ((uint64_t)frame_len[i] >= 0xFFFFFFF0ull || (uint64_t)raw_len[i] >= 0xFFFFFFF0ull) { set_error(h, "frames of 4 GiB or more are not supported"); return ZARC_GPU_E_UNSUPPORTED; } // before any size arithmetic or staging
         flen[i] = frame_len[i]; rlen[i] = raw_len[i];
         in_sz[i] = align_up(frame_len[i], ZARC_GPU_ALIGN);
         out_sz[i] = align_up(raw_len[i], ZARC_GPU_ALIGN);
@@ -913,7 +921,7 @@ int zarc_gpu_unpack_batch(zarc_gpu_t *h, size_t n, const void *const *frame, con
     ZHIP(h->d_arena_out.reserve(2 * out_half));
     uint8_t *const ain = h->d_arena_in.as<uint8_t>(), *const aout = h->d_arena_out.as<uint8_t>();
     const int device = h->device;
-    hipStream_t side = h->stream2;
+    hipStream_t side = h->stream_stage;
     auto copy_in = [&](size_t c) -> int {
         std::vector<Seg> segs;
         uint64_t at = 0;

@@ -57,6 +57,16 @@ std::string to_path(const std::vector<std::string> &name) // Pathname::to_path (
     return p;
 }
 
+// A pathname from an archive is untrusted: a component that is empty, ".", "..", or contains '/' or NUL would let a crafted
+// archive write outside the extraction directory (the reference joins components with PathBuf::push and has the same hole).
+bool safe_name(const std::vector<std::string> &name)
+{
+    if (name.empty()) return false;
+    for (const auto &c : name)
+        if (c.empty() || c == "." || c == ".." || c.find('/') != std::string::npos || c.find('\0') != std::string::npos) return false;
+    return true;
+}
+
 int usage()
 {
     std::fprintf(stderr, "usage: zarc pack --output PATH [--level N] [--zstd PARAM=VALUE]... [--store] [-L] PATH...\n"
@@ -274,7 +284,7 @@ int cmd_unpack(const std::vector<std::string> &a)
                 throw zarc::Error(res[k].status, path + ": " + zarc_gpu_frame_status_name(res[k].status));
             const size_t slash = path.rfind('/');
             if (slash != std::string::npos) mkdirs(path.substr(0, slash), 0777); // parent, in case its entry was not in the zarc
-            const int fd = open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
+            const int fd = open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC | O_NOFOLLOW, 0666);
             if (fd < 0) throw zarc::Error(ZARC_GPU_E_PARAM, path + ": " + std::strerror(errno));
             size_t off = 0;
             while (off < res[k].data.size()) { const ssize_t w = write(fd, res[k].data.data() + off, res[k].data.size() - off); if (w <= 0) { close(fd); throw zarc::Error(ZARC_GPU_E_PARAM, path + ": write failed"); } off += (size_t)w; }
@@ -290,6 +300,7 @@ int cmd_unpack(const std::vector<std::string> &a)
         const zarc::File &f = rd.files()[i];
         const std::string name = to_path(f.name);
         if (!passes(filters, name)) continue;
+        if (!safe_name(f.name)) { std::fprintf(stderr, "WARN unsafe pathname skipped: %s\n", name.c_str()); continue; }
         if (f.is_dir()) {
             flush();
             mkdirs(name, f.mode ? (mode_t)(*f.mode & 07777) : 0777);

@@ -344,7 +344,12 @@ class ArchiveReader {
         if (trailer_.compute_check() != e[17]) throw Error(ZARC_GPU_E_PARAM, "parse error: trailer check byte doesn't match");
         const int64_t raw_off = trailer_.directory_offset;
         if (trailer_.directory_offset < 0) trailer_.directory_offset += (int64_t)len;                                   // trailer.rs:91-95
-        if (trailer_.directory_offset < 12 || (uint64_t)trailer_.directory_offset >= len) throw Error(ZARC_GPU_E_PARAM, "parse error: directory offset");
+        // the directory frame lies between the header and the trailer frame: anything else (a crafted offset inside the last 62 bytes
+        // would make the length below wrap) is a parse error, as in the reference (decode/open.rs:118-133)
+        if (trailer_.directory_offset < 12 || (uint64_t)trailer_.directory_offset > len - SKIPPABLE_FRAME_OVERHEAD - TRAILER_LENGTH)
+            throw Error(ZARC_GPU_E_PARAM, "parse error: directory offset");
+        // a zstd frame cannot expand more than ~2^7 per byte at these sizes; refuse absurd claims before allocating for them
+        if (trailer_.directory_uncompressed_size > ((uint64_t)1 << 32)) throw Error(ZARC_GPU_E_PARAM, "parse error: directory size");
         const uint64_t dir_frame_len = len - SKIPPABLE_FRAME_OVERHEAD - TRAILER_LENGTH - (uint64_t)trailer_.directory_offset;
         (void)raw_off;
         // read_directory (decode/directory.rs:55-119): decode the directory frame, check its digest, parse elements

@@ -170,7 +170,11 @@ class FrameReader {
         std::vector<Digest> expect(n), got(n);
         std::vector<int> status(n);
         for (size_t i = 0; i < n; i++) {
-            if (wanted[i].offset + wanted[i].length > archive_len) throw Error(ZARC_GPU_E_PARAM, "frame outside the archive");
+            // untrusted directory records: no u64 wrap-around, no frame beyond the file, no allocation the engine would refuse anyway
+            if (wanted[i].length > archive_len || wanted[i].offset > archive_len - wanted[i].length) throw Error(ZARC_GPU_E_PARAM, "frame outside the archive");
+            if (wanted[i].uncompressed >= 0xFFFFFFF0ull || wanted[i].length >= 0xFFFFFFF0ull) throw Error(ZARC_GPU_E_UNSUPPORTED, "frames of 4 GiB or more are not supported");
+            // Zstandard cannot expand a frame by more than a factor of ~(128 KiB block from a 4-byte RLE block): a larger claim is corrupt
+            if (wanted[i].uncompressed > (wanted[i].length + 16) * (uint64_t)65536) throw Error(ZARC_GPU_E_PARAM, "frame claims an impossible uncompressed size");
             out[i].data.resize(wanted[i].uncompressed);
             fp[i] = archive + wanted[i].offset;
             fl[i] = wanted[i].length;
