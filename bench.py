@@ -1,18 +1,24 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the content engine (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
 
 metric  : uncompressed GiB/s of `zarc pack` at zstd level 3 (BLAKE3 + frame encode + XXH64), inputs resident in
           HBM; the same line carries the unpack rate, the compression ratio and the ratio vs libzstd -3.
 workload: BASELINE.json configs[1]/[2] -- 10 000 x 1 MiB synthetic entries per GPU (kinds text / records / lz /
           random round-robin); `--entries` scales it down for quick runs.
+          --config c4: configs[3] shape (4 MiB frames of the lz stream, level 9), --config c5: configs[4] shape (64 KiB .. 16 MiB
+          log-uniform sizes, level 3) -- whatever count fits one GPU; their lines are kept under profiles/.
 step    : one pack pass over the whole batch (timed region 1), and one unpack pass over its output (region 2).
-scaling : weak -- every rank packs its own `entries` entries (corpus indices rank*entries ...), no collective
-          on the data path; only the timing barrier / max-over-ranks uses torch.distributed (RCCL).
+scaling : weak -- the global entry list is dealt to the ranks by the same sharder the product uses (zarc::ShardedEncoder: index mod
+          G for equal sizes, greedy by bytes otherwise; zarc_amd/shard.py), every rank packs its share; no collective on the data
+          path; only the timing barrier / max-over-ranks uses torch.distributed (RCCL).
+extras  : host_path (PCIe-inclusive rates through the host-pointer entry points, pageable and pinned), unpack_roofline,
+          cpu_baseline (the reference's CPU path, C driver tests/support/cpu_baseline.c, 1 thread and all host cores).
 """
 import argparse
 import ctypes
+import hashlib
 import json
 import os
 import sys
@@ -27,11 +33,6 @@ GIB = float(1 << 30)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def shard_indices(rank, entries):
-    """Weak scaling: rank r owns corpus entries [r*entries, (r+1)*entries)."""
-    return rank * entries
-
-
 def aggregate(local_seconds, local_units, dist=None, device=None):
     """Max time over ranks, sum of units over ranks (value = units / max time)."""
     if dist is None:
@@ -44,57 +45,115 @@ def aggregate(local_seconds, local_units, dist=None, device=None):
     return float(t.item()), float(u.item())
 
 
-def cpu_baseline(entries_sample, size, first_index):
-    """The reference's CPU path on this box's host cores, bounded sample: libzstd (dlopen) ZSTD_compress2 with
-    checksumFlag=1 at level 3 after session reset (content_frame.rs:37-41, pack.rs:227) + BLAKE3 (oracle port;
-    the blake3 crate's SIMD is faster).  Single thread, like the reference."""
+def cpu_baseline(sample, size, first_index, level):
+    """The reference's CPU path on this box's host cores (rank 0, N = 1 only), bounded sample: tests/support/cpu_baseline.c --
+    one CCtx with session resets (content_frame.rs:37-41), decompressStream in 131 075 / 131 072-byte steps
+    (zstd_iterator.rs:88-153), BLAKE3 on both sides.  libzstd = the fastest build found on the box (they differ 3x)."""
     sys.path.insert(0, os.path.join(ROOT, "tests", "support"))
     import harness
-    corpus, oracle = harness.Corpus(), harness.Oracle()
     zs = harness.libzstds()
-    z = next((x for x in zs if x.version.startswith("1.5")), None) or (zs[0] if zs else None)
-    raws = [corpus.entry(first_index + i, size, -1) for i in range(entries_sample)]
-    t0 = time.perf_counter()
-    comp = 0
-    frames = []
-    for r in raws:
-        oracle.blake3(r)
-        f = z.compress(r, 3, 1) if z else oracle.zge_encode(r)
-        frames.append(f)
-        comp += len(f)
-    t_pack = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    for r, f in zip(raws, frames):
-        if z:
-            out, _ = z.decompress(f, len(r))
-        else:
-            _, out, _ = oracle.zstd_decode(f, len(r))
-        oracle.blake3(out)
-    t_unpack = time.perf_counter() - t0
-    total = float(entries_sample * size)
-    # the same work spread over the host's cores (one context per call; ctypes releases the GIL): what the reference could reach if
-    # its loop (crates/zarc-cli/src/pack.rs:244-265) were parallelised -- reported beside the faithful single-thread figure
-    mt = None
-    try:
-        from concurrent.futures import ThreadPoolExecutor
-        threads = min(os.cpu_count() or 1, 64)
-        if threads > 1 and z:
-            def one(r):
-                oracle.blake3(r)
-                return len(z.compress(r, 3, 1))
+    if not zs:
+        return None, None
+    probe = {}
+    for z in zs:  # quick probe: 16 MiB through each build on one thread
+        r = harness.cpu_baseline(z.path, level, 1, 16, size, first_index)
+        probe[z.path] = r["pack_seconds"]
+    zbest = min(zs, key=lambda z: probe[z.path])
+    z15 = next((z for z in zs if z.version.startswith("1.5")), zbest)
+    cores = os.cpu_count() or 1
+    one = harness.cpu_baseline(zbest.path, level, 1, sample, size, first_index)
+    many = harness.cpu_baseline(zbest.path, level, cores, min(4 * sample, 4096), size, first_index) if cores > 1 else None
+    ref = harness.cpu_baseline(z15.path, level, cores, min(sample, 256), size, first_index)  # ratio yardstick: the 1.5.x build
+    out = {"value": one["bytes"] / one["pack_seconds"] / GIB, "unit": "GiB/s", "cores": 1, "kind": "port",
+           "unpack_value": one["bytes"] / one["unpack_seconds"] / GIB,
+           "sample": "%d x %d B corpus entries from index %d, level %d; C driver tests/support/cpu_baseline.c (one CCtx + session reset per "
+                     "entry, decompressStream in 131075/131072-byte steps, oracle BLAKE3 port on both sides); %s; %d host cores online"
+                     % (sample, size, first_index, level, one["info"], cores),
+           "ratio": one["bytes"] / one["compressed_bytes"]}
+    if many:
+        out["multithreaded"] = {"value": many["bytes"] / many["pack_seconds"] / GIB, "unpack_value": many["bytes"] / many["unpack_seconds"] / GIB,
+                                "unit": "GiB/s", "cores": cores, "kind": "port",
+                                "sample": "%d entries, %d threads, one context per thread" % (many["bytes"] // size, cores)}
+    return out, (ref["compressed_bytes"], ref["bytes"] // size, "libzstd %s" % z15.version)
+
+
+def lib_sha16(path):
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+
+
+def workload(args, rank, world):
+    """(sizes of this rank's entries, corpus index of each, kind, level, description) -- the global list dealt by the product's sharder."""
+    from zarc_amd import shard
+    import random
+    if args.config == "c5":   # BASELINE configs[4] shape: 64 KiB .. 16 MiB log-uniform, kinds round-robin, level 3
+        rnd = random.Random(5)
+        target = int(args.gib * GIB) * world
+        sizes, tot = [], 0
+        while tot < target:
+            s = int(65536 * 2 ** (rnd.random() * 8))
+            sizes.append(s)
+            tot += s
+        level, kind = 3, -1
+        desc = "zarc pack %d mixed entries 64 KiB..16 MiB (log-uniform, %.1f GiB), zstd level 3 (BASELINE configs[4] shape)" % (len(sizes), tot / GIB)
+    elif args.config == "c4":  # BASELINE configs[3] shape: one long lz stream cut into 4 MiB frames, level 9
+        n = int(args.gib * GIB) // (4 << 20) * world
+        sizes = [4 << 20] * n
+        level, kind = 9, 2
+        desc = "zarc pack %d x 4 MiB frames of the lz stream (%.1f GiB), zstd level 9 (BASELINE configs[3] shape)" % (n, n * 4 / 1024.0)
+    else:
+        n = args.entries * world
+        sizes = [args.size] * n
+        level, kind = 3, args.kind
+        desc = "zarc pack %d x %d B synthetic entries per GPU, zstd level 3, checksum on (BASELINE configs[1]%s)" % (
+            args.entries, args.size, "" if (args.entries, args.size) == (10000, 1 << 20) else ", scaled")
+    mine = shard.assign(sizes, world)[rank]          # positions in the global list
+    if args.config == "c2":
+        # Weak scaling keeps every rank's share the SAME mix of kinds: list position j holds corpus entry (j mod G) * entries + j // G, so
+        # that index-mod-G dealing hands rank r the corpus range [r * entries, (r + 1) * entries) (kind = corpus index mod 4; dealing
+        # corpus index j itself would give each of 4 or 8 ranks a single kind).
+        cidx = [(j % world) * args.entries + j // world for j in mine]
+    else:
+        cidx = list(mine)
+    return [sizes[i] for i in mine], cidx, kind, level, desc, len(sizes)
+
+
+def host_path(eng, _lib, torch, d_src, off, lens, n_host, size):
+    """PCIe-inclusive rates through zarc_gpu_pack_batch / zarc_gpu_unpack_batch (what a caller with ordinary buffers gets): the first
+    n_host entries of the resident batch are copied to host memory first; only the ABI calls are timed."""
+    out = {}
+    nbytes = n_host * size
+    cap = int(eng.bound(size)) * n_host
+    for mode in ("pageable", "pinned"):
+        pin = mode == "pinned"
+        src = torch.empty(nbytes, dtype=torch.uint8, pin_memory=pin)
+        dst = torch.empty(cap, dtype=torch.uint8, pin_memory=pin)
+        back = torch.empty(nbytes, dtype=torch.uint8, pin_memory=pin)
+        eng._check(eng.lib.zarc_gpu_memcpy_d2h(eng.h, ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(d_src), nbytes))
+        ptrs = (ctypes.c_void_p * n_host)(*[src.data_ptr() + i * size for i in range(n_host)])
+        ln = (ctypes.c_size_t * n_host)(*[size] * n_host)
+        doff, dlen = (ctypes.c_size_t * n_host)(), (ctypes.c_size_t * n_host)()
+        dig, st = np.zeros((n_host, 32), dtype=np.uint8), (ctypes.c_int * n_host)()
+        dig2 = np.zeros((n_host, 32), dtype=np.uint8)
+        best = [1e30, 1e30]
+        for _ in range(2):
             t0 = time.perf_counter()
-            with ThreadPoolExecutor(threads) as ex:
-                list(ex.map(one, raws))
-            t_mt = time.perf_counter() - t0
-            mt = {"value": total / t_mt / GIB, "unit": "GiB/s", "cores": threads, "kind": "port",
-                  "sample": "same entries, %d threads, one libzstd context per entry" % threads}
-    except Exception:
-        mt = None
-    return {"value": total / t_pack / GIB, "unit": "GiB/s", "cores": 1, "kind": "port", "multithreaded": mt,
-            "unpack_value": total / t_unpack / GIB,
-            "sample": "%d x %d B entries (corpus %d..), libzstd %s via dlopen + oracle BLAKE3, 1 thread"
-                      % (entries_sample, size, first_index, z.version if z else "absent->oracle model"),
-            "ratio": total / comp}, comp
+            eng._check(eng.lib.zarc_gpu_pack_batch(eng.h, n_host, ptrs, ln, ctypes.c_void_p(dst.data_ptr()), cap, doff, dlen,
+                                                   dig.ctypes.data_as(ctypes.c_void_p), st))
+            t1 = time.perf_counter()
+            fptrs = (ctypes.c_void_p * n_host)(*[dst.data_ptr() + doff[i] for i in range(n_host)])
+            flens = (ctypes.c_size_t * n_host)(*[dlen[i] for i in range(n_host)])
+            optrs = (ctypes.c_void_p * n_host)(*[back.data_ptr() + i * size for i in range(n_host)])
+            t2 = time.perf_counter()
+            eng._check(eng.lib.zarc_gpu_unpack_batch(eng.h, n_host, fptrs, flens, ln, optrs, dig.ctypes.data_as(ctypes.c_void_p),
+                                                     dig2.ctypes.data_as(ctypes.c_void_p), st))
+            t3 = time.perf_counter()
+            best = [min(best[0], t1 - t0), min(best[1], t3 - t2)]
+        assert all(s == 0 for s in st) and (dig2 == dig).all() and bool((back == src).all())
+        out[mode] = {"pack_gibs": round(nbytes / best[0] / GIB, 2), "unpack_gibs": round(nbytes / best[1] / GIB, 2)}
+        del src, dst, back
+    out["bytes"] = nbytes
+    out["note"] = "zarc_gpu_pack_batch / zarc_gpu_unpack_batch with host pointers, best of 2, H2D + kernels + D2H inside the timed call"
+    return out
 
 
 def main():
@@ -102,16 +161,23 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", choices=["c2", "c4", "c5"], default="c2", help="c2: BASELINE configs[1]/[2] (the headline); c4 / c5: configs[3] / [4] shapes")
+    ap.add_argument("--gib", type=float, default=32.0, help="c4 / c5: uncompressed GiB per GPU")
     ap.add_argument("--entries", type=int, default=10000, help="entries per GPU (BASELINE configs[1]: 10000)")
     ap.add_argument("--size", type=int, default=1 << 20, help="bytes per entry (BASELINE configs[1]: 1 MiB)")
-    ap.add_argument("--cpu-sample", type=int, default=1024, help="entries timed on the host for cpu_baseline (rank 0, N=1): about 20 s of libzstd + BLAKE3 on one thread")
+    ap.add_argument("--cpu-sample", type=int, default=1024, help="entries timed on one host thread for cpu_baseline (rank 0, N=1)")
+    ap.add_argument("--host-entries", type=int, default=8192, help="entries (of the resident batch) sent through the host-pointer entry points")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-path", action="store_true")
     ap.add_argument("--kind", type=int, default=-1, help="diagnostics: use one corpus kind for every entry (default: round-robin)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE is %d: for N > 1 launch with `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`"
+                 % (args.gpus, world))
     import torch
     dist = None
     if world > 1 or "RANK" in os.environ:  # under torchrun always go through RCCL, even with one rank
@@ -122,20 +188,27 @@ def main():
     device = torch.device("cuda", local_rank)
 
     from zarc_amd import Engine, _lib
+    sizes, index, kind, level, desc, n_global = workload(args, rank, world)
     eng = Engine(local_rank)
-    eng.set_parameter(_lib.P_COMPRESSION_LEVEL, 3)
+    eng.set_parameter(_lib.P_COMPRESSION_LEVEL, level)
     eng.set_parameter(_lib.P_CHECKSUM_FLAG, 1)  # crates/zarc-cli/src/pack.rs:227
 
-    n, size = args.entries, args.size
-    stride = (size + 15) // 16 * 16
-    off = np.arange(n, dtype=np.uint64) * np.uint64(stride)
-    lens = np.full(n, size, dtype=np.uint64)
-    cap = int(eng.bound(size)) * n
-    d_src = eng.malloc(n * stride + _lib.PAD)
+    n = len(sizes)
+    lens = np.array(sizes, dtype=np.uint64)
+    strides = (lens + np.uint64(15)) // np.uint64(16) * np.uint64(16)
+    off = np.concatenate([[0], np.cumsum(strides)[:-1]]).astype(np.uint64)
+    total_in = int(strides.sum())
+    bound_of = {s: int(eng.bound(int(s))) for s in set(sizes)}
+    cap = sum(bound_of[s] for s in sizes)
+    d_src = eng.malloc(total_in + _lib.PAD)
     d_dst = eng.malloc(cap + _lib.PAD)
-    d_out = eng.malloc(n * stride + _lib.PAD)
-    first = shard_indices(rank, n)
-    eng.corpus_fill(d_src, off, lens, first_index=first, kind=args.kind)
+    d_out = eng.malloc(total_in + _lib.PAD)
+    # corpus entry of global index g is generated as corpus index g (any rank can generate any entry independently); c4 cuts ONE lz
+    # stream per frame index the same way
+    idx = np.array(index, dtype=np.int64)
+    runs = np.split(np.arange(n), np.where(np.diff(idx) != 1)[0] + 1) if n else []
+    for r in runs:  # contiguous index runs -> one fill call each (index mod G sharding gives runs of one; fill per entry then)
+        eng.corpus_fill(d_src + int(off[r[0]]), off[r] - off[r[0]], lens[r], first_index=int(idx[r[0]]), kind=kind)
 
     def barrier():
         if dist is not None:
@@ -147,10 +220,10 @@ def main():
         doff, dlen, dig, st = eng.pack_device(d_src, off, lens, d_dst, cap)
     barrier()
     t0 = time.perf_counter()
-    k_ms = np.zeros(_lib.T_TOTAL + 1)
+    k_ms = np.zeros(_lib.T_DEC_FRAMES + 1)
     for _ in range(args.steps):
         doff, dlen, dig, st = eng.pack_device(d_src, off, lens, d_dst, cap)   # synchronous at the ABI
-        k_ms += np.array([eng.kernel_ms(i) for i in range(_lib.T_TOTAL + 1)])
+        k_ms += np.array([eng.kernel_ms(i) for i in range(_lib.T_DEC_FRAMES + 1)])
     barrier()
     t_pack = time.perf_counter() - t0
     assert (st == 0).all()
@@ -163,10 +236,10 @@ def main():
         dig2, st2 = eng.unpack_device(d_dst, doff, dlen, d_out, off, lens, expect=dig)
     barrier()
     t0 = time.perf_counter()
-    u_ms = np.zeros(_lib.T_TOTAL + 1)
+    u_ms = np.zeros(_lib.T_DEC_FRAMES + 1)
     for _ in range(args.steps):
         dig2, st2 = eng.unpack_device(d_dst, doff, dlen, d_out, off, lens, expect=dig)
-        u_ms += np.array([eng.kernel_ms(i) for i in range(_lib.T_TOTAL + 1)])
+        u_ms += np.array([eng.kernel_ms(i) for i in range(_lib.T_DEC_FRAMES + 1)])
     barrier()
     t_unpack = time.perf_counter() - t0
     u_ms /= max(args.steps, 1)
@@ -185,42 +258,64 @@ def main():
         dom = max(names, key=lambda i: k_ms[i])
         alg_bytes = raw_bytes + comp_bytes + 32.0 * n
         achieved = alg_bytes / (k_ms[dom] * 1e-3) / 1e9 if k_ms[dom] > 0 else 0.0
-        # HBM traffic of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
-        # runs; FETCH_SIZE doubled per MI355X_MICROARCH.md -- calibrated here on zarc_xxh64, which reads exactly N bytes
-        # and reports N/2), scaled from the profiled batch to this one by uncompressed bytes.
-        traffic, traffic_src = None, None
-        pmc_file = os.path.join(ROOT, "profiles", "r01_bench_pmc_summary.json")
+        unames = {_lib.T_DEC_SEQS: "zdec_seqs", _lib.T_DEC_LITS: "zdec_literals", _lib.T_DEC_FRAMES: "zstd_frames", _lib.T_XXH64: "xxh64",
+                  _lib.T_BLAKE3: "blake3"}
+        udom = max(unames, key=lambda i: u_ms[i])
+        u_achieved = alg_bytes / (u_ms[udom] * 1e-3) / 1e9 if u_ms[udom] > 0 else 0.0
+        # HBM traffic of those kernels from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs;
+        # FETCH_SIZE doubled per MI355X_MICROARCH.md -- calibrated on zarc_xxh64, which reads exactly N bytes and reports N/2).
+        # Only quoted when the profile was taken on THIS build of the library (sha256 recorded by tools/profile.sh) and this workload.
+        traffic = u_traffic = None
+        traffic_src = "none: no PMC profile of this library build under profiles/"
+        pmc_file = os.path.join(ROOT, "profiles", "r02_bench_pmc_summary.json")
         if os.path.exists(pmc_file):
             pmc = json.load(open(pmc_file))
-            kname = "zarc_" + names[dom]
-            if kname in pmc.get("fetch", {}) and kname in pmc.get("write", {}):
-                per = (2.0 * pmc["fetch"][kname]["per_dispatch"] + pmc["write"][kname]["per_dispatch"]) * 1024.0
-                prof_bytes = float(pmc.get("entries", 2048)) * float(pmc.get("entry_bytes", 1 << 20))
-                traffic = per * raw_bytes / prof_bytes
-                traffic_src = "profiles/r01_bench_pmc_summary.json (%d entries profiled), scaled by uncompressed bytes" % pmc.get("entries", 2048)
+            same = pmc.get("lib_sha16") == lib_sha16(eng.lib_path) and pmc.get("entries") == n and pmc.get("entry_bytes") == args.size and args.config == "c2"
+            if same:
+                def tr(kname):
+                    if kname in pmc.get("fetch", {}) and kname in pmc.get("write", {}):
+                        return (2.0 * pmc["fetch"][kname]["per_dispatch"] + pmc["write"][kname]["per_dispatch"]) * 1024.0
+                    return None
+                traffic, u_traffic = tr("zarc_" + names[dom]), tr("zarc_" + unames[udom])
+                traffic_src = "profiles/r02_bench_pmc_summary.json (same library build %s, same workload)" % pmc["lib_sha16"]
+            else:
+                traffic_src = "none: profiles/r02_bench_pmc_summary.json is of another build or workload"
         line = {
-            "metric": "uncompressed GiB/s (pack) at zstd -3", "value": round(pack_gibs, 3), "unit": "GiB/s",
+            "metric": "uncompressed GiB/s (pack) at zstd -%d" % level, "value": round(pack_gibs, 3), "unit": "GiB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(tp / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "zarc pack %d x %d B synthetic entries per GPU, zstd level 3, checksum on "
-                                   "(BASELINE configs[1]%s)" % (n, size, "" if (n, size) == (10000, 1 << 20) else ", scaled"),
-                       "entries_per_gpu": n, "entry_bytes": size, "kinds": "text/records/lz/random round-robin", "parallelism": "frames sharded by index, no collective"},
+            "config": {"workload": desc, "entries_per_gpu": n, "entries_total": n_global, "entry_bytes": args.size if args.config == "c2" else "mixed" if args.config == "c5" else 4 << 20,
+                       "level": level, "kinds": "text/records/lz/random round-robin" if kind < 0 else "kind %d" % kind,
+                       "parallelism": "frames dealt to %d GPU(s) by the product's sharder (index mod G / greedy by bytes), no collective" % world},
             "unpack_gibs": round(unpack_gibs, 3), "unpack_ms_per_step": round(tu / args.steps * 1e3, 3),
             "roundtrip_bit_exact": ok,
             "ratio": round(raw_bytes / comp_bytes, 4),
             "kernel_ms": {names[i]: round(float(k_ms[i]), 3) for i in names},
-            "unpack_kernel_ms": {"zstd_decode": round(float(u_ms[_lib.T_DECODE]), 3), "xxh64": round(float(u_ms[_lib.T_XXH64]), 3),
-                                 "blake3": round(float(u_ms[_lib.T_BLAKE3]), 3)},
+            "unpack_kernel_ms": {"zstd_decode": round(float(u_ms[_lib.T_DECODE]), 3), "zdec_seqs": round(float(u_ms[_lib.T_DEC_SEQS]), 3),
+                                 "zdec_literals": round(float(u_ms[_lib.T_DEC_LITS]), 3), "zstd_frames": round(float(u_ms[_lib.T_DEC_FRAMES]), 3),
+                                 "xxh64": round(float(u_ms[_lib.T_XXH64]), 3), "blake3": round(float(u_ms[_lib.T_BLAKE3]), 3)},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(float(k_ms[dom]), 3)},
+            "unpack_roofline": {"bound": "hbm", "kernel": unames[udom], "achieved": round(u_achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": round(u_achieved / HBM_PEAK_GBS, 5), "traffic": u_traffic,
+                                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(float(u_ms[udom]), 3)},
+            "library_sha16": lib_sha16(eng.lib_path),
         }
+        if world == 1 and args.config == "c2" and not args.no_host_path:
+            nh = min(args.host_entries, n)
+            line["host_path"] = host_path(eng, _lib, torch, d_src, off, lens, nh, args.size)
         if world == 1 and not args.no_cpu_baseline:
-            sample = min(args.cpu_sample, n)
-            cb, ref_comp = cpu_baseline(sample, size, first)
-            ours = float(dlen[:sample].sum())
-            line["cpu_baseline"] = cb
-            line["ratio_vs_reference"] = round(ref_comp / ours, 4)   # >= 0.95 required (within 5 % of libzstd -3)
+            size0 = int(lens[0])
+            sample = min(args.cpu_sample, n) if args.config == "c2" else min(64, n)
+            cb, ref = cpu_baseline(sample, size0 if args.config != "c5" else 1 << 20, int(index[0]), level)
+            if cb:
+                line["cpu_baseline"] = cb
+                if args.config == "c2" and kind < 0:
+                    ref_comp, ref_n, ref_name = ref
+                    ours = float(dlen[:ref_n].sum())
+                    line["ratio_vs_reference"] = round(ref_comp / ours, 4)   # >= 0.95 required (within 5 % of libzstd -3)
+                    line["ratio_reference"] = "%s -%d on the first %d entries" % (ref_name, level, ref_n)
         print(json.dumps(line))
     for p in (d_src, d_dst, d_out):
         eng.free(p)

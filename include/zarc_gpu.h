@@ -176,7 +176,10 @@ enum {
     ZARC_GPU_T_ASSEMBLE = 4,  /* encoder: frame assembly               */
     ZARC_GPU_T_DECODE = 5,    /* decoder                               */
     ZARC_GPU_T_TOTAL = 6,     /* first launch .. last launch of the call */
-    ZARC_GPU_T_COUNT = 7
+    ZARC_GPU_T_DEC_SEQS = 7,  /* decoder stage 2: sequence entropy decoding (zarc_zdec_seqs)             */
+    ZARC_GPU_T_DEC_LITS = 8,  /* decoder stage 2: Huffman literals (zarc_zdec_literals, side stream)      */
+    ZARC_GPU_T_DEC_FRAMES = 9,/* decoder frame pass (zarc_zstd_frames + the inline decoder for the rest)  */
+    ZARC_GPU_T_COUNT = 10
 };
 float zarc_gpu_last_kernel_ms(const zarc_gpu_t *h, int which);
 /* Fill a device buffer with entries of the synthetic corpus; entry i of the

@@ -59,6 +59,18 @@ def recipe_bytes(recipe, corpus):
         return bytes(out[:n])
     if kind == "random":
         return bytes(rnd.getrandbits(8) for _ in range(n))
+    if kind == "shuffle":
+        # `distinct` units of corpus content in a seeded pseudo-random order, every copy with a few byte mutations: long inputs that
+        # compress to little, whose matches reach back across many 128 KiB blocks -- as far as the encoder's window allows (2 MiB at
+        # level 3, 4 MiB at level 9, 8 MiB at level 19 for these sizes), in frames that carry a Window_Descriptor
+        units = [corpus.entry(recipe["index"] + k, recipe["unit"], recipe["ckind"]) for k in range(recipe["distinct"])]
+        out = bytearray()
+        while len(out) < n:
+            u = bytearray(units[rnd.randrange(recipe["distinct"])])
+            for _ in range(recipe["mut"]):
+                u[rnd.randrange(len(u))] = rnd.randrange(256)
+            out += u
+        return bytes(out[:n])
     raise ValueError(kind)
 
 
@@ -71,6 +83,12 @@ RECIPES = {
     "few50k": {"kind": "few", "n": 50000, "seed": 3}, "sparse100k": {"kind": "sparse", "n": 100000, "seed": 4},
     "runs150k": {"kind": "runs", "n": 150000, "seed": 5},
 }
+# long inputs: frames with a window descriptor, back-references of megabytes across dozens of blocks
+BIG_RECIPES = {
+    "shuf2m5": {"kind": "shuffle", "n": (5 << 20) // 2, "unit": 96 * 1024 + 7, "distinct": 5, "seed": 11, "index": 200, "ckind": 0, "mut": 9},
+    "shuf4m": {"kind": "shuffle", "n": 4 << 20, "unit": 128 * 1024 + 333, "distinct": 6, "seed": 12, "index": 210, "ckind": 1, "mut": 14},
+    "shuf16m": {"kind": "shuffle", "n": 16 << 20, "unit": 160 * 1024 + 1, "distinct": 7, "seed": 13, "index": 220, "ckind": 0, "mut": 20},
+}
 
 
 def main():
@@ -82,7 +100,7 @@ def main():
         d = bytes((131 * i + 7) & 255 for i in range(n))
         xx[str(n)] = "%016x" % xxhash.xxh64(d, seed=0).intdigest()
     json.dump(xx, open(os.path.join(HERE, "xxh64_kat.json"), "w"), indent=1, sort_keys=True)
-    manifest = {"recipes": RECIPES, "frames": []}
+    manifest = {"recipes": dict(RECIPES, **BIG_RECIPES), "frames": []}
     fdir = os.path.join(HERE, "zstd_frames")
     for f in os.listdir(fdir):
         os.remove(os.path.join(fdir, f))
@@ -98,6 +116,19 @@ def main():
                     manifest["frames"].append({"file": fn, "recipe": name, "libzstd": z.version, "level": lvl, "checksum": ck,
                                                "raw_len": len(data), "raw_sha256": hashlib.sha256(data).hexdigest(),
                                                "raw_blake3": o.blake3(data).hex()})
+    for z in libzstds():
+        if not z.version.startswith("1.5"):
+            continue
+        for name, rec in BIG_RECIPES.items():
+            data = recipe_bytes(rec, c)
+            for lvl in (3, 9, 19):
+                frame = z.compress(data, lvl, 1)
+                fn = "%s_v%s_l%d_c1.zst" % (name, z.version, lvl)
+                open(os.path.join(fdir, fn), "wb").write(frame)
+                manifest["frames"].append({"file": fn, "recipe": name, "libzstd": z.version, "level": lvl, "checksum": 1,
+                                           "raw_len": len(data), "raw_sha256": hashlib.sha256(data).hexdigest(),
+                                           "raw_blake3": o.blake3(data).hex()})
+                print(fn, len(frame), "descriptor %#x" % frame[4], "window byte %#x" % frame[5])
     json.dump(manifest, open(os.path.join(HERE, "zstd_frames", "manifest.json"), "w"), indent=1, sort_keys=True)
     print("frames:", len(manifest["frames"]))
 

@@ -82,6 +82,37 @@ int main(int argc, char **argv)
         auto r = rd.read_content_frames((const uint8_t *)img.data(), img.size(), {f});
         CHECK(r[0].status == ZARC_GPU_FRAME_OK && r[0].verify.value_or(false) && r[0].data == e);
     }
+    // --- several devices: the same batch dealt to two engine handles gives the same archive, byte for byte ---
+    {
+        std::vector<std::vector<uint8_t>> es;
+        const size_t mixed[] = {70000, 3000, big, 65536, 0, 90001, 20000, big + 5};
+        for (size_t i = 0; i < 8; i++) { es.emplace_back(mixed[i]); zarc_corpus_entry(es.back().data(), mixed[i], 700 + i, -1); }
+        es.push_back(es[2]); es.push_back(es[1]); es.push_back(es[0]); // duplicates whose first copy is packed by the other handle
+        std::vector<const void *> p2;
+        std::vector<size_t> l2;
+        for (auto &e : es) { p2.push_back(e.data()); l2.push_back(e.size()); }
+        auto run = [&](const std::vector<int> &devices, std::string *image, std::vector<zarc::Digest> *dg, uint64_t *end) {
+            std::ostringstream f2;
+            zarc::Encoder e2(f2, devices);
+            e2.set_zstd_parameter(ZARC_GPU_P_CHECKSUM_FLAG, 1);
+            *dg = e2.add_data_frames(p2.data(), l2.data(), p2.size());
+            *end = e2.offset();
+            *image = f2.str();
+            return e2.frames().size();
+        };
+        std::string one, two, eq;
+        std::vector<zarc::Digest> d1, d2, d3;
+        uint64_t e1 = 0, e2 = 0, e3 = 0;
+        const size_t f1 = run({0}, &one, &d1, &e1), f2 = run({0, 0}, &two, &d2, &e2);
+        CHECK(f1 == 8 && f2 == 8 && one == two && d1 == d2 && e1 == e2 && e1 == one.size());
+        const auto share = zarc::shard_assign(l2.data(), l2.size(), 2);
+        CHECK(share[0].size() + share[1].size() == 11);
+        // equal sizes: index mod G
+        std::vector<size_t> same(10, 4096);
+        const auto rr = zarc::shard_assign(same.data(), same.size(), 3);
+        CHECK(rr[0] == (std::vector<size_t>{0, 3, 6, 9}) && rr[1] == (std::vector<size_t>{1, 4, 7}) && rr[2] == (std::vector<size_t>{2, 5, 8}));
+        (void)eq; (void)d3; (void)e3;
+    }
     // --- parameter errors surface as exceptions carrying the libzstd-style name ---
     bool threw = false;
     try { enc.set_zstd_parameter(ZARC_GPU_P_COMPRESSION_LEVEL, 99); } catch (const zarc::Error &e) { threw = e.code == ZARC_GPU_E_PARAM; }

@@ -28,6 +28,34 @@ def _build_corpus():
     return so
 
 
+def _build_cpu_baseline():
+    d = os.path.join(ROOT, "tests", "support", "_build")
+    os.makedirs(d, exist_ok=True)
+    so = os.path.join(d, "libcpubaseline.so")
+    srcs = [os.path.join(ROOT, "tests", "support", "cpu_baseline.c"), os.path.join(ROOT, "oracle", "blake3_ref.c"),
+            os.path.join(ROOT, "oracle", "oracle.h"), os.path.join(ROOT, "zarc_amd", "csrc", "corpus.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-pthread", "-o", so, srcs[0], srcs[1], "-ldl"])
+    return so
+
+
+def cpu_baseline(libzstd_path, level, threads, n, entry_bytes, first_index=0):
+    """The reference's CPU path (one CCtx + session reset per entry, decompressStream in 131 075 / 131 072 byte steps, BLAKE3 on
+    both sides) on `threads` host threads: tests/support/cpu_baseline.c.  Returns a dict or raises."""
+    lib = ctypes.CDLL(_build_cpu_baseline())
+    lib.cpu_baseline_run.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_uint64,
+                                     ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64),
+                                     ctypes.c_char_p, ctypes.c_size_t]
+    tp, tu, cb = ctypes.c_double(), ctypes.c_double(), ctypes.c_uint64()
+    info = ctypes.create_string_buffer(400)
+    rc = lib.cpu_baseline_run(libzstd_path.encode(), level, threads, n, entry_bytes, first_index, ctypes.byref(tp), ctypes.byref(tu),
+                              ctypes.byref(cb), info, len(info))
+    if rc != 0:
+        raise RuntimeError("cpu_baseline_run failed: %d" % rc)
+    return {"pack_seconds": tp.value, "unpack_seconds": tu.value, "compressed_bytes": cb.value, "info": info.value.decode(),
+            "bytes": n * entry_bytes, "threads": threads}
+
+
 class ZgeParams(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in (
         "level", "checksum", "window_log", "long_log", "short_log", "short_bytes", "tile", "sub", "cap",

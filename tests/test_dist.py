@@ -1,5 +1,8 @@
-"""CPU, world_size 2 over gloo: the only cross-rank logic on this path -- sharding of entries by index and the
-max-time / sum-of-units aggregation bench.py uses (the data path itself has no collective)."""
+"""CPU, world_size 2 over gloo: the multi-GPU path of SURVEY.md section 8(e).  Frames are independent, so the path shards with no
+collective: each rank packs its share of a batch (here through the emulator build of the SAME kernels), the host merges in
+original index order -- running offsets from 12, first-wins dedup across ranks.  The merged archive body must be byte-identical
+to what one handle writes for the same entries, and a duplicate whose copies land on different ranks is written once.
+bench.py's aggregation (max time over ranks, sum of units) and the sharder itself are checked beside it."""
 import os
 import socket
 import sys
@@ -10,6 +13,7 @@ import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "support"))
 
 
 def _free_port():
@@ -20,37 +24,100 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _entries():
+    import harness
+    c = harness.Corpus()
+    ents = [c.entry(500 + i, n, -1) for i, n in enumerate((70000, 3000, 140000, 65536, 0, 90001, 20000, 131072))]
+    ents.append(ents[2])      # duplicates of entries that land on the OTHER rank (index 8 -> rank 0, its first copy 2 -> rank 0; 9 -> see below)
+    ents.append(ents[1])      # index 9: copy of index 1
+    ents.append(ents[0])      # index 10: copy of index 0
+    return ents
+
+
+def _worker(rank, world, port, emu_lib, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import bench
-    first = bench.shard_indices(rank, 1000)
-    # rank r "measures" (r+1) seconds for 1000 MiB
+    from zarc_amd import Engine, _lib, shard
+    ents = _entries()
+    shares = shard.assign([len(e) for e in ents], world)
+    eng = Engine(0, emu_lib)
+    eng.set_parameter(_lib.P_CHECKSUM_FLAG, 1)
+    mine = eng.pack([ents[i] for i in shares[rank]])          # the hot path, on this rank's share only
+    eng.close()
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)                       # host-side bookkeeping only: frames + digests to the merging rank
     t, u = bench.aggregate(float(rank + 1), 1000.0 * (1 << 20), dist, torch.device("cpu"))
-    q.put((rank, first, t, u))
+    if rank == 0:
+        body, records = shard.merge(shares, gathered)
+        q.put((body, records, t, u))
+    dist.barrier()
     dist.destroy_process_group()
 
 
-def test_shard_and_aggregate_world2():
+def test_sharded_pack_over_two_ranks_equals_single_handle(emu_lib_path, oracle):
+    from zarc_amd import Engine, _lib, shard
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, emu_lib_path, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=120) for _ in range(world))
+    body, records, t, u = q.get(timeout=600)
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
-    assert [r[1] for r in res] == [0, 1000]                       # disjoint corpus index ranges
-    for _, _, t, u in res:
-        assert t == 2.0 and u == 2000.0 * (1 << 20)               # max over ranks, sum over ranks
+    assert t == 2.0 and u == 2000.0 * (1 << 20)                  # max over ranks, sum over ranks
+    # the same entries through ONE handle, merged by the same host logic
+    ents = _entries()
+    eng = Engine(0, emu_lib_path)
+    eng.set_parameter(_lib.P_CHECKSUM_FLAG, 1)
+    single = eng.pack(ents)
+    eng.close()
+    body1, records1 = shard.merge([list(range(len(ents)))], [single])
+    assert body == body1 and records == records1                 # byte-identical archive body, identical Frame records
+    # duplicates: copies on different ranks (sizes differ -> greedy sharding) are written once, first index wins
+    shares = shard.assign([len(e) for e in ents], world)
+    owner = {i: d for d, s in enumerate(shares) for i in s}
+    assert any(owner[a] != owner[b] for a, b in ((2, 8), (1, 9), (0, 10)))
+    assert [r[3] for r in records[8:]] == [False, False, False] and all(r[3] for r in records[:8])
+    assert records[8][:2] == records[2][:2] and records[9][:2] == records[1][:2] and records[10][:2] == records[0][:2]
+    # offsets: running sums from 12 over what was written (content_frame.rs:22,45; encode.rs:65,75)
+    pos = 12
+    for (off, ln, dig, written), raw in zip(records, ents):
+        assert dig == oracle.blake3(raw)
+        if written:
+            assert off == pos
+            rc, out, used = oracle.zstd_decode(body[off - 12:off - 12 + ln], len(raw))
+            assert rc == 0 and out == raw and used == ln
+            pos += ln
+    assert pos - 12 == len(body)
 
 
-def test_shards_cover_without_overlap():
+def test_sharder_covers_every_entry_once_and_balances():
+    from zarc_amd import shard
+    import random
+    for g in (1, 2, 3, 8):
+        assert shard.assign([1 << 20] * 10000, g) == [list(range(d, 10000, g)) for d in range(g)]      # equal sizes: index mod G
+    rnd = random.Random(5)
+    sizes = [int(65536 * 2 ** (rnd.random() * 8)) for _ in range(4000)]                                  # BASELINE configs[4] shape
+    for g in (2, 8):
+        shares = shard.assign(sizes, g)
+        assert sorted(i for s in shares for i in s) == list(range(len(sizes)))
+        loads = [sum(sizes[i] for i in s) for s in shares]
+        assert max(loads) - min(loads) <= max(sizes) and all(s == sorted(s) for s in shares)
+
+
+def test_bench_workload_gives_every_rank_the_same_mix():
+    import argparse
     import bench
-    n, world = 10000, 8
-    spans = [(bench.shard_indices(r, n), bench.shard_indices(r, n) + n) for r in range(world)]
-    for a, b in zip(spans, spans[1:]):
-        assert a[1] == b[0]
+    a = argparse.Namespace(config="c2", entries=1000, size=1 << 20, kind=-1, gib=1.0)
+    for world in (1, 2, 4, 8):
+        seen = []
+        for r in range(world):
+            sizes, cidx, kind, level, desc, n_global = bench.workload(a, r, world)
+            assert len(sizes) == 1000 and n_global == 1000 * world and level == 3
+            assert cidx == list(range(r * 1000, (r + 1) * 1000))       # contiguous corpus range: all four kinds in equal parts
+            seen += cidx
+        assert sorted(seen) == list(range(1000 * world))

@@ -70,6 +70,7 @@ struct zarc_gpu {
     // staging arenas for the host-pointer entry points
     DevBuf d_arena_in, d_arena_out;
     hipEvent_t ev[16] = {};
+    hipEvent_t ev_dec[6] = {}; // decoder sub-kernels: seqs begin/end, literals begin/end (side stream), frame pass begin/end
     float ms[ZARC_GPU_T_COUNT];
     size_t scratch_budget = 0; // 0 = derive from free memory (ZARC_GPU_PX_SCRATCH_MB)
     uint64_t stage_chunk = 0;  // 0 = default per entry point (ZARC_GPU_PX_STAGE_CHUNK)
@@ -223,6 +224,8 @@ int zarc_gpu_create(zarc_gpu_t **out, int device)
         hipEventCreate(&h->ev_fork) != hipSuccess || hipEventCreate(&h->ev_join) != hipSuccess) { delete h; return ZARC_GPU_E_DEVICE; }
     for (auto &e : h->ev)
         if (hipEventCreate(&e) != hipSuccess) { delete h; return ZARC_GPU_E_DEVICE; }
+    for (auto &e : h->ev_dec)
+        if (hipEventCreate(&e) != hipSuccess) { delete h; return ZARC_GPU_E_DEVICE; }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) h->num_cus = prop.multiProcessorCount;
     h->params.level = 0;          // CCtx::init(0): default level (crates/zarc/src/encode.rs:62)
@@ -245,6 +248,7 @@ void zarc_gpu_destroy(zarc_gpu_t *h)
                      &h->d_slot_prefix, &h->d_zblocks, &h->d_nseq, &h->d_fast, &h->d_seqidx, &h->d_seqs, &h->d_ztables, &h->d_litidx, &h->d_lits};
     for (DevBuf *b : all) b->release();
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
+    for (auto &e : h->ev_dec) if (e) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->stream3) (void)hipStreamDestroy(h->stream3);
@@ -565,6 +569,7 @@ int zarc_gpu_unpack_batch_device(zarc_gpu_t *h, size_t n, const void *d_frames_b
     }
     Timer t{h};
     int e0, e1, e2, e3;
+    bool have_seq_t = false, have_lit_t = false;
     ZHIP(t.mark(&e0));
     // ---- fast path: block scan (lane per frame), then sequence entropy decoding with one lane per block ----
     bool fastpath = diag_env("ZARC_GPU_DEC_FAST", 1) != 0;
@@ -600,12 +605,16 @@ int zarc_gpu_unpack_batch_device(zarc_gpu_t *h, size_t n, const void *d_frames_b
         const bool side = lit_total && total && diag_env("ZARC_GPU_DEC_SIDE", 1) != 0;
         if (side) { ZHIP(hipEventRecord(h->ev_fork, h->stream)); ZHIP(hipStreamWaitEvent(h->stream2, h->ev_fork, 0)); }
         if (lit_total) {
+            ZHIP(hipEventRecord(h->ev_dec[2], side ? h->stream2 : h->stream));
             hipLaunchKernelGGL(zarc_zdec_literals, dim3((unsigned)((nslots + ZDEC_LIT_GROUP - 1) / ZDEC_LIT_GROUP)), dim3(64), 0, side ? h->stream2 : h->stream, (const uint8_t *)d_frames_base,
                                h->d_frame_off.as<uint64_t>(), (uint64_t)nslots, h->d_slot_prefix.as<uint64_t>(), h->d_zblocks.as<ZdecBlock>(), h->d_litidx.as<uint64_t>(),
                                h->d_lits.as<uint8_t>(), h->d_fast.as<uint32_t>());
             ZHIP(hipGetLastError());
+            ZHIP(hipEventRecord(h->ev_dec[3], side ? h->stream2 : h->stream));
+            have_lit_t = true;
         }
         if (total) {
+            ZHIP(hipEventRecord(h->ev_dec[0], h->stream));
             // Each lane is a long serial chain (about one L2/HBM round trip and 340 instructions per sequence).  Partly filled
             // waves (more waves to interleave) were measured and are slower: 35 ms with 64 lanes per wave, 54 ms with 16
             // (ZARC_GPU_SEQ_LANES reproduces it) -- the waves' own instruction issue dominates, not exposed waits.
@@ -632,10 +641,13 @@ int zarc_gpu_unpack_batch_device(zarc_gpu_t *h, size_t n, const void *d_frames_b
                                h->d_ztables.as<uint16_t>(), h->d_fast.as<uint32_t>(), (uint64_t)0);
             if (split < nslots) ZHIP(hipStreamWaitEvent(h->stream, h->ev_join3, 0));
             ZHIP(hipGetLastError());
+            ZHIP(hipEventRecord(h->ev_dec[1], h->stream));
+            have_seq_t = true;
         }
         if (side) { ZHIP(hipEventRecord(h->ev_join, h->stream2)); ZHIP(hipStreamWaitEvent(h->stream, h->ev_join, 0)); }
     }
     const int dec_dbg = diag_env("ZARC_GPU_DBG_DEC", 0);
+    ZHIP(hipEventRecord(h->ev_dec[4], h->stream));
     ZHIP(hipMemsetAsync(h->d_queue.p, 0, 8, h->stream)); // two queues: the fast frame pass and the general decoder each walk all frames
     if (fastpath) {
         hipLaunchKernelGGL(zarc_zstd_frames, dim3((unsigned)dec_grid), dim3(64), 0, h->stream, (const uint8_t *)d_frames_base, h->d_frame_off.as<uint64_t>(),
@@ -652,6 +664,7 @@ int zarc_gpu_unpack_batch_device(zarc_gpu_t *h, size_t n, const void *d_frames_b
                        h->d_status.as<int32_t>(), h->d_stored_ck.as<uint32_t>(), dec_dbg, h->d_queue.as<uint32_t>() + 1,
                        fastpath ? h->d_fast.as<uint32_t>() : (const uint32_t *)nullptr);
     ZHIP(hipGetLastError());
+    ZHIP(hipEventRecord(h->ev_dec[5], h->stream));
     ZHIP(t.mark(&e1));
     // verification passes over the decoded bytes (K2 + XXH64 inside libzstd in the reference)
     ZHIP(hipEventRecord(h->ev_fork, h->stream)); // checksum (side stream) and digest run next to each other
@@ -679,6 +692,10 @@ int zarc_gpu_unpack_batch_device(zarc_gpu_t *h, size_t n, const void *d_frames_b
         fprintf(stderr, "zstd_decode: %zu of %zu frames on the fast path\n", nf, n);
     }
     h->ms[ZARC_GPU_T_DECODE] = elapsed(h, e0, e1);
+    { float ms = -1.f;
+      if (have_seq_t && hipEventElapsedTime(&ms, h->ev_dec[0], h->ev_dec[1]) == hipSuccess) h->ms[ZARC_GPU_T_DEC_SEQS] = ms;
+      if (have_lit_t && hipEventElapsedTime(&ms, h->ev_dec[2], h->ev_dec[3]) == hipSuccess) h->ms[ZARC_GPU_T_DEC_LITS] = ms;
+      if (hipEventElapsedTime(&ms, h->ev_dec[4], h->ev_dec[5]) == hipSuccess) h->ms[ZARC_GPU_T_DEC_FRAMES] = ms; }
     h->ms[ZARC_GPU_T_XXH64] = elapsed(h, 14, 15); // side stream: overlaps the digest pass
     h->ms[ZARC_GPU_T_BLAKE3] = elapsed(h, e2, e3);
     h->ms[ZARC_GPU_T_TOTAL] = elapsed(h, e0, e3);
@@ -866,7 +883,7 @@ int zarc_gpu_pack_batch(zarc_gpu_t *h, size_t n, const void *const *src, const s
         if (hipStreamSynchronize(side) != hipSuccess) return ZARC_GPU_E_DEVICE; // `dense` is read by an async copy above
         return r;
     };
-    float sum[ZARC_GPU_T_COUNT] = {0, 0, 0, 0, 0, 0, 0};
+    float sum[ZARC_GPU_T_COUNT] = {};
     if ((rc = copy_in(0))) return rc;
     ZHIP(hipStreamSynchronize(side));
     for (size_t c = 0; c < cs.size(); c++) {
@@ -939,7 +956,7 @@ int zarc_gpu_unpack_batch(zarc_gpu_t *h, size_t n, const void *const *frame, con
         }
         return staged_d2h(h, side, segs, aout + (c & 1) * out_half, at);
     };
-    float sum[ZARC_GPU_T_COUNT] = {0, 0, 0, 0, 0, 0, 0};
+    float sum[ZARC_GPU_T_COUNT] = {};
     if ((rc = copy_in(0))) return rc;
     ZHIP(hipStreamSynchronize(side));
     for (size_t c = 0; c < cs.size(); c++) {

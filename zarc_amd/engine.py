@@ -17,7 +17,9 @@ class Engine:
     """One engine handle = one HIP stream on one device (CCtx/DCtx analogue, crates/zarc/src/encode.rs:58-78)."""
 
     def __init__(self, device=0, lib_path=None):
-        self.lib = _lib.load(lib_path)
+        import os
+        self.lib_path = lib_path or os.environ.get("ZARC_GPU_LIB") or _lib.DEFAULT_LIB
+        self.lib = _lib.load(self.lib_path)
         h = ctypes.c_void_p()
         rc = self.lib.zarc_gpu_create(ctypes.byref(h), device)
         if rc != 0:

@@ -69,7 +69,7 @@ bool safe_name(const std::vector<std::string> &name)
 
 int usage()
 {
-    std::fprintf(stderr, "usage: zarc pack --output PATH [--level N] [--zstd PARAM=VALUE]... [--store] [-L] PATH...\n"
+    std::fprintf(stderr, "usage: zarc pack --output PATH [--level N] [--zstd PARAM=VALUE]... [--store] [-L] [--gpus N] PATH...\n"
                          "       zarc unpack INPUT [--filter REGEX]... [--verify DIGEST]\n"
                          "       zarc list-files INPUT [--only-files] [--decorate] [--filter REGEX]...\n");
     return 2;
@@ -153,20 +153,23 @@ int cmd_pack(const std::vector<std::string> &a)
     std::vector<std::string> paths;
     std::vector<ZstdParam> params;
     bool store = false, follow = false, have_level = false;
-    int level = 0;
+    int level = 0, gpus = 1;
     for (size_t i = 0; i < a.size(); i++) {
         if (a[i] == "--output" && i + 1 < a.size()) output = a[++i];
         else if (a[i] == "--level" && i + 1 < a.size()) { level = std::atoi(a[++i].c_str()); have_level = true; }
         else if (a[i] == "--zstd" && i + 1 < a.size()) { ZstdParam p; if (!parse_zstd_param(a[++i], &p)) { std::fprintf(stderr, "error: invalid --zstd value\n"); return 2; } params.push_back(p); }
         else if (a[i] == "--store") store = true;
         else if (a[i] == "-L" || a[i] == "--follow-symlinks") follow = true;
+        else if (a[i] == "--gpus" && i + 1 < a.size()) gpus = std::atoi(a[++i].c_str()); // engine extension: deal every batch to N devices
         else if (!a[i].empty() && a[i][0] == '-') return usage();
         else paths.push_back(a[i]);
     }
-    if (output.empty()) return usage();
+    if (output.empty() || gpus < 1 || gpus > 64) return usage();
     std::ofstream file(output, std::ios::binary | std::ios::trunc);
     if (!file) { std::fprintf(stderr, "Error: %s: %s\n", output.c_str(), std::strerror(errno)); return 1; }
-    zarc::ArchiveWriter enc(file);
+    std::vector<int> devices;
+    for (int d = 0; d < gpus; d++) devices.push_back(d);
+    zarc::ArchiveWriter enc(file, devices);
     enc.set_zstd_parameter(ZARC_GPU_P_CHECKSUM_FLAG, 1); // pack.rs:227
     if (have_level) enc.set_zstd_parameter(ZARC_GPU_P_COMPRESSION_LEVEL, level);
     for (const auto &p : params) enc.set_zstd_parameter(p.id, p.value);

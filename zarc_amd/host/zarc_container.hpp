@@ -263,6 +263,7 @@ struct Trailer { // trailer.rs
 class ArchiveWriter : public Encoder {
   public:
     explicit ArchiveWriter(std::ostream &w, int device = 0) : Encoder(w, device) {}
+    ArchiveWriter(std::ostream &w, const std::vector<int> &devices) : Encoder(w, devices) {} // `zarc pack --gpus N`
 
     // Encoder::add_file_entry (add_file.rs:22-46)
     void add_file_entry(File f) { f.edition = 1; files_.push_back(std::move(f)); }
@@ -314,7 +315,7 @@ class ArchiveWriter : public Encoder {
         frame.resize(zarc_gpu_bound(n));
         size_t off = 0, len = 0;
         int st = 0;
-        engine_.check(zarc_gpu_pack_batch(engine_.get(), 1, &p, &n, frame.data(), frame.size(), &off, &len, (uint8_t(*)[32]) & digest, &st));
+        engine0().check(zarc_gpu_pack_batch(engine0().get(), 1, &p, &n, frame.data(), frame.size(), &off, &len, (uint8_t(*)[32]) & digest, &st));
         if (st != ZARC_GPU_FRAME_OK) throw Error(st, zarc_gpu_frame_status_name(st));
         if (off) std::memmove(frame.data(), frame.data() + off, len);
         return len;

@@ -15,16 +15,26 @@
 // offsets are running sums starting at 12 (encode.rs:65,75).  Unlike the reference, writes use write-all
 // semantics (the reference's `writer.write` can short-write, lowlevel_frames.rs:38 -- SURVEY quirk 1).
 // The archive directory / trailer (`add_file_entry`, `finalise`, `open`) live in zarc_container.hpp.
+//
+// Several GPUs: frames are independent, so an Encoder constructed with G devices deals the entries of a
+// batch to G engine handles (`shard_assign`: index mod G when all sizes are equal, largest-first onto the least loaded device
+// otherwise), packs the shares concurrently (one host thread per handle, no collective, nothing crosses between devices) and
+// then does in ORIGINAL index order exactly what the single-device path does: running offsets and first-wins dedup.  The
+// archive is byte-identical to the single-device one.
 #pragma once
 #include "../../include/zarc_gpu.h"
+#include <algorithm>
 #include <array>
 #include <cstdint>
 #include <cstring>
 #include <map>
+#include <memory>
+#include <numeric>
 #include <optional>
 #include <ostream>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -78,18 +88,47 @@ class Engine { // CCtx/DCtx analogue: one per Encoder / reader (encode.rs:60-62,
     zarc_gpu_t *h_ = nullptr;
 };
 
+// Which device packs which entry.  Equal sizes: entry i goes to device i mod G.  Mixed sizes (BASELINE
+// configs[4]): largest first onto the least loaded device by bytes (ties: the lower device), each share then back in index
+// order.  Deterministic; zarc_amd/shard.py is the same function for bench.py and the tests.
+inline std::vector<std::vector<size_t>> shard_assign(const size_t *len, size_t n, size_t g)
+{
+    std::vector<std::vector<size_t>> out(g ? g : 1);
+    if (g <= 1) { out[0].resize(n); std::iota(out[0].begin(), out[0].end(), (size_t)0); return out; }
+    bool equal = true;
+    for (size_t i = 1; i < n; i++) equal = equal && len[i] == len[0];
+    if (equal) { for (size_t i = 0; i < n; i++) out[i % g].push_back(i); return out; }
+    std::vector<size_t> order(n);
+    std::iota(order.begin(), order.end(), (size_t)0);
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return len[a] > len[b]; });
+    std::vector<uint64_t> load(g, 0);
+    for (size_t i : order) {
+        size_t best = 0;
+        for (size_t d = 1; d < g; d++) if (load[d] < load[best]) best = d;
+        out[best].push_back(i);
+        load[best] += len[i];
+    }
+    for (auto &v : out) std::sort(v.begin(), v.end());
+    return out;
+}
+
 class Encoder {
   public:
     // Encoder::new: creates the context and writes the 12-byte header (encode.rs:58-78)
-    explicit Encoder(std::ostream &writer, int device = 0) : writer_(writer), engine_(device)
+    explicit Encoder(std::ostream &writer, int device = 0) : Encoder(writer, std::vector<int>{device}) {}
+    // ... on several devices: one engine handle each (`zarc pack --gpus N`)
+    Encoder(std::ostream &writer, const std::vector<int> &devices) : writer_(writer)
     {
+        if (devices.empty()) throw Error(ZARC_GPU_E_PARAM, "no device");
+        for (int d : devices) engines_.emplace_back(new Engine(d));
         writer_.write((const char *)FILE_MAGIC, sizeof FILE_MAGIC);
         offset_ = sizeof FILE_MAGIC;
     }
+    size_t devices() const { return engines_.size(); }
     // Encoder::set_zstd_parameter -- sticky for future frames (encode.rs:84-89); id = ZSTD_cParameter value
-    void set_zstd_parameter(int id, int value) { engine_.check(zarc_gpu_set_parameter(engine_.get(), id, value)); }
+    void set_zstd_parameter(int id, int value) { for (auto &e : engines_) e->check(zarc_gpu_set_parameter(e->get(), id, value)); }
     // Encoder::enable_compression (encode.rs:95-97)
-    void enable_compression(bool compress) { zarc_gpu_enable_compression(engine_.get(), compress ? 1 : 0); }
+    void enable_compression(bool compress) { for (auto &e : engines_) zarc_gpu_enable_compression(e->get(), compress ? 1 : 0); }
 
     // Encoder::add_data_frame for one entry (content_frame.rs:20)
     Digest add_data_frame(const uint8_t *content, size_t len)
@@ -107,16 +146,41 @@ class Encoder {
     {
         std::vector<Digest> digests(n);
         if (n == 0) return digests;
-        // 1. one fresh session per frame (reset(SessionOnly), content_frame.rs:37-39) == one independent frame each
-        std::vector<size_t> doff(n), dlen(n);
-        size_t cap = 0;
-        for (size_t k = 0; k < n; k++) cap += zarc_gpu_bound(len[k]);
-        std::vector<uint8_t> buffer(cap);
-        std::vector<int> status(n);
-        engine_.check(zarc_gpu_pack_batch(engine_.get(), n, content, len, buffer.data(), cap, doff.data(), dlen.data(), (uint8_t(*)[32])digests.data(),
-                                          status.data()));
-        // 2. append in call order; first occurrence wins -- against frames already written and inside this batch -- later
-        //    duplicates write nothing; offset/length bookkeeping as content_frame.rs:22,45-57
+        // 1. one fresh session per frame (reset(SessionOnly), content_frame.rs:37-39) == one independent frame each.  The batch
+        //    is dealt to the devices; every device packs its share into its own buffer, concurrently, with no exchange.
+        const size_t g = engines_.size();
+        const auto share = shard_assign(len, n, g);
+        std::vector<std::vector<uint8_t>> buffers(g);
+        std::vector<size_t> dlen(n);
+        std::vector<const uint8_t *> where(n, nullptr); // frame k lives at where[k]
+        std::vector<int> status(n, ZARC_GPU_FRAME_OK);
+        std::vector<int> rc(g, ZARC_GPU_OK);
+        auto pack_share = [&](size_t d) {
+            const std::vector<size_t> &idx = share[d];
+            const size_t m = idx.size();
+            if (m == 0) return;
+            std::vector<const void *> src(m);
+            std::vector<size_t> l(m), off(m), out_len(m);
+            std::vector<Digest> dig(m);
+            std::vector<int> st(m);
+            size_t cap = 0;
+            for (size_t j = 0; j < m; j++) { src[j] = content[idx[j]]; l[j] = len[idx[j]]; cap += zarc_gpu_bound(l[j]); }
+            buffers[d].resize(cap);
+            rc[d] = zarc_gpu_pack_batch(engines_[d]->get(), m, src.data(), l.data(), buffers[d].data(), cap, off.data(), out_len.data(),
+                                        (uint8_t(*)[32])dig.data(), st.data());
+            if (rc[d] != ZARC_GPU_OK) return;
+            for (size_t j = 0; j < m; j++) { digests[idx[j]] = dig[j]; dlen[idx[j]] = out_len[j]; where[idx[j]] = buffers[d].data() + off[j]; status[idx[j]] = st[j]; }
+        };
+        if (g == 1) pack_share(0);
+        else {
+            std::vector<std::thread> th;
+            for (size_t d = 0; d < g; d++) th.emplace_back(pack_share, d);
+            for (auto &t : th) t.join();
+        }
+        for (size_t d = 0; d < g; d++) engines_[d]->check(rc[d]);
+        // 2. append in call order -- whichever device made the frame; first occurrence wins -- against frames already written and
+        //    inside this batch, across devices -- later duplicates write nothing; offsets are the running sum of the lengths of
+        //    what was written (content_frame.rs:22,45-57)
         for (size_t k = 0; k < n; k++) {
             if (status[k] != ZARC_GPU_FRAME_OK) throw Error(status[k], zarc_gpu_frame_status_name(status[k]));
             if (frames_.count(digests[k])) continue; // "frame already exists, skipping"
@@ -126,7 +190,7 @@ class Encoder {
             f.digest = digests[k];
             f.length = dlen[k];
             f.uncompressed = len[k];
-            writer_.write((const char *)buffer.data() + doff[k], (std::streamsize)dlen[k]);
+            writer_.write((const char *)where[k], (std::streamsize)dlen[k]);
             if (!writer_) throw Error(ZARC_GPU_E_DEVICE, "write failed");
             offset_ += dlen[k];
             frames_.emplace(f.digest, f);
@@ -141,7 +205,8 @@ class Encoder {
 
   protected: // ArchiveWriter (zarc_container.hpp) adds add_file_entry / finalise on top
     std::ostream &writer_;
-    Engine engine_;
+    std::vector<std::unique_ptr<Engine>> engines_; // one per device; engines_[0] also serves the directory frame / digest
+    Engine &engine0() { return *engines_[0]; }
     uint16_t edition_ = 1;
     std::map<Digest, Frame> frames_;
     std::vector<Digest> order_;
