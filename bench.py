@@ -60,14 +60,14 @@ def cpu_baseline(sample, size, first_index, level):
         probe[z.path] = r["pack_seconds"]
     zbest = min(zs, key=lambda z: probe[z.path])
     z15 = next((z for z in zs if z.version.startswith("1.5")), zbest)
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     one = harness.cpu_baseline(zbest.path, level, 1, sample, size, first_index)
     many = harness.cpu_baseline(zbest.path, level, cores, min(4 * sample, 4096), size, first_index) if cores > 1 else None
     ref = harness.cpu_baseline(z15.path, level, cores, min(sample, 256), size, first_index)  # ratio yardstick: the 1.5.x build
     out = {"value": one["bytes"] / one["pack_seconds"] / GIB, "unit": "GiB/s", "cores": 1, "kind": "port",
            "unpack_value": one["bytes"] / one["unpack_seconds"] / GIB,
            "sample": "%d x %d B corpus entries from index %d, level %d; C driver tests/support/cpu_baseline.c (one CCtx + session reset per "
-                     "entry, decompressStream in 131075/131072-byte steps, oracle BLAKE3 port on both sides); %s; %d host cores online"
+                     "entry, decompressStream in 131075/131072-byte steps, oracle BLAKE3 port on both sides); %s; %d host cores usable by this process"
                      % (sample, size, first_index, level, one["info"], cores),
            "ratio": one["bytes"] / one["compressed_bytes"]}
     if many:

@@ -88,7 +88,7 @@ enum {
 /* What the engine does with the libzstd ids (pack.rs:86-217 forwards them all):
  *   CompressionLevel  -131072..22 accepted.  Levels <= 8 run the level-3 finder (LDS tables of 2^13 entries on an 8-byte and a
  *                     5-byte hash, a 2^16-bucket far table in HBM, one-byte lazy evaluation from level 2 on); levels >= 9 run the
- *                     deep finder (2^14-entry LDS tables, 4-byte short hash, 4-way far tables on both hashes).
+ *                     deep finder (2^14-entry LDS tables, 4-byte short hash, 2-way far tables on both hashes).
  *   WindowLog         honoured for the frame header / the farthest offset (10..27; default 21, level >= 9: 22).
  *   MinMatch          4..7 honoured (3 is raised to 4); default 5, level >= 9: 4.
  *   HashLog, ChainLog, SearchLog, TargetLength, Strategy

@@ -915,7 +915,7 @@ void zge_default_params(zge_params *P, int level)
     P->far_log = 16; P->far_ways = 1; P->far_step_log = 4; P->far_res_log = 2; P->far_short = 0; P->far_back = 16;
     if (level >= 9) { /* the engine's deep finder (engine.hip: derive_params) */
         P->long_log = 14; P->short_log = 14; P->short_bytes = 4; P->min_match = 4; P->match_cost = 10; P->window_log = 22;
-        P->far_log = 16; P->far_ways = 4; P->far_step_log = 1; P->far_res_log = 0; P->far_short = 1; P->far_back = 8;
+        P->far_log = 16; P->far_ways = 2; P->far_step_log = 1; P->far_res_log = 0; P->far_short = 1; P->far_back = 8;
     }
 }
 

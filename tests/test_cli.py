@@ -30,6 +30,11 @@ def make_tree(base, corpus):
         os.utime(p, ns=(1_600_000_000_123_456_000, 1_650_000_000_654_321_000))
     os.symlink("../a.txt", src / "sub" / "link")
     os.chmod(src / "sub", 0o750)
+    try:                                                   # extended attribute (metadata/encode.rs:343-372); not every file system takes user.*
+        os.setxattr(src / "b.bin", "user.zarc.test", b"caf\xc3\xa9 \xff\x00bytes")
+        os.setxattr(src / "a.txt", "user.note", b"plain text")
+    except OSError:
+        pass
     return files
 
 
@@ -62,6 +67,13 @@ def run_cli(binary, tmp_path, corpus, oracle, libzstds, store=False):
     assert by_name["src/a.txt"][6][2] == ("tag", 0, "2022-04-15T05:20:00.654321+00:00")   # modified
     assert by_name["src/a.txt"][6][3] == ("tag", 0, "2020-09-13T12:26:40.123456+00:00")   # accessed
     assert by_name["src/a.txt"][4][0] == os.getuid() and by_name["src/a.txt"][5][0] == os.getgid()
+    try:                                                                          # xattrs: text when valid UTF-8, bytes otherwise (key 12)
+        want = {"user.note": "plain text"} if os.getxattr(tmp_path / "src" / "a.txt", "user.note") else None
+    except OSError:
+        want = None
+    if want:
+        assert by_name["src/a.txt"][12] == want
+        assert by_name["src/b.bin"][12] == {"user.zarc.test": b"caf\xc3\xa9 \xff\x00bytes"}
     total_raw = sum(f[4] for f in a["frames"])
     for z in libzstds:                                                            # `zstd --test` equivalent
         o, err = z.decompress(img, total_raw + len(a["directory"]))
@@ -74,6 +86,22 @@ def run_cli(binary, tmp_path, corpus, oracle, libzstds, store=False):
     assert out.stdout.decode().splitlines() == [n + ("/" if n in ("src", "src/sub", "src/sub/deep") else "@" if n.endswith("link") else "") for n in names]
     out = subprocess.run([binary, "list", str(arc), "--only-files", "--filter", r"\.txt$"], capture_output=True, timeout=600, check=True)
     assert out.stdout.decode().splitlines() == ["src/a.txt", "src/sub/c.txt"]
+
+    # --- global flags: -v counts up the level, --log-file writes JSON lines (args.rs:39-65, logs.rs:12-67) ---
+    out = subprocess.run([binary, "-vv", "list-files", str(arc)], capture_output=True, timeout=600, check=True)
+    assert b" INFO zarc: logging initialised" in out.stderr and len(out.stdout.decode().splitlines()) == len(names)
+    logdir = tmp_path / "logs"
+    logdir.mkdir(exist_ok=True)
+    env = dict(os.environ); env.pop("RUST_LOG", None)
+    out = subprocess.run([binary, "--log-file", str(logdir), "pack", "--output", str(tmp_path / "logged.zarc"), "src"], cwd=tmp_path, capture_output=True,
+                         timeout=900, check=True, env=env)
+    logs = list(logdir.glob("zarc.*.log"))
+    assert len(logs) >= 1 and re.fullmatch(r"zarc\.\d{4}-\d\d-\d\dT\d\d-\d\d-\d\dZ\.log", logs[0].name)
+    import json
+    lines = [json.loads(l) for l in logs[0].read_text().splitlines()]
+    assert lines[0]["fields"]["message"] == "logging initialised" and any(l["level"] == "DEBUG" for l in lines)   # --log-file alone means -vvv
+    for l in logs:
+        l.unlink()
 
     # --- unpack ---
     dest = tmp_path / ("dest-store" if store else "dest")

@@ -29,11 +29,16 @@ while time.time() < t_end:
         raw = corpus.entry(rnd.randrange(1 << 30), size, kind)
         if rnd.randrange(6) == 0 and size > 64:      # long runs / repeated halves: RLE blocks, overlapping matches, long matches
             raw = raw[:size // 3] + bytes([raw[0]]) * (size // 3) + raw[:size - 2 * (size // 3)]
+        if rnd.randrange(5) == 0 and ents and len(ents[-1]) > 1000:   # far repeats: a mutated copy of the previous entry behind other data (far tables)
+            prev = bytearray(ents[-1][:min(len(ents[-1]), 400000)])
+            for _ in range(rnd.randrange(0, 30)):
+                prev[rnd.randrange(len(prev))] = rnd.randrange(256)
+            raw = raw[:len(raw) // 2] + bytes(prev) + ents[-1][:rnd.randrange(0, 100000)]
         ents.append(raw)
     packed = eng.pack(ents)
     for raw, (frame, dig) in zip(ents, packed):
         assert dig == oracle.blake3(raw)
-        if len(raw) <= 700000:                        # the sequential model is slow: check the smaller ones bit for bit
+        if len(raw) <= (6 << 20):                     # bit for bit against the sequential model
             p = oracle.params(level=level, checksum=checksum)
             assert frame == oracle.zge_encode(raw, p), (level, checksum, len(raw))
         st, out, used = oracle.zstd_decode(frame, len(raw))

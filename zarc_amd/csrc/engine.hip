@@ -123,8 +123,8 @@ ZgeParams derive_params(const zarc_gpu_params &p)
     z.lit_cost = 5; z.match_cost = deep ? 10 : 12; z.rep_cost = 9;
     z.short_window_log = 30;
     // far tables in HBM (zge_match.hip).  Level 3: 2^16 buckets, one way on the 12-byte hash, 4 of 16 positions inserted, every 4th
-    // looked up; level >= 9: 2^16 buckets, four ways on both hashes, every 2nd position inserted, all looked up
-    z.far_log = 16; z.far_ways = deep ? 4 : 1; z.far_step_log = deep ? 1 : 4; z.far_res_log = deep ? 0 : 2; z.far_short = deep ? 1 : 0;
+    // looked up; level >= 9: 2^16 buckets, two ways on both hashes, every 2nd position inserted, all looked up
+    z.far_log = 16; z.far_ways = deep ? 2 : 1; z.far_step_log = deep ? 1 : 4; z.far_res_log = deep ? 0 : 2; z.far_short = deep ? 1 : 0;
     z.far_back = deep ? 8 : 16;
     z.dbg = diag_env("ZARC_GPU_DBG", 0); // timing-only ablations (outputs invalid when set): diagnostic build only
     return z;
@@ -390,7 +390,7 @@ int zarc_gpu_pack_batch_device(zarc_gpu_t *h, size_t n, const void *d_src_base, 
     const ZgeParams P = derive_params(h->params);
     // the match finder has these compiled in (zge_match.hip: F_*)
     if (P.rep_back != 256 || P.back_cap != 8 || P.lazy_delta != 5 || P.min_rep != 3 || P.rep_search != 2 || P.seg_log != 21 || P.short_window_log < 30 ||
-        P.lit_cost != 5 || P.rep_cost != 9 || P.tag_bits != 10 || P.far_log != 16 || P.match_cost != (P.long_log == 14 ? 10 : 12) || P.far_ways != (P.long_log == 14 ? 4 : 1) ||
+        P.lit_cost != 5 || P.rep_cost != 9 || P.tag_bits != 10 || P.far_log != 16 || P.match_cost != (P.long_log == 14 ? 10 : 12) || P.far_ways != (P.long_log == 14 ? 2 : 1) ||
         P.far_step_log != (P.long_log == 14 ? 1 : 4) || P.far_res_log != (P.long_log == 14 ? 0 : 2) || (P.far_short != 0) != (P.long_log == 14) ||
         P.far_back != (P.long_log == 14 ? 8 : 16)) { set_error(h, "internal: encoder parameters differ from the compiled-in ones"); return ZARC_GPU_E_PARAM; }
     uint64_t need = 0;

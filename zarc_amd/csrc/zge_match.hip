@@ -390,7 +390,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
                 for (int u = 0; u < FNEXT_ROWS; u++) {
                     const uint32_t idxn = FAR_COMPACT ? (uint32_t)wave * 128u + ((uint32_t)lane << FAR_RES_LOG) : ZGE_IDX(u);
                     const uint32_t pn = ntile + idxn;
-                    const bool mine = !FAR_COMPACT || (uint32_t)lane < (128u >> FAR_RES_LOG);
+                    const bool mine = (!FAR_COMPACT || (uint32_t)lane < (128u >> FAR_RES_LOG)) && !((dbg & 16384) && wave < 2) && !(dbg & 32768);
                     if (mine && pn < far_end && !(pn & far_rmask) && !(dbg & 2048)) {
                         const uint64_t v = zd::load_u64(tbn + (uint32_t)(pn + wofs_n));
                         const uint32_t hf = hash_far32(v, zd::load_u32(tbn + (uint32_t)(pn + 8 + wofs_n))) >> far_shift, hg = hash_short32(v, SHORT_BYTES) >> far_shift;
@@ -836,5 +836,5 @@ __global__ void __launch_bounds__(512, 2) zarc_zge_match_deep(ZgeParams P, const
                                                            uint32_t *__restrict__ far_scratch)
 {
     __shared__ MatchLds<14> L;
-    zge_match_body<14, 4, 10, 16, 4, true, 1, 0, 8, false>(L, P, src_base, src_off, src_len, order, n_frames, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
+    zge_match_body<14, 4, 10, 16, 2, true, 1, 0, 8, false>(L, P, src_base, src_off, src_len, order, n_frames, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
 }

@@ -6,10 +6,16 @@
 //               -> add_data_frame, entry -> add_file_entry, finalise, prints "digest: <base64>"
 //   unpack      INPUT [--filter REGEX]... [--verify DIGEST]        crates/zarc-cli/src/unpack.rs:18-138
 //   list-files  INPUT [--only-files] [--decorate] [--filter REGEX]...   crates/zarc-cli/src/list_files.rs:8-63
+//   global      -v... (warn / info / debug / trace), --log-file [PATH] (JSON lines; a directory gets zarc.<UTC time>.log), $RUST_LOG
+//               takes precedence -- crates/zarc-cli/src/args.rs:39-65, logs.rs:12-67
 // What differs on purpose: file contents are gathered into batches of about 1 GiB before they go to the engine (frames
 // and directory order do not change: frames in walk order, first occurrence of a content wins); the walk is sorted by
-// name (WalkDir yields directory order); metadata carried: mode, owner/group (id + name), modified / accessed times,
-// directories, symlinks with their target as a full path (metadata/encode.rs:28-75) -- no chattr flags or xattrs.
+// name (WalkDir yields directory order).  Metadata carried (metadata/encode.rs:28-372): mode, owner / group (id + name through a
+// uid / gid cache, owner_cache.rs:14-77), modified / accessed times, directories, symlinks with their target as a full path,
+// chattr flags as `linux.*` attributes, extended attributes.
+// I/O pipeline: pack reads the files of batch k+1 on a reader thread while the engine packs batch k (whose
+// frames the engine's own staging moves over PCIe in chunks); unpack writes the files of batch k on a writer thread while
+// batch k+1 is decoded.  The reference does all of it on one thread, file by file (pack.rs:244-265, unpack.rs:94-124).
 #include "zarc_container.hpp"
 #include <dirent.h>
 #include <fcntl.h>
@@ -18,11 +24,115 @@
 #include <iostream>
 #include <pwd.h>
 #include <regex>
+#include <condition_variable>
+#include <deque>
+#include <linux/fs.h>
+#include <mutex>
+#include <sys/ioctl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/xattr.h>
+#include <thread>
 #include <unistd.h>
+#include <unordered_map>
 
 namespace {
+
+// ---------------------------------------------------------------- diagnostics (logs.rs:12-67) ----------------
+// Levels as tracing's: 1 warn, 2 info, 3 debug, 4 trace.  Plain lines on stderr, or JSON lines in --log-file.
+struct Log {
+    int level = 0;
+    FILE *file = nullptr;
+    std::mutex mu;
+    void init(int verbosity, const std::string &log_file, bool have_log_file)
+    {
+        if (const char *e = getenv("RUST_LOG")) { // "If $RUST_LOG is set, this flag is ignored" (args.rs:49)
+            const std::string v = e;
+            level = v.find("trace") != std::string::npos ? 4 : v.find("debug") != std::string::npos ? 3 : v.find("info") != std::string::npos ? 2 :
+                    v.find("warn") != std::string::npos ? 1 : (v.find("error") != std::string::npos ? 1 : 2);
+            return;
+        }
+        if (have_log_file && verbosity == 0) verbosity = 3; // "If a log level was not already specified, this will set it to -vvv"
+        if (verbosity <= 0) return;
+        level = verbosity > 4 ? 4 : verbosity;
+        if (have_log_file) {
+            std::string path = log_file.empty() ? "." : log_file;
+            struct stat st;
+            if (stat(path.c_str(), &st) == 0 && S_ISDIR(st.st_mode)) {
+                char name[64];
+                const time_t now = time(nullptr);
+                std::tm tm{};
+                gmtime_r(&now, &tm);
+                std::strftime(name, sizeof name, "zarc.%Y-%m-%dT%H-%M-%SZ.log", &tm);
+                path += "/" + std::string(name);
+            }
+            file = std::fopen(path.c_str(), "w");
+            if (!file) std::fprintf(stderr, "Failed to initialise logging, continuing with none\n%s: %s\n", path.c_str(), std::strerror(errno));
+        }
+        event(2, "logging initialised", "");
+    }
+    void event(int lvl, const char *msg, const std::string &fields) // fields: pre-formatted `key=value ...`
+    {
+        if (lvl > level || level == 0) return;
+        static const char *names[] = {"", "WARN", "INFO", "DEBUG", "TRACE"};
+        timespec ts;
+        clock_gettime(CLOCK_REALTIME, &ts);
+        std::tm tm{};
+        gmtime_r(&ts.tv_sec, &tm);
+        char t[40];
+        std::strftime(t, sizeof t, "%Y-%m-%dT%H:%M:%S", &tm);
+        std::lock_guard<std::mutex> g(mu);
+        if (file) {
+            std::string esc;
+            for (char c : fields) { if (c == '"' || c == '\\') esc += '\\'; esc += c; }
+            std::fprintf(file, "{\"timestamp\":\"%s.%06ldZ\",\"level\":\"%s\",\"fields\":{\"message\":\"%s\",\"detail\":\"%s\"},\"target\":\"zarc\"}\n", t, ts.tv_nsec / 1000,
+                         names[lvl], msg, esc.c_str());
+            std::fflush(file);
+        } else std::fprintf(stderr, "%s.%06ldZ %5s zarc: %s %s\n", t, ts.tv_nsec / 1000, names[lvl], msg, fields.c_str());
+    }
+    ~Log() { if (file) std::fclose(file); }
+};
+Log g_log;
+#define LOGF(lvl, msg, ...) do { if ((lvl) <= g_log.level) { char b_[600]; std::snprintf(b_, sizeof b_, __VA_ARGS__); g_log.event((lvl), (msg), b_); } } while (0)
+
+// uid / gid <-> name lookups are slow (over 90 % of a pack before the reference cached them, owner_cache.rs:3-6): cache both ways
+struct OwnerCache {
+    std::unordered_map<uint32_t, std::optional<std::string>> users, groups;
+    std::unordered_map<std::string, std::optional<uint32_t>> uid_by_name, gid_by_name;
+    std::optional<std::string> user_from_uid(uint32_t uid)
+    {
+        auto it = users.find(uid);
+        if (it != users.end()) return it->second;
+        std::optional<std::string> n;
+        if (const passwd *pw = getpwuid((uid_t)uid)) { n = pw->pw_name; uid_by_name[*n] = uid; }
+        return users[uid] = n;
+    }
+    std::optional<std::string> group_from_gid(uint32_t gid)
+    {
+        auto it = groups.find(gid);
+        if (it != groups.end()) return it->second;
+        std::optional<std::string> n;
+        if (const group *gr = getgrgid((gid_t)gid)) { n = gr->gr_name; gid_by_name[*n] = gid; }
+        return groups[gid] = n;
+    }
+    std::optional<uint32_t> uid_from_name(const std::string &name)
+    {
+        auto it = uid_by_name.find(name);
+        if (it != uid_by_name.end()) return it->second;
+        std::optional<uint32_t> v;
+        if (const passwd *pw = getpwnam(name.c_str())) v = (uint32_t)pw->pw_uid;
+        return uid_by_name[name] = v;
+    }
+    std::optional<uint32_t> gid_from_name(const std::string &name)
+    {
+        auto it = gid_by_name.find(name);
+        if (it != gid_by_name.end()) return it->second;
+        std::optional<uint32_t> v;
+        if (const group *gr = getgrnam(name.c_str())) v = (uint32_t)gr->gr_gid;
+        return gid_by_name[name] = v;
+    }
+};
+OwnerCache g_owners;
 
 std::string base64(const uint8_t *p, size_t n) // base64ct::Base64: standard alphabet, padded
 {
@@ -69,7 +179,8 @@ bool safe_name(const std::vector<std::string> &name)
 
 int usage()
 {
-    std::fprintf(stderr, "usage: zarc pack --output PATH [--level N] [--zstd PARAM=VALUE]... [--store] [-L] [--gpus N] PATH...\n"
+    std::fprintf(stderr, "usage: zarc [-v...] [--log-file [PATH]] <pack|unpack|list-files> ...\n"
+                         "       zarc pack --output PATH [--level N] [--zstd PARAM=VALUE]... [--store] [-L] [--gpus N] PATH...\n"
                          "       zarc unpack INPUT [--filter REGEX]... [--verify DIGEST]\n"
                          "       zarc list-files INPUT [--only-files] [--decorate] [--filter REGEX]...\n");
     return 2;
@@ -129,21 +240,74 @@ void walk(const std::string &path, bool follow, std::vector<Walked> &out) // Wal
     for (const auto &n : names) walk(path + (path.back() == '/' ? "" : "/") + n, follow, out);
 }
 
-zarc::File build_file_with_metadata(const Walked &w) // metadata/encode.rs:28-75
+// chattr flags as `linux.*` booleans plus the portable aliases (metadata/encode.rs:212-329)
+std::optional<zarc::File::AttrMap> file_attributes(const Walked &w)
+{
+    if (!S_ISREG(w.st.st_mode) && !S_ISDIR(w.st.st_mode)) return std::nullopt; // FS_IOC_GETFLAGS needs an open regular file or directory
+    const int fd = open(w.path.c_str(), O_RDONLY | O_NONBLOCK | O_NOFOLLOW | O_CLOEXEC);
+    if (fd < 0) return std::nullopt;
+    int flags = 0;
+    const int rc = ioctl(fd, FS_IOC_GETFLAGS, &flags);
+    close(fd);
+    if (rc != 0) return std::nullopt; // file systems without flags (tmpfs, overlay ...)
+    static const struct { const char *name; int bit; } names[] = {
+        {"append-only", FS_APPEND_FL}, {"casefold", 0x40000000 /* FS_CASEFOLD_FL */}, {"compressed", FS_COMPR_FL}, {"delete-undo", FS_UNRM_FL},
+        {"delete-zero", FS_SECRM_FL}, {"dir-sync", FS_DIRSYNC_FL}, {"encrypted", 0x00000800 /* FS_ENCRYPT_FL */}, {"file-sync", FS_SYNC_FL},
+        {"immutable", FS_IMMUTABLE_FL}, {"no-atime", FS_NOATIME_FL}, {"no-backup", FS_NODUMP_FL}, {"no-cow", 0x00800000 /* FS_NOCOW_FL */},
+        {"not-compressed", FS_NOCOMP_FL}};
+    zarc::File::AttrMap m;
+    zarc::File::Attr yes;
+    yes.is_bool = true; yes.b = true;
+    for (const auto &n : names) if (flags & n.bit) m[std::string("linux.") + n.name] = yes;
+    if (m.empty()) return std::nullopt;
+    if (m.count("linux.append-only")) m["append-only"] = yes;
+    if (m.count("linux.immutable")) m["immutable"] = yes;
+    if (m.count("linux.compressed")) m["compressed"] = yes;
+    if (!(w.st.st_mode & 0222)) m["read-only"] = yes;
+    return m;
+}
+
+// extended attributes, names that are valid UTF-8 only (metadata/encode.rs:343-372)
+std::optional<zarc::File::AttrMap> file_extended_attributes(const Walked &w)
+{
+    std::vector<char> names(1024);
+    ssize_t n;
+    while ((n = llistxattr(w.path.c_str(), names.data(), names.size())) < 0 && errno == ERANGE) names.resize(names.size() * 4);
+    if (n < 0) return std::nullopt; // unsupported here
+    zarc::File::AttrMap m;
+    for (ssize_t i = 0; i < n;) {
+        const std::string name(names.data() + i);
+        i += (ssize_t)name.size() + 1;
+        if (!zarc::valid_utf8(name)) { LOGF(1, "not storing non-Unicode xattr", "path=%s", w.path.c_str()); continue; }
+        std::vector<char> val(256);
+        ssize_t v;
+        while ((v = lgetxattr(w.path.c_str(), name.c_str(), val.data(), val.size())) < 0 && errno == ERANGE) val.resize(val.size() * 4);
+        if (v < 0) continue;
+        zarc::File::Attr a;
+        a.s.assign(val.data(), (size_t)v);
+        m[name] = a;
+    }
+    return m;
+}
+
+zarc::File build_file_with_metadata(const Walked &w) // metadata/encode.rs:28-85
 {
     zarc::File f;
     f.name = normal_components(w.path);
     f.mode = (uint32_t)w.st.st_mode;
     zarc::File::Owner u, g;
     u.id = (uint64_t)w.st.st_uid;
-    if (const passwd *pw = getpwuid(w.st.st_uid)) u.name = pw->pw_name;
+    u.name = g_owners.user_from_uid((uint32_t)w.st.st_uid);
     g.id = (uint64_t)w.st.st_gid;
-    if (const group *gr = getgrgid(w.st.st_gid)) g.name = gr->gr_name;
+    g.name = g_owners.group_from_gid((uint32_t)w.st.st_gid);
     f.user = u; f.group = g;
     f.modified = zarc::Timestamp{(int64_t)w.st.st_mtim.tv_sec, (uint32_t)w.st.st_mtim.tv_nsec};
     f.accessed = zarc::Timestamp{(int64_t)w.st.st_atim.tv_sec, (uint32_t)w.st.st_atim.tv_nsec};
     if (S_ISDIR(w.st.st_mode)) f.special_kind = 1;
     else if (w.is_link && S_ISLNK(w.st.st_mode)) { f.special_kind = 10; f.link_target = w.target; }
+    f.attributes = file_attributes(w);
+    f.extended_attributes = file_extended_attributes(w);
+    LOGF(4, "build_file_with_metadata", "path=%s mode=%o", w.path.c_str(), (unsigned)w.st.st_mode);
     return f;
 }
 
@@ -177,36 +341,76 @@ int cmd_pack(const std::vector<std::string> &a)
 
     std::vector<Walked> entries;
     for (const auto &p : paths) walk(p, follow, entries);
-    // contents go to the engine in batches; entries are added in walk order once their digest is known
+    LOGF(2, "walked", "entries=%zu devices=%d", entries.size(), gpus);
+    // Contents go to the engine in batches of about 1 GiB.  A reader thread fills batch k+1 (file reads) while this thread has the
+    // engine pack batch k and appends its frames to the archive; entries are added in walk order once their digest is known.
+    struct Batch { size_t first = 0, last = 0; std::vector<std::vector<uint8_t>> contents; std::vector<size_t> owner; std::string error; };
     const size_t BATCH = (size_t)1 << 30;
-    size_t first = 0;
-    while (first < entries.size()) {
-        size_t last = first, bytes = 0;
-        std::vector<std::vector<uint8_t>> contents;
-        std::vector<size_t> owner;
-        while (last < entries.size() && (bytes < BATCH || last == first)) {
-            const Walked &w = entries[last];
-            if (S_ISREG(w.st.st_mode)) {
-                std::ifstream in(w.path, std::ios::binary);
-                if (!in) { std::fprintf(stderr, "Error: %s: %s\n", w.path.c_str(), std::strerror(errno)); return 1; }
-                contents.emplace_back((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
-                owner.push_back(last);
-                bytes += contents.back().size();
+    std::deque<Batch> ready;
+    std::mutex mu;
+    std::condition_variable cv;
+    bool reader_done = false;
+    std::thread reader([&] {
+        size_t first = 0;
+        while (first < entries.size()) {
+            Batch b;
+            b.first = first;
+            size_t last = first, bytes = 0;
+            while (last < entries.size() && (bytes < BATCH || last == first) && b.error.empty()) {
+                const Walked &w = entries[last];
+                if (S_ISREG(w.st.st_mode)) {
+                    std::ifstream in(w.path, std::ios::binary);
+                    if (!in) { b.error = w.path + ": " + std::strerror(errno); break; }
+                    b.contents.emplace_back((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+                    b.owner.push_back(last);
+                    bytes += b.contents.back().size();
+                }
+                last++;
             }
-            last++;
+            b.last = last;
+            const bool failed = !b.error.empty();
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return ready.size() < 2; }); // at most two batches of file contents in memory
+                ready.push_back(std::move(b));
+            }
+            cv.notify_all();
+            if (failed) break;
+            first = last;
         }
+        { std::lock_guard<std::mutex> lk(mu); reader_done = true; }
+        cv.notify_all();
+    });
+    std::string failure;
+    for (;;) {
+        Batch b;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return !ready.empty() || reader_done; });
+            if (ready.empty()) break;
+            b = std::move(ready.front());
+            ready.pop_front();
+        }
+        cv.notify_all();
+        if (!b.error.empty()) { failure = b.error; break; }
         std::vector<const void *> ptr;
         std::vector<size_t> len;
-        for (auto &c : contents) { ptr.push_back(c.data()); len.push_back(c.size()); }
+        for (auto &c : b.contents) { ptr.push_back(c.data()); len.push_back(c.size()); }
+        LOGF(3, "add_data_frames", "entries=%zu files=%zu", b.last - b.first, ptr.size());
         const std::vector<zarc::Digest> dig = enc.add_data_frames(ptr.data(), len.data(), ptr.size());
         size_t k = 0;
-        for (size_t i = first; i < last; i++) {
+        for (size_t i = b.first; i < b.last; i++) {
             zarc::File f = build_file_with_metadata(entries[i]);
-            if (k < owner.size() && owner[k] == i) f.digest = dig[k++];
+            if (k < b.owner.size() && b.owner[k] == i) f.digest = dig[k++];
             enc.add_file_entry(f);
         }
-        first = last;
     }
+    if (!failure.empty()) { // let the reader finish before leaving
+        { std::unique_lock<std::mutex> lk(mu); ready.clear(); }
+        cv.notify_all();
+    }
+    reader.join();
+    if (!failure.empty()) { std::fprintf(stderr, "Error: %s\n", failure.c_str()); return 1; }
     timespec now;
     clock_gettime(CLOCK_REALTIME, &now);
     const zarc::Digest digest = enc.finalise(zarc::Timestamp{(int64_t)now.tv_sec, (uint32_t)now.tv_nsec});
@@ -244,8 +448,9 @@ void mkdirs(const std::string &path, mode_t mode)
 void set_metadata(const zarc::File &f, int fd) // unpack.rs:126-138: ownership, permissions, timestamps
 {
     uid_t uid = (uid_t)-1; gid_t gid = (gid_t)-1;
-    if (f.user) { if (f.user->name) { if (const passwd *pw = getpwnam(f.user->name->c_str())) uid = pw->pw_uid; else if (f.user->id) uid = (uid_t)*f.user->id; } else if (f.user->id) uid = (uid_t)*f.user->id; }
-    if (f.group) { if (f.group->name) { if (const group *gr = getgrnam(f.group->name->c_str())) gid = gr->gr_gid; else if (f.group->id) gid = (gid_t)*f.group->id; } else if (f.group->id) gid = (gid_t)*f.group->id; }
+    // by name first, then by id (directory/posix_owner.rs:25-110), through the cache
+    if (f.user) { std::optional<uint32_t> v; if (f.user->name) v = g_owners.uid_from_name(*f.user->name); if (!v && f.user->id) v = (uint32_t)*f.user->id; if (v) uid = (uid_t)*v; }
+    if (f.group) { std::optional<uint32_t> v; if (f.group->name) v = g_owners.gid_from_name(*f.group->name); if (!v && f.group->id) v = (uint32_t)*f.group->id; if (v) gid = (gid_t)*v; }
     if ((uid != (uid_t)-1 || gid != (gid_t)-1) && fchown(fd, uid, gid) != 0) { /* needs privileges; an unprivileged unpack keeps the caller's ids */ }
     if (f.mode) (void)fchmod(fd, (mode_t)(*f.mode & 07777));
     if (f.modified || f.accessed) {
@@ -277,27 +482,68 @@ int cmd_unpack(const std::vector<std::string> &a)
     const size_t BATCH = (size_t)1 << 30;
     std::vector<size_t> batch;
     size_t batch_bytes = 0;
+    // A writer thread creates and fills the files of batch k while this thread has the engine decode batch k+1.
+    struct Done { std::vector<size_t> idx; std::vector<zarc::FrameReader::Result> res; };
+    std::deque<Done> todo;
+    std::mutex mu;
+    std::condition_variable cv;
+    bool no_more = false;
+    std::string failure;
+    std::thread writer([&] {
+        for (;;) {
+            Done d;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return !todo.empty() || no_more; });
+                if (todo.empty()) return;
+                d = std::move(todo.front());
+                todo.pop_front();
+            }
+            cv.notify_all();
+            for (size_t k = 0; k < d.idx.size(); k++) {
+                const zarc::File &f = rd.files()[d.idx[k]];
+                const std::string path = to_path(f.name);
+                std::string err;
+                if (d.res[k].status != ZARC_GPU_FRAME_OK && d.res[k].status != ZARC_GPU_FRAME_DIGEST) err = path + ": " + zarc_gpu_frame_status_name(d.res[k].status);
+                int fd = -1;
+                if (err.empty()) {
+                    const size_t slash = path.rfind('/');
+                    if (slash != std::string::npos) mkdirs(path.substr(0, slash), 0777); // parent, in case its entry was not in the zarc
+                    fd = open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC | O_NOFOLLOW, 0666);
+                    if (fd < 0) err = path + ": " + std::strerror(errno);
+                }
+                size_t off = 0;
+                while (err.empty() && off < d.res[k].data.size()) {
+                    const ssize_t w = write(fd, d.res[k].data.data() + off, d.res[k].data.size() - off);
+                    if (w <= 0) err = path + ": write failed"; else off += (size_t)w;
+                }
+                if (!err.empty()) { if (fd >= 0) close(fd); std::lock_guard<std::mutex> lk(mu); if (failure.empty()) failure = err; continue; }
+                if (!d.res[k].verify.value_or(false)) std::fprintf(stderr, "ERROR frame verification failed! path=%s\n", path.c_str()); // unpack.rs:118-120
+                set_metadata(f, fd);
+                close(fd);
+                LOGF(3, "extract_file", "path=%s bytes=%zu", path.c_str(), d.res[k].data.size());
+                std::lock_guard<std::mutex> lk(mu);
+                unpacked++;
+            }
+        }
+    });
     auto flush = [&]() {
         if (batch.empty()) return;
-        auto res = rd.read_files(batch);
-        for (size_t k = 0; k < batch.size(); k++) {
-            const zarc::File &f = rd.files()[batch[k]];
-            const std::string path = to_path(f.name);
-            if (res[k].status != ZARC_GPU_FRAME_OK && res[k].status != ZARC_GPU_FRAME_DIGEST)
-                throw zarc::Error(res[k].status, path + ": " + zarc_gpu_frame_status_name(res[k].status));
-            const size_t slash = path.rfind('/');
-            if (slash != std::string::npos) mkdirs(path.substr(0, slash), 0777); // parent, in case its entry was not in the zarc
-            const int fd = open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC | O_NOFOLLOW, 0666);
-            if (fd < 0) throw zarc::Error(ZARC_GPU_E_PARAM, path + ": " + std::strerror(errno));
-            size_t off = 0;
-            while (off < res[k].data.size()) { const ssize_t w = write(fd, res[k].data.data() + off, res[k].data.size() - off); if (w <= 0) { close(fd); throw zarc::Error(ZARC_GPU_E_PARAM, path + ": write failed"); } off += (size_t)w; }
-            if (!res[k].verify.value_or(false)) std::fprintf(stderr, "ERROR frame verification failed! path=%s\n", path.c_str()); // unpack.rs:118-120
-            set_metadata(f, fd);
-            close(fd);
-            unpacked++;
+        Done d;
+        d.idx = batch;
+        d.res = rd.read_files(batch);
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return todo.size() < 2; }); // at most two decoded batches in memory
+            todo.push_back(std::move(d));
         }
+        cv.notify_all();
         batch.clear();
         batch_bytes = 0;
+    };
+    auto drain = [&]() { // directories are made by this thread: every file queued before must be on disk first
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return todo.empty(); });
     };
     for (size_t i = 0; i < rd.files().size(); i++) {
         const zarc::File &f = rd.files()[i];
@@ -305,7 +551,6 @@ int cmd_unpack(const std::vector<std::string> &a)
         if (!passes(filters, name)) continue;
         if (!safe_name(f.name)) { std::fprintf(stderr, "WARN unsafe pathname skipped: %s\n", name.c_str()); continue; }
         if (f.is_dir()) {
-            flush();
             mkdirs(name, f.mode ? (mode_t)(*f.mode & 07777) : 0777);
             const int fd = open(name.c_str(), O_RDONLY | O_DIRECTORY);
             if (fd >= 0) { set_metadata(f, fd); close(fd); }
@@ -317,7 +562,12 @@ int cmd_unpack(const std::vector<std::string> &a)
             if (batch_bytes >= BATCH) flush();
         }
     }
-    flush();
+    try { flush(); } catch (...) { { std::lock_guard<std::mutex> lk(mu); no_more = true; } cv.notify_all(); writer.join(); throw; }
+    (void)drain;
+    { std::lock_guard<std::mutex> lk(mu); no_more = true; }
+    cv.notify_all();
+    writer.join();
+    if (!failure.empty()) throw zarc::Error(ZARC_GPU_E_PARAM, failure);
     std::fprintf(stderr, "unpacked %llu files\n", unpacked);
     return 0;
 }
@@ -350,9 +600,25 @@ int cmd_list_files(const std::vector<std::string> &a)
 
 int main(int argc, char **argv)
 {
-    if (argc < 2) return usage();
-    const std::string verb = argv[1];
-    std::vector<std::string> rest(argv + 2, argv + argc);
+    // global flags come before the subcommand (args.rs:39-65): -v / -vv / --verbose (counted), --log-file [PATH]
+    int verbosity = 0, i = 1;
+    bool have_log_file = false;
+    std::string log_file;
+    for (; i < argc; i++) {
+        const std::string a = argv[i];
+        if (a == "--verbose") verbosity++;
+        else if (a.size() >= 2 && a[0] == '-' && a[1] == 'v' && a.find_first_not_of('v', 1) == std::string::npos) verbosity += (int)a.size() - 1;
+        else if (a.rfind("--log-file=", 0) == 0) { have_log_file = true; log_file = a.substr(11); }
+        else if (a == "--log-file") {
+            have_log_file = true;
+            // num_args = 0..=1: a following word that is not a subcommand is the path
+            if (i + 1 < argc) { const std::string n = argv[i + 1]; const bool verb = !n.empty() && (std::string("pack").rfind(n, 0) == 0 || std::string("unpack").rfind(n, 0) == 0 || std::string("list-files").rfind(n, 0) == 0); if (!verb && n[0] != '-') log_file = argv[++i]; }
+        } else break;
+    }
+    if (i >= argc) return usage();
+    g_log.init(verbosity, log_file, have_log_file);
+    const std::string verb = argv[i];
+    std::vector<std::string> rest(argv + i + 1, argv + argc);
     try {
         // `infer_subcommands = true` (args.rs:23): unambiguous prefixes select the subcommand
         if (!verb.empty() && std::string("pack").rfind(verb, 0) == 0) return cmd_pack(rest);

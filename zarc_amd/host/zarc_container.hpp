@@ -41,6 +41,7 @@ class CborWriter {
     void map(uint64_t n) { head(5, n); }
     void tag(uint64_t t) { head(6, t); }
     void null() { buf.push_back(0xF6); }
+    void boolean(bool b) { buf.push_back(b ? 0xF5 : 0xF4); }
 };
 
 class CborReader {
@@ -49,6 +50,8 @@ class CborReader {
     bool done() const { return p_ >= end_; }
     int major() const { need(1); return *p_ >> 5; }
     bool is_null() const { need(1); return *p_ == 0xF6; }
+    bool is_bool() const { need(1); return *p_ == 0xF4 || *p_ == 0xF5; }
+    bool boolean() { need(1); return *p_++ == 0xF5; }
     void skip_null() { need(1); p_++; }
     uint64_t head(int want_major)
     {
@@ -150,6 +153,10 @@ struct File { // directory/file.rs:16-62 (fields this host mirror carries; the r
     std::optional<std::string> link_target; // LinkTarget::FullPath (specials.rs:158-186); text when valid UTF-8, bytes otherwise
     struct Owner { std::optional<uint64_t> id; std::optional<std::string> name; }; // PosixOwner (posix_owner.rs:17-21)
     std::optional<Owner> user, group;
+    // AttributeValue (strings.rs:154-212): a boolean, or a string that is CBOR text when valid UTF-8 and bytes otherwise
+    struct Attr { bool is_bool = false; bool b = false; std::string s; bool operator==(const Attr &o) const { return is_bool == o.is_bool && b == o.b && s == o.s; } };
+    typedef std::map<std::string, Attr> AttrMap; // the reference keeps a HashMap (any order on disk); a sorted map is reproducible
+    std::optional<AttrMap> user_metadata, attributes, extended_attributes; // file.rs:49-61, keys 10 / 11 / 12
     bool is_normal() const { return digest.has_value() && !special_kind.has_value(); }
     bool is_dir() const { return special_kind.has_value() && *special_kind == 1; }
     bool is_symlink() const { return special_kind.has_value() && *special_kind >= 10 && *special_kind <= 13; }
@@ -187,7 +194,8 @@ inline void encode_edition(CborWriter &w, const Edition &e) // {0: number, 1: wr
 inline void encode_file(CborWriter &w, const File &f)
 {
     const bool ts = f.created || f.modified || f.accessed;
-    w.map(2 + (f.digest ? 1 : 0) + (f.mode ? 1 : 0) + (f.user ? 1 : 0) + (f.group ? 1 : 0) + (ts ? 1 : 0) + (f.special_kind ? 1 : 0));
+    w.map(2 + (f.digest ? 1 : 0) + (f.mode ? 1 : 0) + (f.user ? 1 : 0) + (f.group ? 1 : 0) + (ts ? 1 : 0) + (f.special_kind ? 1 : 0) +
+          (f.user_metadata ? 1 : 0) + (f.attributes ? 1 : 0) + (f.extended_attributes ? 1 : 0));
     w.uint(0); w.uint(f.edition);
     w.uint(1); w.array(f.name.size());
     for (const auto &c : f.name) { if (valid_utf8(c)) w.text(c); else w.bytes((const uint8_t *)c.data(), c.size()); }
@@ -213,6 +221,18 @@ inline void encode_file(CborWriter &w, const File &f)
         w.array(f.link_target ? 2 : 1);
         w.uint(*f.special_kind);
         if (f.link_target) { if (valid_utf8(*f.link_target)) w.text(*f.link_target); else w.bytes((const uint8_t *)f.link_target->data(), f.link_target->size()); }
+    }
+    for (int which = 0; which < 3; which++) { // attribute maps: text key -> bool | text | bytes
+        const auto &m = which == 0 ? f.user_metadata : (which == 1 ? f.attributes : f.extended_attributes);
+        if (!m) continue;
+        w.uint(10 + (uint64_t)which);
+        w.map(m->size());
+        for (const auto &kv : *m) {
+            w.text(kv.first);
+            if (kv.second.is_bool) w.boolean(kv.second.b);
+            else if (valid_utf8(kv.second.s)) w.text(kv.second.s);
+            else w.bytes((const uint8_t *)kv.second.s.data(), kv.second.s.size());
+        }
     }
 }
 
@@ -475,6 +495,18 @@ class ArchiveReader {
                     else if (j == 1 && r.major() == 2) { auto b = r.bytes(); f.link_target = std::string((const char *)b.data(), b.size()); }
                     else r.skip(); // component-array targets are what the reference cannot read back either (specials.rs:193-196)
                 }
+            } else if (k >= 10 && k <= 12) {
+                File::AttrMap m;
+                const uint64_t c = r.head(5);
+                for (uint64_t j = 0; j < c; j++) {
+                    const std::string key = r.text();
+                    File::Attr a;
+                    if (r.is_bool()) { a.is_bool = true; a.b = r.boolean(); }
+                    else if (r.major() == 3) a.s = r.text();
+                    else { auto b = r.bytes(); a.s.assign((const char *)b.data(), b.size()); }
+                    m[key] = a;
+                }
+                (k == 10 ? f.user_metadata : (k == 11 ? f.attributes : f.extended_attributes)) = m;
             } else r.skip();
         }
         return f;
