@@ -34,6 +34,7 @@ typedef struct {
     int far_res_log;  /* ... and positions with p mod 2^far_res_log == 0 are looked up: of 2^far_res_log inserted neighbours
                          exactly one lands on a looked-up position, whatever the offset of the repeat                          */
     int far_short;    /* 1 = a second far table keyed by the short hash */
+    int far_skip;     /* a far candidate is not compared once a candidate of this many bytes is in hand (0 = always compared)        */
     int far_back;     /* backward-extension cap of far candidates (they are found up to 2^far_step_log + 2^far_res_log - 2
                          positions into a repeat) */
 } zge_params;

@@ -806,6 +806,8 @@ static uint32_t matchfind_block(mf_ctx *c, size_t bs, size_t be, zge_seq *seq, u
                 uint32_t off = offs[k], len; int is_rep; int32_t sc;
                 if (off == 0 || off > p || off > c->window) continue;
                 is_rep = off == erep0 || off == erep1;
+                /* with 64 bytes in hand already, a far candidate is not looked at: comparing it would be the longest compare of the tile */
+                if (k >= 1 && k < ntab && P->far_skip && best_len >= (uint32_t)P->far_skip) continue;
                 len = match_len(src, p, p - off, cap);
                 if (len < (uint32_t)(is_rep ? P->min_rep : P->min_match)) continue;
                 sc = score_of(P, len, off, is_rep);
@@ -912,10 +914,10 @@ void zge_default_params(zge_params *P, int level)
     P->back_cap = 8; P->lazy = level >= 2 || level == 0 ? 1 : 0; P->lazy_delta = 5; /* engine.hip: derive_params */
     P->lit_cost = 5; P->match_cost = 12; P->rep_cost = 9;
     P->window_log = 21; P->short_window_log = 30;
-    P->far_log = 16; P->far_ways = 1; P->far_step_log = 4; P->far_res_log = 2; P->far_short = 0; P->far_back = 16;
+    P->far_log = 16; P->far_ways = 1; P->far_step_log = 5; P->far_res_log = 2; P->far_short = 0; P->far_skip = 64; P->far_back = 24;
     if (level >= 9) { /* the engine's deep finder (engine.hip: derive_params) */
         P->long_log = 14; P->short_log = 14; P->short_bytes = 4; P->min_match = 4; P->match_cost = 10; P->window_log = 22;
-        P->far_log = 16; P->far_ways = 2; P->far_step_log = 1; P->far_res_log = 0; P->far_short = 1; P->far_back = 8;
+        P->far_log = 16; P->far_ways = 2; P->far_step_log = 1; P->far_res_log = 0; P->far_short = 1; P->far_skip = 0; P->far_back = 8;
     }
 }
 

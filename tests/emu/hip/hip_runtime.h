@@ -86,6 +86,9 @@ static inline hipError_t hipMemset(void *d, int v, size_t n) { if (n) memset(d, 
 static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t = 0) { if (n) memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipStreamCreate(hipStream_t *s) { *s = 0; return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+enum { hipStreamDefault = 0 };
+static inline hipError_t hipDeviceGetStreamPriorityRange(int *least, int *greatest) { *least = 0; *greatest = 0; return hipSuccess; }
+static inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { *s = 0; return hipSuccess; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned = 0) { return hipSuccess; } // launches are synchronous here
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }

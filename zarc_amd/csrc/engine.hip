@@ -67,6 +67,8 @@ struct zarc_gpu {
     DevBuf d_slot_prefix, d_zblocks, d_nseq, d_fast, d_seqidx, d_seqs, d_ztables, d_litidx, d_lits; // decoder fast path (sequences decoded ahead)
     DevBuf d_queue; // frame queues of the persistent kernels (one u32 each)
     int num_cus = 1;
+    uint64_t blake3_total_chunks = 0;
+    hipEvent_t ev_b3[2] = {}; // digest kernels on the side stream (pack)
     // staging arenas for the host-pointer entry points
     DevBuf d_arena_in, d_arena_out;
     hipEvent_t ev[16] = {};
@@ -122,12 +124,19 @@ ZgeParams derive_params(const zarc_gpu_params &p)
     z.lazy = level >= 2 ? 1 : 0; z.lazy_delta = 5;
     z.lit_cost = 5; z.match_cost = deep ? 10 : 12; z.rep_cost = 9;
     z.short_window_log = 30;
-    // far tables in HBM (zge_match.hip).  Level 3: 2^16 buckets, one way on the 12-byte hash, 4 of 16 positions inserted, every 4th
+    // far tables in HBM (zge_match.hip).  Level 3: 2^16 buckets, one way on the 12-byte hash, 4 of 32 positions inserted, every 4th
     // looked up; level >= 9: 2^16 buckets, two ways on both hashes, every 2nd position inserted, all looked up
-    z.far_log = 16; z.far_ways = deep ? 2 : 1; z.far_step_log = deep ? 1 : 4; z.far_res_log = deep ? 0 : 2; z.far_short = deep ? 1 : 0;
-    z.far_back = deep ? 8 : 16;
+    z.far_log = 16; z.far_ways = deep ? 2 : 1; z.far_step_log = deep ? 1 : 5; z.far_res_log = deep ? 0 : 2; z.far_short = deep ? 1 : 0;
+    z.far_back = deep ? 8 : 24; z.far_skip = deep ? 0 : 64;
     z.dbg = diag_env("ZARC_GPU_DBG", 0); // timing-only ablations (outputs invalid when set): diagnostic build only
     return z;
+}
+
+inline hipError_t create_low_priority_stream(hipStream_t *s)
+{
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return hipStreamCreate(s);
+    return hipStreamCreateWithPriority(s, hipStreamDefault, least);
 }
 
 inline uint64_t chunks_of(uint64_t len) { return len == 0 ? 1 : (len + 1023) / 1024; }
@@ -153,9 +162,15 @@ int upload_u32(zarc_gpu *h, DevBuf &b, const uint32_t *src, size_t n)
 }
 
 // BLAKE3 of n entries described by device arrays d_off/d_len (already uploaded); result in h->d_digests
-int run_blake3(zarc_gpu *h, size_t n, const uint8_t *d_base, const uint64_t *off, const uint64_t *len, const uint64_t *d_off, const uint64_t *d_len)
+// `side` (pack): the two kernels go to the low-priority side stream behind an event of the engine stream -- the caller launches the
+// match finder first, so the digest fills the tail of that launch instead of standing in front of it
+int run_blake3(zarc_gpu *h, size_t n, const uint8_t *d_base, const uint64_t *off, const uint64_t *len, const uint64_t *d_off, const uint64_t *d_len,
+               bool prepare_only = false, bool launch_only = false, hipStream_t stream = nullptr)
 {
     (void)off;
+    if (!stream) stream = h->stream;
+    if (launch_only) goto launch;
+    {
     std::vector<uint64_t> prefix(n + 1);
     prefix[0] = 0;
     for (size_t i = 0; i < n; i++) prefix[i + 1] = prefix[i] + chunks_of(len[i]);
@@ -165,14 +180,21 @@ int run_blake3(zarc_gpu *h, size_t n, const uint8_t *d_base, const uint64_t *off
     ZHIP(h->d_cvs.reserve(total * 32));
     ZHIP(h->d_cvs_tmp.reserve(total * 32));
     ZHIP(h->d_digests.reserve(std::max<size_t>(n, 1) * 32));
+    h->blake3_total_chunks = total;
+    }
+    if (prepare_only) return 0;
+launch:
+    {
+    const uint64_t total = h->blake3_total_chunks;
     const uint32_t tpb = 256;
     const uint64_t grid = (total + tpb - 1) / tpb;
-    hipLaunchKernelGGL(zarc_blake3_chunks, dim3((unsigned)grid), dim3(tpb), 0, h->stream, d_base, d_off, d_len, h->d_chunk_prefix.as<uint64_t>(),
+    hipLaunchKernelGGL(zarc_blake3_chunks, dim3((unsigned)grid), dim3(tpb), 0, stream, d_base, d_off, d_len, h->d_chunk_prefix.as<uint64_t>(),
                        (uint32_t)n, total, h->d_cvs.as<uint32_t>(), h->d_digests.as<uint32_t>());
     const unsigned tgrid = (unsigned)std::min<size_t>(n, 65535);
-    hipLaunchKernelGGL(zarc_blake3_tree, dim3(tgrid), dim3(256), 0, h->stream, h->d_chunk_prefix.as<uint64_t>(), (uint32_t)n,
+    hipLaunchKernelGGL(zarc_blake3_tree, dim3(tgrid), dim3(256), 0, stream, h->d_chunk_prefix.as<uint64_t>(), (uint32_t)n,
                        h->d_cvs.as<uint32_t>(), h->d_cvs_tmp.as<uint32_t>(), h->d_digests.as<uint32_t>());
     ZHIP(hipGetLastError());
+    }
     return 0;
 }
 
@@ -219,12 +241,14 @@ int zarc_gpu_create(zarc_gpu_t **out, int device)
     zarc_gpu *h = new (std::nothrow) zarc_gpu();
     if (!h) return ZARC_GPU_E_NOMEM;
     h->device = device;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess || hipStreamCreate(&h->stream2) != hipSuccess || hipStreamCreate(&h->stream3) != hipSuccess || hipStreamCreate(&h->stream_stage) != hipSuccess ||
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess || hipStreamCreate(&h->stream2) != hipSuccess || create_low_priority_stream(&h->stream3) != hipSuccess || hipStreamCreate(&h->stream_stage) != hipSuccess ||
         hipEventCreate(&h->ev_fork3) != hipSuccess || hipEventCreate(&h->ev_join3) != hipSuccess ||
         hipEventCreate(&h->ev_fork) != hipSuccess || hipEventCreate(&h->ev_join) != hipSuccess) { delete h; return ZARC_GPU_E_DEVICE; }
     for (auto &e : h->ev)
         if (hipEventCreate(&e) != hipSuccess) { delete h; return ZARC_GPU_E_DEVICE; }
     for (auto &e : h->ev_dec)
+        if (hipEventCreate(&e) != hipSuccess) { delete h; return ZARC_GPU_E_DEVICE; }
+    for (auto &e : h->ev_b3)
         if (hipEventCreate(&e) != hipSuccess) { delete h; return ZARC_GPU_E_DEVICE; }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) h->num_cus = prop.multiProcessorCount;
@@ -249,6 +273,7 @@ void zarc_gpu_destroy(zarc_gpu_t *h)
     for (DevBuf *b : all) b->release();
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
     for (auto &e : h->ev_dec) if (e) (void)hipEventDestroy(e);
+    for (auto &e : h->ev_b3) if (e) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->stream3) (void)hipStreamDestroy(h->stream3);
@@ -391,8 +416,8 @@ int zarc_gpu_pack_batch_device(zarc_gpu_t *h, size_t n, const void *d_src_base, 
     // the match finder has these compiled in (zge_match.hip: F_*)
     if (P.rep_back != 256 || P.back_cap != 8 || P.lazy_delta != 5 || P.min_rep != 3 || P.rep_search != 2 || P.seg_log != 21 || P.short_window_log < 30 ||
         P.lit_cost != 5 || P.rep_cost != 9 || P.tag_bits != 10 || P.far_log != 16 || P.match_cost != (P.long_log == 14 ? 10 : 12) || P.far_ways != (P.long_log == 14 ? 2 : 1) ||
-        P.far_step_log != (P.long_log == 14 ? 1 : 4) || P.far_res_log != (P.long_log == 14 ? 0 : 2) || (P.far_short != 0) != (P.long_log == 14) ||
-        P.far_back != (P.long_log == 14 ? 8 : 16)) { set_error(h, "internal: encoder parameters differ from the compiled-in ones"); return ZARC_GPU_E_PARAM; }
+        P.far_step_log != (P.long_log == 14 ? 1 : 5) || P.far_res_log != (P.long_log == 14 ? 0 : 2) || (P.far_short != 0) != (P.long_log == 14) ||
+        P.far_back != (P.long_log == 14 ? 8 : 24) || P.far_skip != (P.long_log == 14 ? 0 : 64)) { set_error(h, "internal: encoder parameters differ from the compiled-in ones"); return ZARC_GPU_E_PARAM; }
     uint64_t need = 0;
     for (size_t i = 0; i < n; i++) {
         if (src_off[i] % ZARC_GPU_ALIGN) { set_error(h, "entry offset not 16-byte aligned"); return ZARC_GPU_E_PARAM; }
@@ -411,8 +436,8 @@ int zarc_gpu_pack_batch_device(zarc_gpu_t *h, size_t n, const void *d_src_base, 
     int e0, e1, e2;
     ZHIP(t.mark(&e0));
     if (h->params.compress) {
-        // the frame checksum is a chain of 64-bit multiplies per entry (few waves, latency-bound): it runs on the side stream
-        // next to the digest and is only waited for by the first frame assembly
+        // the frame checksum is a chain of 64-bit multiplies per entry (few waves, latency-bound): it runs on a side stream from the
+        // start and is only waited for by the first frame assembly
         ZHIP(hipEventRecord(h->ev_fork, h->stream));
         ZHIP(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
         ZHIP(hipEventRecord(h->ev[14], h->stream2));
@@ -420,8 +445,11 @@ int zarc_gpu_pack_batch_device(zarc_gpu_t *h, size_t n, const void *d_src_base, 
         ZHIP(hipEventRecord(h->ev[15], h->stream2));
         ZHIP(hipEventRecord(h->ev_join, h->stream2));
     }
-    if ((rc = run_blake3(h, n, base, src_off, src_len, d_off, d_len))) return rc;
+    // the digest: in store mode right here; otherwise its kernels are queued on the low-priority side stream right behind the first
+    // match-finder launch (below), fill the tail of that launch and are joined before the digests travel back
+    if ((rc = run_blake3(h, n, base, src_off, src_len, d_off, d_len, /*prepare_only=*/h->params.compress != 0))) return rc;
     ZHIP(t.mark(&e1));
+    bool digest_queued = false;
     if (!h->params.compress) {
         // store mode (Encoder::enable_compression(false)): raw-block frames, no checksum (lowlevel_frames.rs:47-84)
         hipLaunchKernelGGL(zarc_zge_store, dim3((unsigned)n), dim3(256), 0, h->stream, base, d_off, d_len, (uint32_t)n, (uint8_t *)d_dst,
@@ -492,6 +520,15 @@ int zarc_gpu_pack_batch_device(zarc_gpu_t *h, size_t n, const void *d_src_base, 
                            h->d_block_prefix.as<uint64_t>(), h->d_blocks.as<ZgeBlock>(), h->d_seq.as<uint64_t>(), h->d_lit.as<uint8_t>(),
                            h->d_queue.as<uint32_t>(), h->d_far.as<uint32_t>());
         ZHIP(hipGetLastError());
+        if (!digest_queued) {
+            ZHIP(hipEventRecord(h->ev_fork3, h->stream)); // orders the side stream behind the descriptor uploads (and this launch)
+            ZHIP(hipStreamWaitEvent(h->stream3, h->ev_fork3, 0));
+            ZHIP(hipEventRecord(h->ev_b3[0], h->stream3));
+            if ((rc = run_blake3(h, n, base, src_off, src_len, d_off, d_len, false, /*launch_only=*/true, h->stream3))) return rc;
+            ZHIP(hipEventRecord(h->ev_b3[1], h->stream3));
+            ZHIP(hipEventRecord(h->ev_join3, h->stream3));
+            digest_queued = true;
+        }
         ZHIP(t.mark(&b));
         hipLaunchKernelGGL(zarc_zge_entropy, dim3((unsigned)nb), dim3(64), 0, h->stream, (uint32_t)nb, h->d_blocks.as<ZgeBlock>(),
                            h->d_seq.as<uint64_t>(), h->d_lit.as<uint8_t>(), h->d_out.as<uint8_t>(),
@@ -525,16 +562,17 @@ int zarc_gpu_pack_batch_device(zarc_gpu_t *h, size_t n, const void *d_src_base, 
         t.next = 3;
         start = end;
     }
+    ZHIP(hipStreamWaitEvent(h->stream, h->ev_join3, 0)); // the digests are done
     ZHIP(hipMemcpyAsync(dst_len, h->d_dst_len.p, n * 8, hipMemcpyDeviceToHost, h->stream));
     ZHIP(hipMemcpyAsync(digest, h->d_digests.p, n * 32, hipMemcpyDeviceToHost, h->stream));
     ZHIP(hipStreamSynchronize(h->stream));
     if (status) for (size_t i = 0; i < n; i++) status[i] = ZARC_GPU_FRAME_OK;
-    h->ms[ZARC_GPU_T_BLAKE3] = elapsed(h, e0, e1);
-    h->ms[ZARC_GPU_T_XXH64] = elapsed(h, 14, 15); // side stream: overlaps the digest pass, not part of the total
+    { float ms = -1.f; if (hipEventElapsedTime(&ms, h->ev_b3[0], h->ev_b3[1]) == hipSuccess) h->ms[ZARC_GPU_T_BLAKE3] = ms; } // side stream: queue wait + kernels
+    h->ms[ZARC_GPU_T_XXH64] = elapsed(h, 14, 15); // side stream: overlaps the match finder, not part of the total
     h->ms[ZARC_GPU_T_MATCH] = ms_match;
     h->ms[ZARC_GPU_T_ENTROPY] = ms_ent;
     h->ms[ZARC_GPU_T_ASSEMBLE] = ms_asm;
-    h->ms[ZARC_GPU_T_TOTAL] = h->ms[ZARC_GPU_T_BLAKE3] + ms_match + ms_ent + ms_asm;
+    h->ms[ZARC_GPU_T_TOTAL] = elapsed(h, e0, e1) + ms_match + ms_ent + ms_asm; // the digest and the checksum run beside these
     return ZARC_GPU_OK;
 }
 

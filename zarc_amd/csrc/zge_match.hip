@@ -145,11 +145,11 @@ __device__ __forceinline__ uint32_t tile_end(uint32_t tile, uint32_t n)
 // one for level >= 9 (2^14-entry tables = 128 KiB of LDS, one workgroup per CU; 4-byte short hash, cheaper matches).
 // DIAG: the timing-only switches of ZARC_GPU_DBG are compiled into a separate instantiation, so the product kernels carry none of
 // their scalar tests
-// F_FAR_LOG / FAR_WAYS / FAR_SHORT / FAR_STEP_LOG / FAR_RES_LOG / FAR_BACK: the far tables (0 ways = none); the engine checks that
+// F_FAR_LOG / FAR_WAYS / FAR_SHORT / FAR_STEP_LOG / FAR_RES_LOG / FAR_SKIP / FAR_BACK: the far tables (0 ways = none); the engine checks that
 // P carries the same values.  Positions p with p mod 2^FAR_STEP_LOG < 2^FAR_RES_LOG are inserted, positions with
 // p mod 2^FAR_RES_LOG == 0 are looked up: of 2^FAR_RES_LOG inserted neighbours exactly one lands on a looked-up position whatever the
 // offset of the repeat -- the memory requests per tile (what the far tables cost) go down by that factor.
-template <int TAB_LOG, int SHORT_BYTES, int MATCH_COST, int F_FAR_LOG, int FAR_WAYS, bool FAR_SHORT, int FAR_STEP_LOG, int FAR_RES_LOG, int FAR_BACK, bool DIAG>
+template <int TAB_LOG, int SHORT_BYTES, int MATCH_COST, int F_FAR_LOG, int FAR_WAYS, bool FAR_SHORT, int FAR_STEP_LOG, int FAR_RES_LOG, int FAR_SKIP, int FAR_BACK, bool DIAG>
 __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgeParams &P, const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off,
                                                const uint64_t *__restrict__ src_len, const uint32_t *__restrict__ order, uint32_t n_frames,
                                                const uint64_t *__restrict__ block_prefix, ZgeBlock *__restrict__ blocks,
@@ -163,7 +163,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
     uint32_t *const far_l = far_scratch + (size_t)blockIdx.x * far_words;  // this workgroup's slab: long-hash table, then short-hash table
     uint32_t *const far_s = far_l + ((size_t)FAR_WAYS << F_FAR_LOG);
     constexpr uint32_t far_smask = (1u << FAR_STEP_LOG) - 1, far_rmask = (1u << FAR_RES_LOG) - 1;
-    static_assert(FAR_BACK == 8 || FAR_BACK == 16, "backward extension of far candidates");
+    static_assert(FAR_BACK == 8 || FAR_BACK == 16 || FAR_BACK == 24 || FAR_BACK == 32, "backward extension of far candidates");
     const int tid = (int)threadIdx.x, lane = zd::lane_id();
     const uint32_t dbg = DIAG ? (uint32_t)P.dbg : 0u;
     const int wave = (int)zd::uniform((uint32_t)zd::wave_id()); // scalar: chunk bounds and the parse walk stay on the SALU
@@ -277,10 +277,14 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
             if (skip_left) { // cold stretch: the tile is not searched -- its bytes go straight from HBM to the literals
                 skip_left--;
                 const uint32_t start = (uint32_t)((pos > tile ? pos : tile) - tile);
-#pragma unroll
-                for (int u = 0; u < PER; u++) {
-                    const uint32_t idx = ZGE_IDX(u);
-                    if (idx >= start && idx < tcount && !(dbg & 32)) lit_out[lp + (idx - start)] = src[tile + idx];
+                { // 16 bytes per thread (one wave moves a whole tile) instead of a byte per position
+                    const uint32_t cntb = tcount - start, k = (uint32_t)tid * 16;
+                    const uint8_t *sp = src + tile + start;
+                    uint8_t *dp = lit_out + lp;
+                    if (!(dbg & 32)) {
+                        if (k + 16 <= cntb) { U128 v; __builtin_memcpy(&v, sp + k, 16); __builtin_memcpy(dp + k, &v, 16); }
+                        else for (uint32_t r = k; r < cntb; r++) dp[r] = sp[r];
+                    }
                 }
                 lp += tcount - start;
                 zd::lds_barrier(); // every thread has read K_POS
@@ -299,6 +303,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
             const uint32_t wofs = sw.wofs;
             const uint32_t ntile = tile + TILE; // may be the first tile of the next block
             uint32_t wofs_n = 0;
+            bool staged_now = false; // this tile's own window had to be written just now: S1 must wait for it (uniform)
             {
                 // this tile's window: normally staged while the previous tile was worked on
                 if (lds_tile[bsel] != tile) {
@@ -306,6 +311,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
                     if (pf_tile != tile && tid < sw.ndw) v = sw.w[tid]; // first tile of a frame, or after skipped tiles
                     if (tid < sw.ndw) L.tb[bsel][tid] = v;
                     lds_tile[bsel] = tile;
+                    staged_now = true;
                 }
                 if (ntile < n) {
                     const StageWin nw = stage_window(P, src, n, ntile, tile_end(ntile, n), cap_max);
@@ -323,7 +329,9 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
                     }
                 }
             }
-            zd::lds_barrier();
+            // In the steady state this tile's window has been in LDS since the previous tile and the one written above (the next
+            // tile's) is not read before S3: no barrier between S0 and S1.
+            if (staged_now) zd::lds_barrier();
             ZGE_PROF(1);
             // ---- S1: hashes (index << TAG_BITS | tag) ----
             uint64_t p8[PER]; // first 8 bytes at each of this thread's positions
@@ -384,28 +392,6 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
                 L.a1[idx] = hs;
                 L.ex[idx] = 0; // S4 offers start empty (the previous tile's walk is over)
             }
-            if (NFAR) {
-                // the NEXT tile's far entries: hashes out of its window in the other LDS buffer; the requests have S2 and S3 to come back
-#pragma unroll
-                for (int u = 0; u < FNEXT_ROWS; u++) {
-                    const uint32_t idxn = FAR_COMPACT ? (uint32_t)wave * 128u + ((uint32_t)lane << FAR_RES_LOG) : ZGE_IDX(u);
-                    const uint32_t pn = ntile + idxn;
-                    const bool mine = (!FAR_COMPACT || (uint32_t)lane < (128u >> FAR_RES_LOG)) && !((dbg & 16384) && wave < 2) && !(dbg & 32768);
-                    if (mine && pn < far_end && !(pn & far_rmask) && !(dbg & 2048)) {
-                        const uint64_t v = zd::load_u64(tbn + (uint32_t)(pn + wofs_n));
-                        const uint32_t hf = hash_far32(v, zd::load_u32(tbn + (uint32_t)(pn + 8 + wofs_n))) >> far_shift, hg = hash_short32(v, SHORT_BYTES) >> far_shift;
-#pragma unroll
-                        for (int w = 0; w < FAR_WAYS; w++) {
-                            fnext[u][w] = zd::load_l2_u32(far_l + ((size_t)(hf >> TAG_BITS) * FAR_WAYS + w));
-                            if (FAR_SHORT) fnext[u][FAR_WAYS + w] = zd::load_l2_u32(far_s + ((size_t)(hg >> TAG_BITS) * FAR_WAYS + w));
-                        }
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < NFAR; k++) fnext[u][k] = 0;
-                    }
-                }
-                pf_far_tile = ntile;
-            }
             zd::lds_barrier();
             ZGE_PROF(2);
             // ---- S2: ordered lookup + insert (wave 0); no waits between the steps on hardware ----
@@ -447,6 +433,28 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
             // idx + rep_back rule) are LDS reads at a lane offset; hash candidates are global loads `frame base (SGPR) + position`.
             // Phase A requests the first 8 source bytes of every candidate of BOTH positions, phase B scores them and loads more
             // only for candidates that match 8 bytes. ----
+            if (NFAR) {
+                // the NEXT tile's far entries: hashes out of its window in the other LDS buffer; requested here, behind two barriers since S0 wrote that buffer; the requests have S3 to come back
+#pragma unroll
+                for (int u = 0; u < FNEXT_ROWS; u++) {
+                    const uint32_t idxn = FAR_COMPACT ? (uint32_t)wave * 128u + ((uint32_t)lane << FAR_RES_LOG) : ZGE_IDX(u);
+                    const uint32_t pn = ntile + idxn;
+                    const bool mine = (!FAR_COMPACT || (uint32_t)lane < (128u >> FAR_RES_LOG)) && !((dbg & 16384) && wave < 2) && !(dbg & 32768);
+                    if (mine && pn < far_end && !(pn & far_rmask) && !(dbg & 2048)) {
+                        const uint64_t v = zd::load_u64(tbn + (uint32_t)(pn + wofs_n));
+                        const uint32_t hf = hash_far32(v, zd::load_u32(tbn + (uint32_t)(pn + 8 + wofs_n))) >> far_shift, hg = hash_short32(v, SHORT_BYTES) >> far_shift;
+#pragma unroll
+                        for (int w = 0; w < FAR_WAYS; w++) {
+                            fnext[u][w] = zd::load_l2_u32(far_l + ((size_t)(hf >> TAG_BITS) * FAR_WAYS + w));
+                            if (FAR_SHORT) fnext[u][FAR_WAYS + w] = zd::load_l2_u32(far_s + ((size_t)(hg >> TAG_BITS) * FAR_WAYS + w));
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < NFAR; k++) fnext[u][k] = 0;
+                    }
+                }
+                pf_far_tile = ntile;
+            }
             uint32_t mo[PER], mw[PER];
             uint32_t offs[PER][NTAB];
             U128 q16[PER];                    // near candidate: source[-8 .. 8)
@@ -535,6 +543,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
                 for (int k = 0; k < NTAB; k++) {
                     const uint32_t off = offs[u][k];
                     if (!off) continue;
+                    if (FAR_SKIP && k >= 1 && best_len >= (uint32_t)FAR_SKIP) continue; // with that many bytes in hand a far candidate is not looked at: it would be the tile's longest compare
                     const bool is_rep = off == erep0 || off == erep1;
                     uint64_t x = (k < 1 ? q16[u].hi : qf[u][k < 1 ? 0 : k - 1]) ^ p8[u];
                     uint32_t len = 0;
@@ -575,9 +584,14 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
                         if (NFAR && best_far) best_before = zd::load_u64(src + (q - 8));
                         const uint64_t x = zd::load_u64(tbb + (uint32_t)(p - 8 + wofs)) ^ best_before;
                         back = x ? (uint32_t)(__clzll((long long)x) >> 3) : 8u;
-                        if (NFAR && FAR_BACK > 8 && best_far && back == 8 && maxb > 8) {
-                            const uint64_t x2 = zd::load_u64(tbb + (uint32_t)(p - 16 + wofs)) ^ zd::load_u64(src + (q - 16));
-                            back += x2 ? (uint32_t)(__clzll((long long)x2) >> 3) : 8u;
+                        if (NFAR && FAR_BACK > 8 && best_far) { // further back 8 bytes at a time while everything so far was equal
+#pragma unroll
+                            for (uint32_t j = 16; j <= (uint32_t)FAR_BACK; j += 8) {
+                                if (back == j - 8 && maxb > j - 8) {
+                                    const uint64_t x2 = zd::load_u64(tbb + (uint32_t)(p - j + wofs)) ^ zd::load_u64(src + (q - j));
+                                    back += x2 ? (uint32_t)(__clzll((long long)x2) >> 3) : 8u;
+                                }
+                            }
                         }
                         if (back > maxb) back = maxb;
                     }
@@ -593,7 +607,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
             for (int u = 0; u < PER; u++) L.a0[ZGE_IDX(u)] = match_pack(mo[u], mw[u] & 0xFFFF, (mw[u] >> 24) & 1);
             if (mo[0] | mo[1]) L.ctrl[K_ANY] = 1; // benign race: every writer stores 1
             // ---- S4: backward propagation.  A position whose match extends b bytes backwards offers it to the b
-            // positions before it (ds_max of score << 5 | 16-k: best score wins, then the nearest source); every position
+            // positions before it (ds_max of score << 6 | 32-k: best score wins, then the nearest source); every position
             // then adopts the best offer if it beats its own match.  Same result as scanning the 8 following positions.
 #pragma unroll
             for (int u = 0; u < PER; u++) {
@@ -603,7 +617,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
                     const bool rep = (mw[u] >> 24) & 1;
                     for (uint32_t k = 1; k <= back && k <= idx; k++) {
                         const int32_t sc = score_of(P, len + k, mo[u], rep);
-                        if (sc > 0) atomicMax(&L.ex[idx - k], ((uint32_t)sc << 5) | (16u - k));
+                        if (sc > 0) atomicMax(&L.ex[idx - k], ((uint32_t)sc << 6) | (32u - k));
                     }
                 }
             }
@@ -653,8 +667,8 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
                 bool brep = (mw[u] >> 24) & 1;
                 if (offer) {
                     const int32_t own = blen_ ? score_of(P, blen_, boff, brep) : 0;
-                    if ((int32_t)(offer >> 5) > own) {
-                        const uint32_t k = 16u - (offer & 31u);
+                    if ((int32_t)(offer >> 6) > own) {
+                        const uint32_t k = 32u - (offer & 63u);
                         const uint32_t nm = L.a0[idx + k];
                         boff = match_off(nm);
                         blen_ = match_len(nm) + k;
@@ -812,7 +826,7 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                                                       uint32_t *__restrict__ far_scratch)
 {
     __shared__ MatchLds<13> L;
-    zge_match_body<13, 5, 12, 16, 1, false, 4, 2, 16, false>(L, P, src_base, src_off, src_len, order, n_frames, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
+    zge_match_body<13, 5, 12, 16, 1, false, 5, 2, 64, 24, false>(L, P, src_base, src_off, src_len, order, n_frames, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
 }
 
 #ifdef ZARC_GPU_DIAG
@@ -825,7 +839,7 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match_diag(ZgeParams P, const
                                                            uint32_t *__restrict__ far_scratch)
 {
     __shared__ MatchLds<13> L;
-    zge_match_body<13, 5, 12, 16, 1, false, 4, 2, 16, true>(L, P, src_base, src_off, src_len, order, n_frames, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
+    zge_match_body<13, 5, 12, 16, 1, false, 5, 2, 64, 24, true>(L, P, src_base, src_off, src_len, order, n_frames, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
 }
 #endif
 
@@ -836,5 +850,5 @@ __global__ void __launch_bounds__(512, 2) zarc_zge_match_deep(ZgeParams P, const
                                                            uint32_t *__restrict__ far_scratch)
 {
     __shared__ MatchLds<14> L;
-    zge_match_body<14, 4, 10, 16, 2, true, 1, 0, 8, false>(L, P, src_base, src_off, src_len, order, n_frames, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
+    zge_match_body<14, 4, 10, 16, 2, true, 1, 0, 0, 8, false>(L, P, src_base, src_off, src_len, order, n_frames, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
 }

@@ -19,6 +19,13 @@
 #include "zarc_device.h"
 #include "zarc_kernels.h"
 
+// timing-only ablation switches exist in the diagnostic build alone (make DIAG=1); in the product library they fold to zero
+#ifdef ZARC_GPU_DIAG
+#define ZDEC_DBG(x) (x)
+#else
+#define ZDEC_DBG(x) 0
+#endif
+
 namespace {
 
 constexpr int BLOCK_MAX = 128 * 1024;
@@ -1088,7 +1095,7 @@ __global__ void __launch_bounds__(64, 5) zarc_zstd_decode(const uint8_t *__restr
         if (slot >= n_frames) break;
         const uint32_t f = order[slot];
         if (fast != nullptr && zd::uniform(fast[f]) != 0) continue; // zarc_zstd_frames has it
-        decode_frame<false>(L, lane, f, lit_buf, frames_base, frame_off, frame_len, dst_base, dst_off, raw_len, status, stored_checksum, dbg, nullptr, nullptr,
+        decode_frame<false>(L, lane, f, lit_buf, frames_base, frame_off, frame_len, dst_base, dst_off, raw_len, status, stored_checksum, ZDEC_DBG(dbg), nullptr, nullptr,
                             nullptr, nullptr, nullptr);
         zd::wave_sync_global(); // LDS tables and the literal buffer are reused by the next frame
     }
@@ -1116,7 +1123,7 @@ __global__ void __launch_bounds__(64, 5) zarc_zstd_frames(const uint8_t *__restr
         const uint32_t f = order[slot];
         if (zd::uniform(fast[f]) == 0) continue; // zarc_zstd_decode has it
         const uint64_t first = slot_prefix[f];
-        decode_frame<true>(L, lane, f, nullptr, frames_base, frame_off, frame_len, dst_base, dst_off, raw_len, status, stored_checksum, dbg,
+        decode_frame<true>(L, lane, f, nullptr, frames_base, frame_off, frame_len, dst_base, dst_off, raw_len, status, stored_checksum, ZDEC_DBG(dbg),
                            zblocks + first, seq_index + first, seqs, lit_index + first, lits);
         zd::wave_sync_global(); // the LDS staging buffer is reused by the next frame
     }
