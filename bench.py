@@ -45,7 +45,7 @@ def aggregate(local_seconds, local_units, dist=None, device=None):
     return float(t.item()), float(u.item())
 
 
-def cpu_baseline(sample, size, first_index, level):
+def cpu_baseline(sample, size, first_index, level, kind=-1):
     """The reference's CPU path on this box's host cores (rank 0, N = 1 only), bounded sample: tests/support/cpu_baseline.c --
     one CCtx with session resets (content_frame.rs:37-41), decompressStream in 131 075 / 131 072-byte steps
     (zstd_iterator.rs:88-153), BLAKE3 on both sides.  libzstd = the fastest build found on the box (they differ 3x)."""
@@ -56,19 +56,19 @@ def cpu_baseline(sample, size, first_index, level):
         return None, None
     probe = {}
     for z in zs:  # quick probe: 16 MiB through each build on one thread
-        r = harness.cpu_baseline(z.path, level, 1, 16, size, first_index)
+        r = harness.cpu_baseline(z.path, level, 1, 16, size, first_index, kind)
         probe[z.path] = r["pack_seconds"]
     zbest = min(zs, key=lambda z: probe[z.path])
     z15 = next((z for z in zs if z.version.startswith("1.5")), zbest)
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    one = harness.cpu_baseline(zbest.path, level, 1, sample, size, first_index)
-    many = harness.cpu_baseline(zbest.path, level, cores, min(4 * sample, 4096), size, first_index) if cores > 1 else None
-    ref = harness.cpu_baseline(z15.path, level, cores, min(sample, 256), size, first_index)  # ratio yardstick: the 1.5.x build
+    one = harness.cpu_baseline(zbest.path, level, 1, sample, size, first_index, kind)
+    many = harness.cpu_baseline(zbest.path, level, cores, min(4 * sample, 4096), size, first_index, kind) if cores > 1 else None
+    ref = harness.cpu_baseline(z15.path, level, cores, min(sample, 256), size, first_index, kind)  # ratio yardstick: the 1.5.x build
     out = {"value": one["bytes"] / one["pack_seconds"] / GIB, "unit": "GiB/s", "cores": 1, "kind": "port",
            "unpack_value": one["bytes"] / one["unpack_seconds"] / GIB,
            "sample": "%d x %d B corpus entries from index %d, level %d; C driver tests/support/cpu_baseline.c (one CCtx + session reset per "
                      "entry, decompressStream in 131075/131072-byte steps, oracle BLAKE3 port on both sides); %s; %d host cores usable by this process"
-                     % (sample, size, first_index, level, one["info"], cores),
+                     % (sample, size, kind, first_index, level, one["info"], cores),
            "ratio": one["bytes"] / one["compressed_bytes"]}
     if many:
         out["multithreaded"] = {"value": many["bytes"] / many["pack_seconds"] / GIB, "unpack_value": many["bytes"] / many["unpack_seconds"] / GIB,
@@ -308,10 +308,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             size0 = int(lens[0])
             sample = min(args.cpu_sample, n) if args.config == "c2" else min(64, n)
-            cb, ref = cpu_baseline(sample, size0 if args.config != "c5" else 1 << 20, int(index[0]), level)
+            cb, ref = cpu_baseline(sample, size0 if args.config != "c5" else 1 << 20, int(index[0]), level, kind)
             if cb:
                 line["cpu_baseline"] = cb
-                if args.config == "c2" and kind < 0:
+                if args.config in ("c2", "c4"):   # same entries on both sides (c5's sizes are mixed: its baseline sample is 1 MiB entries)
                     ref_comp, ref_n, ref_name = ref
                     ours = float(dlen[:ref_n].sum())
                     line["ratio_vs_reference"] = round(ref_comp / ours, 4)   # >= 0.95 required (within 5 % of libzstd -3)

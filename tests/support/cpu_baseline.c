@@ -137,7 +137,7 @@ static int run_phase(job *proto, int threads, int phase, double *seconds)
 }
 
 /* Returns 0 on success.  info receives "libzstd <version>; <cpu model>; <online cores> cores". */
-int cpu_baseline_run(const char *libzstd_path, int level, int threads, size_t n, size_t entry_bytes, uint64_t first_index,
+int cpu_baseline_run(const char *libzstd_path, int level, int threads, size_t n, size_t entry_bytes, uint64_t first_index, int kind,
                      double *pack_seconds, double *unpack_seconds, uint64_t *compressed_bytes, char *info, size_t info_cap)
 {
     zapi z;
@@ -160,7 +160,7 @@ int cpu_baseline_run(const char *libzstd_path, int level, int threads, size_t n,
     j.digest = (uint8_t(*)[32])calloc(n, 32);
     for (i = 0; i < n; i++) {
         j.raw[i] = (uint8_t *)malloc(entry_bytes + 16);
-        zarc_corpus_entry(j.raw[i], entry_bytes, first_index + i, -1);
+        zarc_corpus_entry(j.raw[i], entry_bytes, first_index + i, kind);
     }
     if (threads < 1) threads = 1;
     rc = run_phase(&j, threads, 0, pack_seconds);

@@ -39,16 +39,16 @@ def _build_cpu_baseline():
     return so
 
 
-def cpu_baseline(libzstd_path, level, threads, n, entry_bytes, first_index=0):
+def cpu_baseline(libzstd_path, level, threads, n, entry_bytes, first_index=0, kind=-1):
     """The reference's CPU path (one CCtx + session reset per entry, decompressStream in 131 075 / 131 072 byte steps, BLAKE3 on
     both sides) on `threads` host threads: tests/support/cpu_baseline.c.  Returns a dict or raises."""
     lib = ctypes.CDLL(_build_cpu_baseline())
-    lib.cpu_baseline_run.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_uint64,
+    lib.cpu_baseline_run.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_uint64, ctypes.c_int,
                                      ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64),
                                      ctypes.c_char_p, ctypes.c_size_t]
     tp, tu, cb = ctypes.c_double(), ctypes.c_double(), ctypes.c_uint64()
     info = ctypes.create_string_buffer(400)
-    rc = lib.cpu_baseline_run(libzstd_path.encode(), level, threads, n, entry_bytes, first_index, ctypes.byref(tp), ctypes.byref(tu),
+    rc = lib.cpu_baseline_run(libzstd_path.encode(), level, threads, n, entry_bytes, first_index, kind, ctypes.byref(tp), ctypes.byref(tu),
                               ctypes.byref(cb), info, len(info))
     if rc != 0:
         raise RuntimeError("cpu_baseline_run failed: %d" % rc)

@@ -38,6 +38,6 @@ for f in glob.glob("$O/sq*/**/*counter_collection.csv", recursive=True):
             sq[k][row["Counter_Name"]][0] += 1; sq[k][row["Counter_Name"]][1] += float(row["Counter_Value"])
 out["sq_per_dispatch"] = {k: {c: v[1] / max(v[0], 1) for c, v in d.items()} for k, d in sq.items()}
 json.dump(out, open("$O/pmc_summary.json", "w"), indent=1, sort_keys=True)
-print(json.dumps({k: {kk: round(vv["per_dispatch"]) for kk, vv in v.items()} for k, v in out.items() if isinstance(v, dict)}, indent=0)[:1500])
+print(json.dumps({k: {kk: round(vv["per_dispatch"]) for kk, vv in v.items()} for k, v in out.items() if k in ("fetch", "write")}, indent=0)[:1500])
 PY
 tail -1 $O/trace.log | cut -c1-600
