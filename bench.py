@@ -66,7 +66,7 @@ def cpu_baseline(sample, size, first_index, level, kind=-1):
     ref = harness.cpu_baseline(z15.path, level, cores, min(sample, 256), size, first_index, kind)  # ratio yardstick: the 1.5.x build
     out = {"value": one["bytes"] / one["pack_seconds"] / GIB, "unit": "GiB/s", "cores": 1, "kind": "port",
            "unpack_value": one["bytes"] / one["unpack_seconds"] / GIB,
-           "sample": "%d x %d B corpus entries from index %d, level %d; C driver tests/support/cpu_baseline.c (one CCtx + session reset per "
+           "sample": "%d x %d B corpus entries (kind %d) from index %d, level %d; C driver tests/support/cpu_baseline.c (one CCtx + session reset per "
                      "entry, decompressStream in 131075/131072-byte steps, oracle BLAKE3 port on both sides); %s; %d host cores usable by this process"
                      % (sample, size, kind, first_index, level, one["info"], cores),
            "ratio": one["bytes"] / one["compressed_bytes"]}
