@@ -34,12 +34,24 @@ __global__ void __launch_bounds__(256) zarc_xxh64(const uint8_t *__restrict__ ba
     uint64_t acc = k == 0 ? XP1 + XP2 : (k == 1 ? XP2 : (k == 2 ? 0 : 0 - XP1));
     const uint64_t *q = (const uint64_t *)p + k;
     uint64_t s = 0;
-    // the loads do not depend on the accumulator chain: keep 8 in flight
-    for (; s + 8 <= stripes; s += 8) {
-        uint64_t x0 = q[0], x1 = q[4], x2 = q[8], x3 = q[12], x4 = q[16], x5 = q[20], x6 = q[24], x7 = q[28];
-        acc = xround(acc, x0); acc = xround(acc, x1); acc = xround(acc, x2); acc = xround(acc, x3);
-        acc = xround(acc, x4); acc = xround(acc, x5); acc = xround(acc, x6); acc = xround(acc, x7);
-        q += 32;
+    // The loads do not depend on the accumulator chain.  One entry is one chain however many entries the batch has (a 16 MiB entry
+    // is half a million rounds for its four lanes), so the chain must never wait for memory: 8 stripes are consumed while the
+    // next 16 are in flight (three register sets in rotation).
+    if (stripes >= 16) {
+        uint64_t x[8], y[8], z[8];
+#define XLOAD(v, at) _Pragma("unroll") for (int i = 0; i < 8; i++) v[i] = q[(at) + 4 * i]
+#define XROUNDS(v) _Pragma("unroll") for (int i = 0; i < 8; i++) acc = xround(acc, v[i])
+        XLOAD(x, 0); XLOAD(y, 32);
+        for (; s + 40 <= stripes; s += 24) { // the three sets change roles in place: no register copies that would wait for the newest loads
+            XLOAD(z, 64); XROUNDS(x);
+            XLOAD(x, 96); XROUNDS(y);
+            XLOAD(y, 128); XROUNDS(z);
+            q += 96;
+        }
+        XROUNDS(x); XROUNDS(y);
+#undef XLOAD
+#undef XROUNDS
+        s += 16; q += 64;
     }
     for (; s < stripes; s++) { acc = xround(acc, q[0]); q += 4; }
     // combine the four accumulators of the group (all lanes run the shuffles; lane k==0 finishes)

@@ -370,10 +370,40 @@ __device__ __forceinline__ void lane_stage32(uint8_t *d, const uint8_t *s, uint3
     } else if (n == 1) d[0] = s[0];
 }
 
+// The same copy in two halves, so that the loads of several copies are in flight together and the wave waits ONCE: lane_stage32
+// keeps its loads inside the branch of its length class, and a wave with mixed lengths pays one HBM round trip per class.  Here the
+// loads do not depend on the class -- 16 bytes at the start (up to 15 of them beyond the run: the caller checks that they exist) and
+// the 16 bytes that end the run when it is longer than that -- and the classes only differ in the LDS stores.
+struct Win32 { uint64_t a0, a1, b0, b1; };
+__device__ __forceinline__ void lane_load32(Win32 &w, const uint8_t *s, uint32_t n)
+{
+    __builtin_memcpy(&w.a0, s, 8); __builtin_memcpy(&w.a1, s + 8, 8);
+    const uint8_t *t = s + (n > 16 ? n - 16 : 0u);
+    __builtin_memcpy(&w.b0, t, 8); __builtin_memcpy(&w.b1, t + 8, 8);
+}
+__device__ __forceinline__ void lane_store32(uint8_t *d, const Win32 &w, uint32_t n)
+{
+    if (n >= 16) {
+        __builtin_memcpy(d, &w.a0, 8); __builtin_memcpy(d + 8, &w.a1, 8); __builtin_memcpy(d + n - 16, &w.b0, 8); __builtin_memcpy(d + n - 8, &w.b1, 8);
+    } else if (n >= 8) {
+        const uint32_t sh = 8 * (n - 8); // bytes [n-8, n) of the 16 loaded
+        const uint64_t y = sh ? (w.a0 >> sh) | (w.a1 << (64 - sh)) : w.a0;
+        __builtin_memcpy(d, &w.a0, 8); __builtin_memcpy(d + n - 8, &y, 8);
+    } else if (n >= 4) {
+        const uint32_t x = (uint32_t)w.a0, y = (uint32_t)(w.a0 >> (8 * (n - 4)));
+        __builtin_memcpy(d, &x, 4); __builtin_memcpy(d + n - 4, &y, 4);
+    } else if (n >= 2) {
+        const uint16_t x = (uint16_t)w.a0, y = (uint16_t)(w.a0 >> (8 * (n - 2)));
+        __builtin_memcpy(d, &x, 2); __builtin_memcpy(d + n - 2, &y, 2);
+    } else if (n == 1) d[0] = (uint8_t)w.a0;
+}
+
 // LDS -> LDS, n <= 32, ranges do not overlap: same head/tail scheme
 __device__ __forceinline__ void lane_move32(uint8_t *d, const uint8_t *s, uint32_t n)
 {
-    lane_stage32(d, s, n);
+    Win32 w; // one LDS round trip whatever the mix of lengths in the wave (the staging buffer has spare bytes behind it for the over-read)
+    lane_load32(w, s, n);
+    lane_store32(d, w, n);
 }
 
 // Huffman tree description -> weights in LDS, returns bytes consumed (or -1); lane-serial part on lane 0.
@@ -729,6 +759,7 @@ __device__ __forceinline__ void decode_frame(Lds &L, const int lane, const uint3
         const uint32_t ltype = b0 & 3, sf = (b0 >> 2) & 3;
         const uint8_t *lit = lit_buf; // where the literal bytes live
         uint32_t lit_len = 0, lused = 0;
+        uint32_t lit_room = 0; // bytes that may be READ from lit (the fast path over-reads short runs)
         bool lit_rle = false;
         uint8_t lit_rle_byte = 0;
         if (ltype < 2) {
@@ -740,6 +771,7 @@ __device__ __forceinline__ void decode_frame(Lds &L, const int lane, const uint3
             if (ltype == 0) {
                 if (hdr + lit_len > blen) { err = ZARC_FRAME_CORRUPT; break; }
                 lit = bp + hdr; // used in place
+                lit_room = slen - (uint32_t)(lit - src);
                 lused = hdr + lit_len;
             } else {
                 if (hdr + 1 > blen) { err = ZARC_FRAME_CORRUPT; break; }
@@ -764,6 +796,7 @@ __device__ __forceinline__ void decode_frame(Lds &L, const int lane, const uint3
             if (use_pre) { // fast path: stage 2 has regenerated these literals
                 if (fblocks[my_b].lit_len != lit_len) { err = ZARC_FRAME_CORRUPT; break; } // not reachable
                 lit = lits + flit_index[my_b];
+                lit_room = lit_len + 64; // the literal scratch ends with 64 spare bytes
                 lused = hdr + comp;
             } else {
             const uint8_t *hp = bp + hdr;
@@ -840,6 +873,8 @@ __device__ __forceinline__ void decode_frame(Lds &L, const int lane, const uint3
                 }
                 if (zd::ballot(!okb) != 0) { err = ZARC_FRAME_CORRUPT; break; }
             }
+            uint64_t q_next = 0; // fast path: the next batch's sequences are requested one batch ahead
+            if (PRE && (uint32_t)lane < nseq) q_next = pre[lane];
             for (uint32_t base = 0; base < nseq && !err; base += SEQ_BATCH) {
                 const uint32_t cnt = nseq - base < SEQ_BATCH ? nseq - base : SEQ_BATCH;
                 if (dbg & 2) continue;
@@ -848,8 +883,9 @@ __device__ __forceinline__ void decode_frame(Lds &L, const int lane, const uint3
                     // every lane fetches its sequence; stage 2 already resolved the offset as far as the block alone allows, what is
                     // left refers to the history at the start of the block (rep0..2 stay fixed during a pre-decoded block)
                     bool pbad = false;
+                    const uint64_t q = q_next;
+                    if (base + SEQ_BATCH + (uint32_t)lane < nseq) q_next = pre[base + SEQ_BATCH + (uint32_t)lane];
                     if ((uint32_t)lane < cnt) {
-                        const uint64_t q = pre[base + (uint32_t)lane];
                         const uint32_t llr = zge_seq_ll(q), v = zge_seq_ofv(q);
                         p_ll = llr & (ZDEC_LL_REF - 1);
                         p_ml = zge_seq_ml(q);
@@ -916,9 +952,20 @@ __device__ __forceinline__ void decode_frame(Lds &L, const int lane, const uint3
                         uint8_t *const ob = L.obuf;
                         const uint32_t o_lit = dlit - bpos, o_mat = dmat - bpos;
                         // (1) literal runs and (2) far matches (sources below this batch's output): independent of each other
-                        if (lit_rle) { for (uint32_t r = 0; r < ll; r++) ob[o_lit + r] = lit_rle_byte; }
-                        else if (ll <= 32 && !(dbg & 32)) lane_stage32(ob + o_lit, lit + slit, ll);
-                        if (far && ml <= 32 && !(dbg & 64)) lane_stage32(ob + o_mat, out + msrc, ml);
+                        // short runs: all their loads are issued before any is used, one round trip for the batch (the runs that would
+                        // read past the end of their buffer take lane_stage32)
+                        {
+                            const bool lit_short = !lit_rle && ll > 0 && ll <= 32 && !(dbg & 32), far_short = far && ml > 0 && ml <= 32 && !(dbg & 64);
+                            const bool lit_w = lit_short && slit + 16 <= lit_room, far_w = far_short && (uint64_t)msrc + 16 <= cap;
+                            Win32 wl, wf;
+                            if (lit_w) lane_load32(wl, lit + slit, ll);
+                            if (far_w) lane_load32(wf, out + msrc, ml);
+                            if (lit_rle) { for (uint32_t r = 0; r < ll; r++) ob[o_lit + r] = lit_rle_byte; }
+                            if (lit_w) lane_store32(ob + o_lit, wl, ll);
+                            else if (lit_short) lane_stage32(ob + o_lit, lit + slit, ll);
+                            if (far_w) lane_store32(ob + o_mat, wf, ml);
+                            else if (far_short) lane_stage32(ob + o_mat, out + msrc, ml);
+                        }
                         uint64_t longs = lit_rle ? 0ull : zd::ballot(ll > 32);
                         while (longs) {
                             const int i = zd::ctz64(longs);
@@ -934,14 +981,18 @@ __device__ __forceinline__ void decode_frame(Lds &L, const int lane, const uint3
                             for (uint32_t k = (uint32_t)lane; k < n_; k += 64) ob[d_ + k] = out[s_ + k];
                         }
                         zd::wave_sync();
-                        // (3a) near matches whose source touches no other near match's output run together, one lane each.  Outputs are
-                        // ordered like the lanes, so "the near matches that start below my source's end" is a lane count (binary search
-                        // over the match positions) and only the last of them can reach up to my source's start.
+                        // (3) near matches.  Those whose source touches no UNRESOLVED near match's output run together, one lane each, round
+                        // after round (records: every field copies the previous record's, so a round retires one record's matches and
+                        // a batch takes as many rounds as it holds records, not one step per match).  Outputs are ordered like the lanes,
+                        // so "the near matches that start below my source's end" is a lane count (binary search over the match positions,
+                        // once per batch) and only the last unresolved one of them can reach up to my source's start.  A round that finds
+                        // nothing (long, overlapping or straddling matches) runs the lowest unresolved match wave-wide: all below it is final.
                         uint64_t near = (dbg & 8) ? 0ull : zd::ballot(have && !far);
-                        if (near && !(dbg & 128)) {
+                        if (near) {
                             const int32_t s_rel = (int32_t)o_mat - (int32_t)offset;   // source start relative to the batch
                             const uint32_t s_end = (uint32_t)s_rel + ml;              // meaningful when s_rel >= 0
-                            const bool cand = have && !far && s_rel >= 0 && offset >= ml && ml <= 32;
+                            const bool cand = have && !far && s_rel >= 0 && offset >= ml && ml <= 32 && !(dbg & 128);
+                            const uint32_t o_end = o_mat + ml;
                             uint32_t jb = 0;                                          // lanes whose match starts below s_end
 #pragma unroll
                             for (uint32_t step = 32; step; step >>= 1) {
@@ -949,26 +1000,29 @@ __device__ __forceinline__ void decode_frame(Lds &L, const int lane, const uint3
                                 if (probe < s_end) jb += step;
                             }
                             if (zd::shfl(o_mat, 63) < s_end) jb = 64;
-                            const uint64_t before = jb >= 64 ? near : (near & ((1ull << jb) - 1));
-                            const uint32_t last_end = zd::shfl(o_mat + ml, before ? 63 - __clzll((long long)before) : 0);
-                            const bool indep = cand && (before == 0 || last_end <= (uint32_t)s_rel);
-                            const uint64_t im = zd::ballot(indep);
-                            if (indep) lane_move32(ob + o_mat, ob + s_rel, ml);
-                            if (im) { zd::wave_sync(); near &= ~im; }
-                        }
-                        // (3b) the rest in order: their sources are bytes of this batch (LDS) or, below its start, earlier output
-                        while (near) {
-                            const int i = zd::ctz64(near);
-                            near &= near - 1;
-                            const uint32_t n_ = zd::readlane(ml, (uint32_t)i), d_ = zd::readlane(o_mat, (uint32_t)i), o_ = zd::readlane(offset, (uint32_t)i);
-                            // all reads come from below the match start: byte k <- source[k mod offset]
-                            for (uint32_t k = (uint32_t)lane; k < n_; k += 64) {
-                                uint32_t j = k;
-                                if (j >= o_) j = j % o_;
-                                const int32_t sp = (int32_t)d_ - (int32_t)o_ + (int32_t)j; // relative to the batch start
-                                ob[d_ + k] = sp >= 0 ? ob[sp] : out[bpos + sp];
+                            const uint64_t below = jb >= 64 ? ~0ull : ((1ull << jb) - 1);
+                            while (near) {
+                                const uint64_t before = near & below;
+                                const uint32_t last_end = zd::shfl(o_end, before ? 63 - __clzll((long long)before) : 0);
+                                const bool indep = cand && ((near >> lane) & 1) && (before == 0 || last_end <= (uint32_t)s_rel);
+                                const uint64_t im = zd::ballot(indep);
+                                if (im) {
+                                    if (indep) lane_move32(ob + o_mat, ob + s_rel, ml);
+                                    near &= ~im;
+                                } else {
+                                    const int i = zd::ctz64(near);
+                                    near &= near - 1;
+                                    const uint32_t n_ = zd::readlane(ml, (uint32_t)i), d_ = zd::readlane(o_mat, (uint32_t)i), o_ = zd::readlane(offset, (uint32_t)i);
+                                    // all reads come from below the match start: byte k <- source[k mod offset]; the source may begin under the batch
+                                    for (uint32_t k = (uint32_t)lane; k < n_; k += 64) {
+                                        uint32_t j = k;
+                                        if (j >= o_) j = j % o_;
+                                        const int32_t sp = (int32_t)d_ - (int32_t)o_ + (int32_t)j; // relative to the batch start
+                                        ob[d_ + k] = sp >= 0 ? ob[sp] : out[bpos + sp];
+                                    }
+                                }
+                                zd::wave_sync();
                             }
-                            zd::wave_sync();
                         }
                         // (4) the finished bytes leave LDS 16 per lane
                         for (uint32_t k = (uint32_t)lane * 16; k < tot_all && !(dbg & 16); k += 64 * 16) {
