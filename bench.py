@@ -169,6 +169,7 @@ def main():
     ap.add_argument("--host-entries", type=int, default=8192, help="entries (of the resident batch) sent through the host-pointer entry points")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true")
+    ap.add_argument("--dec-groups", type=int, default=0, help="diagnostics: ZARC_GPU_PX_DEC_GROUPS (0 = the engine decides by the batch's shape)")
     ap.add_argument("--kind", type=int, default=-1, help="diagnostics: use one corpus kind for every entry (default: round-robin)")
     args = ap.parse_args()
 
@@ -192,6 +193,8 @@ def main():
     eng = Engine(local_rank)
     eng.set_parameter(_lib.P_COMPRESSION_LEVEL, level)
     eng.set_parameter(_lib.P_CHECKSUM_FLAG, 1)  # crates/zarc-cli/src/pack.rs:227
+    if args.dec_groups:
+        eng.set_parameter(_lib.PX_DEC_GROUPS, args.dec_groups)
 
     n = len(sizes)
     lens = np.array(sizes, dtype=np.uint64)

@@ -83,7 +83,9 @@ enum {
     ZARC_GPU_PX_SCRATCH_MB = 9001,   /* encoder scratch budget in MiB (0 = up to 64 GiB / 45 % of free HBM): batches beyond it run as sub-batches */
     ZARC_GPU_PX_STAGE_CHUNK = 9002,  /* host-pointer entry points: content bytes per staged chunk (0 = 2 GiB pack / 4 GiB unpack; >= 4096)         */
     ZARC_GPU_PX_STAGE_THREAD = 9003, /* 1 (default) = a helper thread moves neighbouring chunks over PCIe while the kernels run                     */
-    ZARC_GPU_PX_COPY_THREADS = 9004  /* host threads that fill / drain the pinned staging ring (default 8)                                          */
+    ZARC_GPU_PX_COPY_THREADS = 9004, /* host threads that fill / drain the pinned staging ring (default 8)                                          */
+    ZARC_GPU_PX_DEC_GROUPS = 9005    /* unpack: frames are dealt by descending size into this many groups whose stages overlap (1..4; 0 = by the
+                                        batch: 2 when its largest frame has 4 MiB and more and four times the mean size, else 1)                                                    */
 };
 /* What the engine does with the libzstd ids (pack.rs:86-217 forwards them all):
  *   CompressionLevel  -131072..22 accepted.  Levels <= 8 run the level-3 finder (LDS tables of 2^13 entries on an 8-byte and a

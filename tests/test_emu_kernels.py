@@ -50,6 +50,33 @@ def test_emu_host_staging_in_chunks(emu_engine, oracle, corpus, golden_frames):
         emu_engine.set_parameter(_lib.PX_STAGE_CHUNK, 0)
 
 
+def test_emu_unpack_in_size_groups(emu_engine, oracle, corpus, golden_frames):
+    """Unpack deals the frames by descending size into groups whose stages overlap on their own streams (engine.hip,
+    zarc_gpu_unpack_batch_device); by itself it does so only for batches with large frames.  Forced here on small ones: golden
+    frames, error statuses (the inline decoder runs per group), fuzzed frames and round trips must not change, and results must
+    come back in the caller's order."""
+    for g in (2, 3, 4):
+        emu_engine.set_parameter(_lib.PX_DEC_GROUPS, g)
+        try:
+            pc.check_unpack_golden(emu_engine, oracle, corpus, golden_frames, limit=70000)
+            pc.check_unpack_errors(emu_engine, oracle, corpus, golden_frames)
+            pc.check_roundtrip(emu_engine, oracle, corpus, big=False)
+            if g == 3:
+                ok, bad = pc.check_unpack_fuzz(emu_engine, oracle, corpus, golden_frames, n_mut=60, seed=3, max_raw=70000)
+                assert bad > 10
+        finally:
+            emu_engine.set_parameter(_lib.PX_DEC_GROUPS, 0)
+    # fewer frames than groups
+    emu_engine.set_parameter(_lib.PX_DEC_GROUPS, 4)
+    try:
+        raw = corpus.entry(77, 50000, 0)
+        (frame, dig), = emu_engine.pack([raw])
+        (out, d2, st), = emu_engine.unpack([frame], [len(raw)], [dig])
+        assert st == _lib.FRAME_OK and out == raw and d2 == dig
+    finally:
+        emu_engine.set_parameter(_lib.PX_DEC_GROUPS, 0)
+
+
 def test_emu_pack_in_sub_batches(emu_engine, oracle, corpus, libzstds):
     """A batch whose encoder scratch does not fit the budget is packed in several sub-batches (scratch reused between them):
     frames must not change."""

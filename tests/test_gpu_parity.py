@@ -127,11 +127,36 @@ def test_gpu_mixed_sizes_config5_shape(engine, oracle, corpus):
             assert frame == oracle.zge_encode(raw), (i, sizes[i])
             rc, out, used = oracle.zstd_decode(frame, len(raw))
             assert rc == 0 and out == raw
-        dig2, st2 = engine.unpack_device(d_dst, doff, dlen, d_out, off, sizes, expect=dig)
-        assert (st2 == 0).all() and (dig2 == dig).all()
+        # this shape (largest frame of 16 MiB, several times the mean) is what makes unpack deal the frames into two size groups by
+        # itself (0); the other group counts must give the same bytes, digests and statuses
+        for g in (0, 1, 3, 4):
+            engine.set_parameter(_lib.PX_DEC_GROUPS, g)
+            try:
+                for i in (1, n - 3, n - 1):
+                    engine.h2d(d_out + off[i], bytes(sizes[i]))   # the bytes checked below are this run's
+                dig2, st2 = engine.unpack_device(d_dst, doff, dlen, d_out, off, sizes, expect=dig)
+            finally:
+                engine.set_parameter(_lib.PX_DEC_GROUPS, 0)
+            assert (st2 == 0).all() and (dig2 == dig).all(), g
+            for i in (1, n - 3, n - 1):
+                assert bytes(engine.d2h(d_out + off[i], sizes[i])) == corpus.entry(7000 + i, sizes[i], -1), (g, i)
     finally:
         for p in (d_src, d_dst, d_out):
             engine.free(p)
+
+
+def test_gpu_unpack_in_size_groups(engine, oracle, corpus, golden_frames):
+    """Forced group counts on the golden frames (every libzstd-made frame, up to 16 MiB), the error statuses (the inline decoder
+    runs once per group) and fuzzed frames: nothing may change, and results come back in the caller's order."""
+    for g in (2, 4):
+        engine.set_parameter(_lib.PX_DEC_GROUPS, g)
+        try:
+            pc.check_unpack_golden(engine, oracle, corpus, golden_frames)
+            pc.check_unpack_errors(engine, oracle, corpus, golden_frames)
+            ok, bad = pc.check_unpack_fuzz(engine, oracle, corpus, golden_frames, n_mut=1500, seed=20 + g)
+            assert bad > 300
+        finally:
+            engine.set_parameter(_lib.PX_DEC_GROUPS, 0)
 
 
 def test_gpu_level9_parameter_config4_shape(engine, oracle, corpus, libzstds):

@@ -22,7 +22,7 @@ FRAME_OK, FRAME_CORRUPT, FRAME_CHECKSUM, FRAME_DIGEST, FRAME_DSTSIZE, FRAME_BAD_
 P_COMPRESSION_LEVEL, P_WINDOW_LOG, P_HASH_LOG, P_CHAIN_LOG, P_SEARCH_LOG, P_MIN_MATCH, P_TARGET_LENGTH, P_STRATEGY = 100, 101, 102, 103, 104, 105, 106, 107
 P_CONTENT_SIZE_FLAG, P_CHECKSUM_FLAG, P_DICT_ID_FLAG = 200, 201, 202
 # engine tuning (batching only; frames are identical for every value)
-PX_SCRATCH_MB, PX_STAGE_CHUNK, PX_STAGE_THREAD, PX_COPY_THREADS = 9001, 9002, 9003, 9004
+PX_SCRATCH_MB, PX_STAGE_CHUNK, PX_STAGE_THREAD, PX_COPY_THREADS, PX_DEC_GROUPS = 9001, 9002, 9003, 9004, 9005
 # timers
 T_BLAKE3, T_XXH64, T_MATCH, T_ENTROPY, T_ASSEMBLE, T_DECODE, T_TOTAL, T_DEC_SEQS, T_DEC_LITS, T_DEC_FRAMES = range(10)
 

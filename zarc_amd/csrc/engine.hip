@@ -72,7 +72,12 @@ struct zarc_gpu {
     // staging arenas for the host-pointer entry points
     DevBuf d_arena_in, d_arena_out;
     hipEvent_t ev[16] = {};
-    hipEvent_t ev_dec[6] = {}; // decoder sub-kernels: seqs begin/end, literals begin/end (side stream), frame pass begin/end
+    // decoder groups (zarc_gpu_unpack_batch_device): a pair of streams per group; events: 0/1 sequences, 2/3 literals, 4/5 frame passes, 6/7 checksum,
+    // 8/9 digest, 10 literals done (join)
+    static constexpr int DEC_GROUPS = 4;
+    hipStream_t gs[2 * DEC_GROUPS] = {};
+    hipEvent_t ev_g[DEC_GROUPS][11] = {};
+    int dec_groups = 0;        // ZARC_GPU_PX_DEC_GROUPS: 0 = by the batch's shape
     float ms[ZARC_GPU_T_COUNT];
     size_t scratch_budget = 0; // 0 = derive from free memory (ZARC_GPU_PX_SCRATCH_MB)
     uint64_t stage_chunk = 0;  // 0 = default per entry point (ZARC_GPU_PX_STAGE_CHUNK)
@@ -246,8 +251,14 @@ int zarc_gpu_create(zarc_gpu_t **out, int device)
         hipEventCreate(&h->ev_fork) != hipSuccess || hipEventCreate(&h->ev_join) != hipSuccess) { delete h; return ZARC_GPU_E_DEVICE; }
     for (auto &e : h->ev)
         if (hipEventCreate(&e) != hipSuccess) { delete h; return ZARC_GPU_E_DEVICE; }
-    for (auto &e : h->ev_dec)
-        if (hipEventCreate(&e) != hipSuccess) { delete h; return ZARC_GPU_E_DEVICE; }
+    for (int i = 0; i < 2 * zarc_gpu::DEC_GROUPS; i++) { // the first group holds the largest frames, whose chains are the critical path: its streams go first
+        int least = 0, greatest = 0;
+        const bool prio = i < 2 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least;
+        if ((prio ? hipStreamCreateWithPriority(&h->gs[i], hipStreamDefault, greatest) : hipStreamCreate(&h->gs[i])) != hipSuccess) { delete h; return ZARC_GPU_E_DEVICE; }
+    }
+    for (auto &row : h->ev_g)
+        for (auto &e : row)
+            if (hipEventCreate(&e) != hipSuccess) { delete h; return ZARC_GPU_E_DEVICE; }
     for (auto &e : h->ev_b3)
         if (hipEventCreate(&e) != hipSuccess) { delete h; return ZARC_GPU_E_DEVICE; }
     hipDeviceProp_t prop;
@@ -272,7 +283,8 @@ void zarc_gpu_destroy(zarc_gpu_t *h)
                      &h->d_slot_prefix, &h->d_zblocks, &h->d_nseq, &h->d_fast, &h->d_seqidx, &h->d_seqs, &h->d_ztables, &h->d_litidx, &h->d_lits};
     for (DevBuf *b : all) b->release();
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
-    for (auto &e : h->ev_dec) if (e) (void)hipEventDestroy(e);
+    for (auto &row : h->ev_g) for (auto &e : row) if (e) (void)hipEventDestroy(e);
+    for (auto &st : h->gs) if (st) (void)hipStreamDestroy(st);
     for (auto &e : h->ev_b3) if (e) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
@@ -313,6 +325,9 @@ int zarc_gpu_set_parameter(zarc_gpu_t *h, int id, int value)
     case ZARC_GPU_PX_COPY_THREADS:
         if (value < 1 || value > 64) return ZARC_GPU_E_PARAM;
         h->copy_threads = value; return ZARC_GPU_OK;
+    case ZARC_GPU_PX_DEC_GROUPS:
+        if (value < 0 || value > zarc_gpu::DEC_GROUPS) return ZARC_GPU_E_PARAM;
+        h->dec_groups = value; return ZARC_GPU_OK;
     case ZARC_GPU_P_CONTENT_SIZE_FLAG:
         if (value != 1) return ZARC_GPU_E_UNSUPPORTED; // frames always carry their content size
         return ZARC_GPU_OK;
@@ -576,38 +591,49 @@ int zarc_gpu_pack_batch_device(zarc_gpu_t *h, size_t n, const void *d_src_base, 
     return ZARC_GPU_OK;
 }
 
-int zarc_gpu_unpack_batch_device(zarc_gpu_t *h, size_t n, const void *d_frames_base, const uint64_t *frame_off, const uint64_t *frame_len,
-                                 void *d_dst_base, const uint64_t *dst_off, const uint64_t *raw_len, const uint8_t *expect, uint8_t *digest,
+// The decoder's stages (sequences + literals ahead, frame pass, checksum + digest) of ONE frame are a chain, and a large frame's chain
+// is long whatever runs beside it (one wave walks its blocks; XXH64 is serial by construction).  Frames are therefore taken in
+// descending size and dealt into up to DEC_GROUPS groups of equal bytes, each group with its own pair of streams: the frame pass and
+// the hashes of the large frames start as soon as THEIR sequences and literals are decoded and run beside the earlier stages of the
+// groups behind them.  Per-frame arrays are uploaded in that order (group = index range = slot range); results go back in the caller's.
+int zarc_gpu_unpack_batch_device(zarc_gpu_t *h, size_t n, const void *d_frames_base, const uint64_t *frame_off_in, const uint64_t *frame_len_in,
+                                 void *d_dst_base, const uint64_t *dst_off_in, const uint64_t *raw_len_in, const uint8_t *expect_in, uint8_t *digest,
                                  int *status)
 {
     int rc = check_common(h, n);
     if (rc) return rc;
     if (n == 0) return ZARC_GPU_OK;
-    if (!d_frames_base || !frame_off || !frame_len || !d_dst_base || !dst_off || !raw_len || !digest || !status) return ZARC_GPU_E_PARAM;
+    if (!d_frames_base || !frame_off_in || !frame_len_in || !d_dst_base || !dst_off_in || !raw_len_in || !digest || !status) return ZARC_GPU_E_PARAM;
+    uint64_t total_raw = 0;
     for (size_t i = 0; i < n; i++) {
-        if (dst_off[i] % ZARC_GPU_ALIGN) { set_error(h, "output offset not 16-byte aligned"); return ZARC_GPU_E_PARAM; }
-        if (frame_len[i] >= 0xFFFFFFF0ull || raw_len[i] >= 0xFFFFFFF0ull) { set_error(h, "frames of 4 GiB or more are not supported"); return ZARC_GPU_E_UNSUPPORTED; }
+        if (dst_off_in[i] % ZARC_GPU_ALIGN) { set_error(h, "output offset not 16-byte aligned"); return ZARC_GPU_E_PARAM; }
+        if (frame_len_in[i] >= 0xFFFFFFF0ull || raw_len_in[i] >= 0xFFFFFFF0ull) { set_error(h, "frames of 4 GiB or more are not supported"); return ZARC_GPU_E_UNSUPPORTED; }
+        total_raw += raw_len_in[i];
     }
-    if ((rc = upload_u64(h, h->d_frame_off, frame_off, n))) return rc;
-    if ((rc = upload_u64(h, h->d_frame_len, frame_len, n))) return rc;
-    if ((rc = upload_u64(h, h->d_dst_off, dst_off, n))) return rc;
-    if ((rc = upload_u64(h, h->d_raw_len, raw_len, n))) return rc;
     std::vector<uint32_t> order(n);
     std::iota(order.begin(), order.end(), 0u);
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return raw_len[a] > raw_len[b]; });
-    if ((rc = upload_u32(h, h->d_order, order.data(), n))) return rc;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return raw_len_in[a] > raw_len_in[b]; });
+    std::vector<uint64_t> frame_off(n), frame_len(n), dst_off(n), raw_len(n);
+    for (size_t i = 0; i < n; i++) { const uint32_t f = order[i]; frame_off[i] = frame_off_in[f]; frame_len[i] = frame_len_in[f]; dst_off[i] = dst_off_in[f]; raw_len[i] = raw_len_in[f]; }
+    if ((rc = upload_u64(h, h->d_frame_off, frame_off.data(), n))) return rc;
+    if ((rc = upload_u64(h, h->d_frame_len, frame_len.data(), n))) return rc;
+    if ((rc = upload_u64(h, h->d_dst_off, dst_off.data(), n))) return rc;
+    if ((rc = upload_u64(h, h->d_raw_len, raw_len.data(), n))) return rc;
+    { std::vector<uint32_t> ident(n); std::iota(ident.begin(), ident.end(), 0u); if ((rc = upload_u32(h, h->d_order, ident.data(), n))) return rc; } // the queues walk the (sorted) indices
     const size_t dec_grid = std::min<size_t>(n, (size_t)h->num_cus * 20); // 5 waves per SIMD (launch bounds of the decoder)
     ZHIP(h->d_declit.reserve(dec_grid * (size_t)(ZARC_BLOCK + 64)));
     ZHIP(h->d_queue.reserve(256));
     ZHIP(h->d_status.reserve(n * 4));
     ZHIP(h->d_stored_ck.reserve(n * 8));
-    if (expect) {
+    std::vector<uint8_t> expect;
+    if (expect_in) {
+        expect.resize(n * 32);
+        for (size_t i = 0; i < n; i++) memcpy(&expect[i * 32], expect_in + (size_t)order[i] * 32, 32);
         ZHIP(h->d_expect.reserve(n * 32));
-        ZHIP(hipMemcpyAsync(h->d_expect.p, expect, n * 32, hipMemcpyHostToDevice, h->stream));
+        ZHIP(hipMemcpyAsync(h->d_expect.p, expect.data(), n * 32, hipMemcpyHostToDevice, h->stream));
     }
     Timer t{h};
-    int e0, e1, e2, e3;
-    bool have_seq_t = false, have_lit_t = false;
+    int e0, e1, e3;
     ZHIP(t.mark(&e0));
     // ---- fast path: block scan (lane per frame), then sequence entropy decoding with one lane per block ----
     bool fastpath = diag_env("ZARC_GPU_DEC_FAST", 1) != 0;
@@ -615,6 +641,42 @@ int zarc_gpu_unpack_batch_device(zarc_gpu_t *h, size_t n, const void *d_frames_b
     for (size_t i = 0; i < n; i++) slot_prefix[i + 1] = slot_prefix[i] + raw_len[i] / ZARC_BLOCK + 2; // blocks a well-formed frame needs, plus slack
     const size_t nslots = (size_t)slot_prefix[n];
     if (nslots * (size_t)ZDEC_TABLE_CELLS * 2 > ((size_t)8 << 30)) fastpath = false; // table scratch out of proportion (millions of tiny frames)
+    // groups: [gf[g], gf[g+1]) in sorted order, equal shares of the bytes.  One group (the stages simply follow each other) unless the
+    // batch holds frames large enough for their chains to matter.
+    int groups = h->dec_groups;
+    // Measured (tools/ab_groups.sh): overlapped stages slow each other down (they all live on memory latency), so equal-sized frames are
+    // best served by one group (configs[1]: 64 / 82 / 117 ms with 1 / 2 / 4 groups); a batch whose largest frames are several times the
+    // mean gains from two (configs[4] shape: 227 / 203 / 285 ms) -- the large half's frame pass and XXH64 chains run beside the small
+    // half's sequence stage instead of after it.
+    if (groups <= 0) groups = (fastpath && n >= 16 && raw_len[0] >= ((uint64_t)4 << 20) && raw_len[0] * (uint64_t)n >= 4 * total_raw) ? 2 : 1;
+    if (!fastpath) groups = 1;
+    if (groups > zarc_gpu::DEC_GROUPS) groups = zarc_gpu::DEC_GROUPS;
+    if ((size_t)groups > n) groups = (int)n;
+    std::vector<size_t> gf(groups + 1, n);
+    gf[0] = 0;
+    { uint64_t acc = 0; int g = 1;
+      for (size_t i = 0; i < n && g < groups; i++) {
+          acc += raw_len[i];
+          if (acc * (uint64_t)groups >= total_raw * (uint64_t)g && i + 1 + (size_t)(groups - g) <= n) gf[g++] = i + 1; // every group keeps a frame
+      }
+      for (; g < groups; g++) gf[g] = std::max(gf[g - 1] + 1, n - (size_t)(groups - g)); }
+    // digest descriptors: per group, chunk prefixes rebased to the group's first chunk (the kernels take sub-ranges by pointer)
+    std::vector<uint64_t> cprefix(n + (size_t)groups), gchunk0(groups + 1, 0);
+    { uint64_t c = 0;
+      for (int g = 0; g < groups; g++) {
+          gchunk0[g] = c;
+          uint64_t r = 0;
+          for (size_t i = gf[g]; i < gf[g + 1]; i++) { cprefix[i + (size_t)g] = r; r += chunks_of(raw_len[i]); }
+          cprefix[gf[g + 1] + (size_t)g] = r;
+          c += r;
+      }
+      gchunk0[groups] = c; }
+    if ((rc = upload_u64(h, h->d_chunk_prefix, cprefix.data(), cprefix.size()))) return rc;
+    ZHIP(h->d_cvs.reserve(gchunk0[groups] * 32));
+    ZHIP(h->d_cvs_tmp.reserve(gchunk0[groups] * 32));
+    ZHIP(h->d_digests.reserve(n * 32));
+    ZHIP(h->d_xxh.reserve(n * 8));
+    std::vector<uint64_t> seqidx, litidx;
     if (fastpath) {
         if ((rc = upload_u64(h, h->d_slot_prefix, slot_prefix.data(), n + 1))) return rc;
         ZHIP(h->d_zblocks.reserve(nslots * sizeof(ZdecBlock)));
@@ -632,110 +694,159 @@ int zarc_gpu_unpack_batch_device(zarc_gpu_t *h, size_t n, const void *d_frames_b
         std::vector<uint32_t> counts(nslots * 2);
         ZHIP(hipMemcpyAsync(counts.data(), h->d_nseq.p, nslots * 8, hipMemcpyDeviceToHost, h->stream));
         ZHIP(hipStreamSynchronize(h->stream)); // the sequence / literal scratch is sized exactly: sums of the blocks' counts
-        std::vector<uint64_t> seqidx(nslots), litidx(nslots);
+        seqidx.resize(nslots + 1); litidx.resize(nslots + 1);
         uint64_t total = 0, lit_total = 0;
         for (size_t i = 0; i < nslots; i++) { seqidx[i] = total; total += counts[2 * i]; litidx[i] = lit_total; lit_total += counts[2 * i + 1]; }
+        seqidx[nslots] = total; litidx[nslots] = lit_total;
         if ((rc = upload_u64(h, h->d_seqidx, seqidx.data(), nslots))) return rc;
         if ((rc = upload_u64(h, h->d_litidx, litidx.data(), nslots))) return rc;
         ZHIP(h->d_seqs.reserve(std::max<uint64_t>(total, 1) * 8));
         ZHIP(h->d_lits.reserve(std::max<uint64_t>(lit_total, 1) + 64));
-        // the literal and the sequence kernels are independent and neither fills the chip: they run side by side
-        const bool side = lit_total && total && diag_env("ZARC_GPU_DEC_SIDE", 1) != 0;
-        if (side) { ZHIP(hipEventRecord(h->ev_fork, h->stream)); ZHIP(hipStreamWaitEvent(h->stream2, h->ev_fork, 0)); }
-        if (lit_total) {
-            ZHIP(hipEventRecord(h->ev_dec[2], side ? h->stream2 : h->stream));
-            hipLaunchKernelGGL(zarc_zdec_literals, dim3((unsigned)((nslots + ZDEC_LIT_GROUP - 1) / ZDEC_LIT_GROUP)), dim3(64), 0, side ? h->stream2 : h->stream, (const uint8_t *)d_frames_base,
-                               h->d_frame_off.as<uint64_t>(), (uint64_t)nslots, h->d_slot_prefix.as<uint64_t>(), h->d_zblocks.as<ZdecBlock>(), h->d_litidx.as<uint64_t>(),
-                               h->d_lits.as<uint8_t>(), h->d_fast.as<uint32_t>());
-            ZHIP(hipGetLastError());
-            ZHIP(hipEventRecord(h->ev_dec[3], side ? h->stream2 : h->stream));
-            have_lit_t = true;
-        }
-        if (total) {
-            ZHIP(hipEventRecord(h->ev_dec[0], h->stream));
-            // Each lane is a long serial chain (about one L2/HBM round trip and 340 instructions per sequence).  Partly filled
-            // waves (more waves to interleave) were measured and are slower: 35 ms with 64 lanes per wave, 54 ms with 16
-            // (ZARC_GPU_SEQ_LANES reproduces it) -- the waves' own instruction issue dominates, not exposed waits.
-            int seq_lanes = diag_env("ZARC_GPU_SEQ_LANES", 64);
-            if (seq_lanes != 8 && seq_lanes != 16 && seq_lanes != 32 && seq_lanes != 64) seq_lanes = 64;
-            // The two sequence kernels stress different things (zarc_zdec_seqs: HBM / MALL bandwidth; zarc_zdec_seqs_lds: nothing
-            // but its own serial chains, one wave per SIMD), so the slots are split between them and they run side by side.
-            double frac = diag_env_f("ZARC_GPU_SEQ_LDS_FRAC", 0.0);
-            if (frac < 0) frac = 0;
-            if (frac > 1) frac = 1;
-            const uint64_t split = frac <= 0 ? (uint64_t)nslots : (uint64_t)((double)nslots * (1.0 - frac)) / 64 * 64; // slots [0, split): tables in HBM scratch; [split, nslots): in LDS
-            if (split < nslots) {
-                ZHIP(hipEventRecord(h->ev_fork3, h->stream));
-                ZHIP(hipStreamWaitEvent(h->stream3, h->ev_fork3, 0));
-                hipLaunchKernelGGL(zarc_zdec_seqs_lds, dim3((unsigned)((nslots - split + ZDEC_LDS_LANES - 1) / ZDEC_LDS_LANES)), dim3(ZDEC_LDS_LANES), 0, h->stream3,
-                                   (const uint8_t *)d_frames_base, h->d_frame_off.as<uint64_t>(), (uint64_t)nslots, h->d_slot_prefix.as<uint64_t>(),
-                                   h->d_zblocks.as<ZdecBlock>(), h->d_seqidx.as<uint64_t>(), h->d_seqs.as<uint64_t>(), h->d_fast.as<uint32_t>(), split);
-                ZHIP(hipGetLastError());
-                ZHIP(hipEventRecord(h->ev_join3, h->stream3));
-            }
-            if (split > 0)
-            hipLaunchKernelGGL(zarc_zdec_seqs, dim3((unsigned)((split + seq_lanes - 1) / seq_lanes)), dim3(seq_lanes), 0, h->stream, (const uint8_t *)d_frames_base, h->d_frame_off.as<uint64_t>(),
-                               (uint64_t)split, h->d_slot_prefix.as<uint64_t>(), h->d_zblocks.as<ZdecBlock>(), h->d_seqidx.as<uint64_t>(), h->d_seqs.as<uint64_t>(),
-                               h->d_ztables.as<uint16_t>(), h->d_fast.as<uint32_t>(), (uint64_t)0);
-            if (split < nslots) ZHIP(hipStreamWaitEvent(h->stream, h->ev_join3, 0));
-            ZHIP(hipGetLastError());
-            ZHIP(hipEventRecord(h->ev_dec[1], h->stream));
-            have_seq_t = true;
-        }
-        if (side) { ZHIP(hipEventRecord(h->ev_join, h->stream2)); ZHIP(hipStreamWaitEvent(h->stream, h->ev_join, 0)); }
     }
+    ZHIP(hipMemsetAsync(h->d_queue.p, 0, 256, h->stream)); // two queues per group: the fast frame pass and the general decoder each walk the group's frames
+    ZHIP(hipEventRecord(h->ev_fork, h->stream)); // descriptors are in place
     const int dec_dbg = diag_env("ZARC_GPU_DBG_DEC", 0);
-    ZHIP(hipEventRecord(h->ev_dec[4], h->stream));
-    ZHIP(hipMemsetAsync(h->d_queue.p, 0, 8, h->stream)); // two queues: the fast frame pass and the general decoder each walk all frames
-    if (fastpath) {
-        hipLaunchKernelGGL(zarc_zstd_frames, dim3((unsigned)dec_grid), dim3(64), 0, h->stream, (const uint8_t *)d_frames_base, h->d_frame_off.as<uint64_t>(),
-                           h->d_frame_len.as<uint64_t>(), (uint8_t *)d_dst_base, h->d_dst_off.as<uint64_t>(), h->d_raw_len.as<uint64_t>(),
-                           h->d_order.as<uint32_t>(), (uint32_t)n, h->d_status.as<int32_t>(), h->d_stored_ck.as<uint32_t>(), dec_dbg, h->d_queue.as<uint32_t>(),
-                           h->d_fast.as<uint32_t>(), h->d_slot_prefix.as<uint64_t>(), h->d_zblocks.as<ZdecBlock>(), h->d_seqidx.as<uint64_t>(),
-                           h->d_seqs.as<uint64_t>(), h->d_litidx.as<uint64_t>(), h->d_lits.as<uint8_t>());
+    const bool side = diag_env("ZARC_GPU_DEC_SIDE", 1) != 0;
+    int seq_lanes = diag_env("ZARC_GPU_SEQ_LANES", 64);
+    if (seq_lanes != 8 && seq_lanes != 16 && seq_lanes != 32 && seq_lanes != 64) seq_lanes = 64;
+    // (the LDS-table sequence kernel zarc_zdec_seqs_lds stays a measured alternative of the diagnostic build, one group only)
+    double lds_frac = groups == 1 ? diag_env_f("ZARC_GPU_SEQ_LDS_FRAC", 0.0) : 0.0;
+    if (lds_frac < 0) lds_frac = 0;
+    if (lds_frac > 1) lds_frac = 1;
+    bool have_seq_t[zarc_gpu::DEC_GROUPS] = {}, have_lit_t[zarc_gpu::DEC_GROUPS] = {};
+    for (int g = 0; g < groups; g++) {
+        // The stages ahead (sequences, literals) of all groups follow each other on the engine's two streams -- several sequence kernels side
+        // by side were measured and only slow each other down (they live on MALL / fabric latency) -- while the frame pass and the hashes
+        // of a group run on the group's own pair of streams beside the next group's stages ahead.
+        hipStream_t pa = h->stream, pb = h->stream2;
+        hipStream_t sa = groups == 1 ? h->stream : h->gs[2 * g], sb = groups == 1 ? h->stream2 : h->gs[2 * g + 1];
+        hipEvent_t *ev = h->ev_g[g];
+        const size_t f0 = gf[g], f1 = gf[g + 1], ng = f1 - f0;
+        if (g == 0) ZHIP(hipStreamWaitEvent(pb, h->ev_fork, 0));
+        if (fastpath) {
+            hipStream_t sa_post = sa, sb_post = sb;
+            sa = pa; sb = pb; // this block launches the stages ahead
+            const uint64_t s0 = slot_prefix[f0], s1 = slot_prefix[f1];
+            const uint64_t g_seqs = seqidx[s1] - seqidx[s0], g_lits = litidx[s1] - litidx[s0];
+            // the literal and the sequence kernels are independent and neither fills the chip: they run side by side
+            hipStream_t sl = side ? sb : sa;
+            if (g_lits) {
+                ZHIP(hipEventRecord(ev[2], sl));
+                hipLaunchKernelGGL(zarc_zdec_literals, dim3((unsigned)((s1 - s0 + ZDEC_LIT_GROUP - 1) / ZDEC_LIT_GROUP)), dim3(64), 0, sl, (const uint8_t *)d_frames_base,
+                                   h->d_frame_off.as<uint64_t>(), s1, h->d_slot_prefix.as<uint64_t>(), h->d_zblocks.as<ZdecBlock>(), h->d_litidx.as<uint64_t>(),
+                                   h->d_lits.as<uint8_t>(), h->d_fast.as<uint32_t>(), s0);
+                ZHIP(hipGetLastError());
+                ZHIP(hipEventRecord(ev[3], sl));
+                have_lit_t[g] = true;
+            }
+            if (g_seqs) {
+                ZHIP(hipEventRecord(ev[0], sa));
+                // Each lane is a long serial chain (about one L2/HBM round trip and 340 instructions per sequence).  Partly filled
+                // waves (more waves to interleave) were measured and are slower: 35 ms with 64 lanes per wave, 54 ms with 16
+                // (ZARC_GPU_SEQ_LANES reproduces it) -- the waves' own instruction issue dominates, not exposed waits.
+                const uint64_t split = lds_frac <= 0 ? s1 : s0 + (uint64_t)((double)(s1 - s0) * (1.0 - lds_frac)) / 64 * 64; // [s0, split): tables in HBM scratch; [split, s1): in LDS
+                if (split < s1) {
+                    ZHIP(hipEventRecord(h->ev_fork3, sa));
+                    ZHIP(hipStreamWaitEvent(h->stream3, h->ev_fork3, 0));
+                    hipLaunchKernelGGL(zarc_zdec_seqs_lds, dim3((unsigned)((s1 - split + ZDEC_LDS_LANES - 1) / ZDEC_LDS_LANES)), dim3(ZDEC_LDS_LANES), 0, h->stream3,
+                                       (const uint8_t *)d_frames_base, h->d_frame_off.as<uint64_t>(), s1, h->d_slot_prefix.as<uint64_t>(),
+                                       h->d_zblocks.as<ZdecBlock>(), h->d_seqidx.as<uint64_t>(), h->d_seqs.as<uint64_t>(), h->d_fast.as<uint32_t>(), split);
+                    ZHIP(hipGetLastError());
+                    ZHIP(hipEventRecord(h->ev_join3, h->stream3));
+                }
+                if (split > s0)
+                    hipLaunchKernelGGL(zarc_zdec_seqs, dim3((unsigned)((split - s0 + seq_lanes - 1) / seq_lanes)), dim3(seq_lanes), 0, sa, (const uint8_t *)d_frames_base,
+                                       h->d_frame_off.as<uint64_t>(), split, h->d_slot_prefix.as<uint64_t>(), h->d_zblocks.as<ZdecBlock>(), h->d_seqidx.as<uint64_t>(),
+                                       h->d_seqs.as<uint64_t>(), h->d_ztables.as<uint16_t>(), h->d_fast.as<uint32_t>(), s0);
+                if (split < s1) ZHIP(hipStreamWaitEvent(sa, h->ev_join3, 0));
+                ZHIP(hipGetLastError());
+                ZHIP(hipEventRecord(ev[1], sa));
+                have_seq_t[g] = true;
+            }
+            sa = sa_post; sb = sb_post;
+            if (groups > 1) { ZHIP(hipEventRecord(ev[1], pa)); ZHIP(hipStreamWaitEvent(sa, ev[1], 0)); } // (re-recorded when the group has no sequences: it still orders the group behind the descriptors)
+            if (g_lits && side) { ZHIP(hipEventRecord(ev[10], pb)); ZHIP(hipStreamWaitEvent(sa, ev[10], 0)); }
+        }
+        ZHIP(hipEventRecord(ev[4], sa));
+        const size_t grid_g = std::max<size_t>(1, std::min<size_t>(ng, dec_grid / (size_t)groups));
+        if (fastpath) {
+            hipLaunchKernelGGL(zarc_zstd_frames, dim3((unsigned)std::min<size_t>(ng, dec_grid)), dim3(64), 0, sa, (const uint8_t *)d_frames_base, h->d_frame_off.as<uint64_t>(),
+                               h->d_frame_len.as<uint64_t>(), (uint8_t *)d_dst_base, h->d_dst_off.as<uint64_t>(), h->d_raw_len.as<uint64_t>(),
+                               h->d_order.as<uint32_t>() + f0, (uint32_t)ng, h->d_status.as<int32_t>(), h->d_stored_ck.as<uint32_t>(), dec_dbg, h->d_queue.as<uint32_t>() + 2 * g,
+                               h->d_fast.as<uint32_t>(), h->d_slot_prefix.as<uint64_t>(), h->d_zblocks.as<ZdecBlock>(), h->d_seqidx.as<uint64_t>(),
+                               h->d_seqs.as<uint64_t>(), h->d_litidx.as<uint64_t>(), h->d_lits.as<uint8_t>());
+            ZHIP(hipGetLastError());
+        }
+        // frames the fast path turned down (or all of them when it is off) are decoded inline; with nothing to do every wave leaves at once.
+        // Each group's launch has its own slice of the per-wave literal scratch.
+        hipLaunchKernelGGL(zarc_zstd_decode, dim3((unsigned)grid_g), dim3(64), (size_t)diag_env("ZARC_GPU_DEC_PADLDS", 0), sa,
+                           (const uint8_t *)d_frames_base, h->d_frame_off.as<uint64_t>(), h->d_frame_len.as<uint64_t>(), (uint8_t *)d_dst_base,
+                           h->d_dst_off.as<uint64_t>(), h->d_raw_len.as<uint64_t>(), h->d_order.as<uint32_t>() + f0, (uint32_t)ng,
+                           h->d_declit.as<uint8_t>() + (size_t)g * (dec_grid / (size_t)groups) * (size_t)(ZARC_BLOCK + 64),
+                           h->d_status.as<int32_t>(), h->d_stored_ck.as<uint32_t>(), dec_dbg, h->d_queue.as<uint32_t>() + 2 * g + 1,
+                           fastpath ? h->d_fast.as<uint32_t>() : (const uint32_t *)nullptr);
         ZHIP(hipGetLastError());
+        ZHIP(hipEventRecord(ev[5], sa));
+        // verification passes over the decoded bytes (K2 + XXH64 inside libzstd in the reference): checksum (side stream) and digest
+        // next to each other
+        ZHIP(hipStreamWaitEvent(sb, ev[5], 0));
+        ZHIP(hipEventRecord(ev[6], sb));
+        hipLaunchKernelGGL(zarc_xxh64, dim3((unsigned)((ng * 4 + 255) / 256)), dim3(256), 0, sb, (const uint8_t *)d_dst_base, h->d_dst_off.as<uint64_t>() + f0,
+                           h->d_raw_len.as<uint64_t>() + f0, (uint32_t)ng, h->d_xxh.as<uint64_t>() + f0);
+        ZHIP(hipGetLastError());
+        ZHIP(hipEventRecord(ev[7], sb));
+        ZHIP(hipEventRecord(ev[8], sa));
+        {
+            const uint64_t chunks = gchunk0[g + 1] - gchunk0[g];
+            hipLaunchKernelGGL(zarc_blake3_chunks, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, sa, (const uint8_t *)d_dst_base, h->d_dst_off.as<uint64_t>() + f0,
+                               h->d_raw_len.as<uint64_t>() + f0, h->d_chunk_prefix.as<uint64_t>() + f0 + (size_t)g, (uint32_t)ng, chunks,
+                               h->d_cvs.as<uint32_t>() + gchunk0[g] * 8, h->d_digests.as<uint32_t>() + f0 * 8);
+            hipLaunchKernelGGL(zarc_blake3_tree, dim3((unsigned)std::min<size_t>(ng, 65535)), dim3(256), 0, sa, h->d_chunk_prefix.as<uint64_t>() + f0 + (size_t)g, (uint32_t)ng,
+                               h->d_cvs.as<uint32_t>() + gchunk0[g] * 8, h->d_cvs_tmp.as<uint32_t>() + gchunk0[g] * 8, h->d_digests.as<uint32_t>() + f0 * 8);
+            ZHIP(hipGetLastError());
+        }
+        ZHIP(hipEventRecord(ev[9], sa));
     }
-    // frames the fast path turned down (or all of them when it is off) are decoded inline; with nothing to do every wave leaves at once
-    hipLaunchKernelGGL(zarc_zstd_decode, dim3((unsigned)dec_grid), dim3(64), (size_t)diag_env("ZARC_GPU_DEC_PADLDS", 0), h->stream,
-                       (const uint8_t *)d_frames_base, h->d_frame_off.as<uint64_t>(), h->d_frame_len.as<uint64_t>(), (uint8_t *)d_dst_base,
-                       h->d_dst_off.as<uint64_t>(), h->d_raw_len.as<uint64_t>(), h->d_order.as<uint32_t>(), (uint32_t)n, h->d_declit.as<uint8_t>(),
-                       h->d_status.as<int32_t>(), h->d_stored_ck.as<uint32_t>(), dec_dbg, h->d_queue.as<uint32_t>() + 1,
-                       fastpath ? h->d_fast.as<uint32_t>() : (const uint32_t *)nullptr);
-    ZHIP(hipGetLastError());
-    ZHIP(hipEventRecord(h->ev_dec[5], h->stream));
+    // join: the decode time ends with the last group's frame pass, the whole call with the last hash
+    for (int g = 0; g < groups; g++) if (groups > 1) ZHIP(hipStreamWaitEvent(h->stream, h->ev_g[g][5], 0));
     ZHIP(t.mark(&e1));
-    // verification passes over the decoded bytes (K2 + XXH64 inside libzstd in the reference)
-    ZHIP(hipEventRecord(h->ev_fork, h->stream)); // checksum (side stream) and digest run next to each other
-    ZHIP(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
-    ZHIP(hipEventRecord(h->ev[14], h->stream2));
-    if ((rc = run_xxh64(h, n, (const uint8_t *)d_dst_base, h->d_dst_off.as<uint64_t>(), h->d_raw_len.as<uint64_t>(), h->stream2))) return rc;
-    ZHIP(hipEventRecord(h->ev[15], h->stream2));
-    ZHIP(hipEventRecord(h->ev_join, h->stream2));
-    ZHIP(t.mark(&e2));
-    if ((rc = run_blake3(h, n, (const uint8_t *)d_dst_base, dst_off, raw_len, h->d_dst_off.as<uint64_t>(), h->d_raw_len.as<uint64_t>()))) return rc;
-    ZHIP(hipStreamWaitEvent(h->stream, h->ev_join, 0));
+    for (int g = 0; g < groups; g++) {
+        ZHIP(hipStreamWaitEvent(h->stream, h->ev_g[g][7], 0));
+        if (groups > 1) ZHIP(hipStreamWaitEvent(h->stream, h->ev_g[g][9], 0));
+    }
     ZHIP(t.mark(&e3));
     hipLaunchKernelGGL(zarc_unpack_verdict, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, (uint32_t)n, h->d_xxh.as<uint64_t>(),
-                       h->d_stored_ck.as<uint32_t>(), h->d_digests.as<uint32_t>(), expect ? h->d_expect.as<uint32_t>() : (const uint32_t *)nullptr,
+                       h->d_stored_ck.as<uint32_t>(), h->d_digests.as<uint32_t>(), expect_in ? h->d_expect.as<uint32_t>() : (const uint32_t *)nullptr,
                        h->d_status.as<int32_t>());
     ZHIP(hipGetLastError());
-    ZHIP(hipMemcpyAsync(status, h->d_status.p, n * 4, hipMemcpyDeviceToHost, h->stream));
-    ZHIP(hipMemcpyAsync(digest, h->d_digests.p, n * 32, hipMemcpyDeviceToHost, h->stream));
+    std::vector<int32_t> st(n);
+    std::vector<uint8_t> dg(n * 32);
+    ZHIP(hipMemcpyAsync(st.data(), h->d_status.p, n * 4, hipMemcpyDeviceToHost, h->stream));
+    ZHIP(hipMemcpyAsync(dg.data(), h->d_digests.p, n * 32, hipMemcpyDeviceToHost, h->stream));
     ZHIP(hipStreamSynchronize(h->stream));
+    for (size_t i = 0; i < n; i++) { status[order[i]] = st[i]; memcpy(digest + (size_t)order[i] * 32, &dg[i * 32], 32); }
     if (fastpath && diag_env("ZARC_GPU_DEC_STATS", 0)) { // diagnostics: how many frames had their sequences decoded ahead
         std::vector<uint32_t> fl(n);
         ZHIP(hipMemcpy(fl.data(), h->d_fast.p, n * 4, hipMemcpyDeviceToHost));
         size_t nf = 0;
         for (uint32_t v : fl) nf += v != 0;
-        fprintf(stderr, "zstd_decode: %zu of %zu frames on the fast path\n", nf, n);
+        fprintf(stderr, "zstd_decode: %zu of %zu frames on the fast path, %d group(s)\n", nf, n, groups);
     }
     h->ms[ZARC_GPU_T_DECODE] = elapsed(h, e0, e1);
-    { float ms = -1.f;
-      if (have_seq_t && hipEventElapsedTime(&ms, h->ev_dec[0], h->ev_dec[1]) == hipSuccess) h->ms[ZARC_GPU_T_DEC_SEQS] = ms;
-      if (have_lit_t && hipEventElapsedTime(&ms, h->ev_dec[2], h->ev_dec[3]) == hipSuccess) h->ms[ZARC_GPU_T_DEC_LITS] = ms;
-      if (hipEventElapsedTime(&ms, h->ev_dec[4], h->ev_dec[5]) == hipSuccess) h->ms[ZARC_GPU_T_DEC_FRAMES] = ms; }
-    h->ms[ZARC_GPU_T_XXH64] = elapsed(h, 14, 15); // side stream: overlaps the digest pass
-    h->ms[ZARC_GPU_T_BLAKE3] = elapsed(h, e2, e3);
+    // per-kernel times: sums over the groups (with several groups the kernels of different groups overlap, so the sums exceed T_DECODE)
+    float t_seq = 0, t_lit = 0, t_frm = 0, t_xxh = 0, t_b3 = 0;
+    for (int g = 0; g < groups; g++) {
+        float ms = 0;
+        hipEvent_t *ev = h->ev_g[g];
+        if (have_seq_t[g] && hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) t_seq += ms;
+        if (have_lit_t[g] && hipEventElapsedTime(&ms, ev[2], ev[3]) == hipSuccess) t_lit += ms;
+        if (hipEventElapsedTime(&ms, ev[4], ev[5]) == hipSuccess) t_frm += ms;
+        if (hipEventElapsedTime(&ms, ev[6], ev[7]) == hipSuccess) t_xxh += ms;
+        if (hipEventElapsedTime(&ms, ev[8], ev[9]) == hipSuccess) t_b3 += ms;
+    }
+    h->ms[ZARC_GPU_T_DEC_SEQS] = t_seq; h->ms[ZARC_GPU_T_DEC_LITS] = t_lit; h->ms[ZARC_GPU_T_DEC_FRAMES] = t_frm;
+    h->ms[ZARC_GPU_T_XXH64] = t_xxh; // side stream: overlaps the digest pass
+    h->ms[ZARC_GPU_T_BLAKE3] = t_b3;
     h->ms[ZARC_GPU_T_TOTAL] = elapsed(h, e0, e3);
     return ZARC_GPU_OK;
 }

@@ -88,7 +88,7 @@ __global__ void zarc_zdec_scan(const uint8_t *frames_base, const uint64_t *frame
                                uint32_t *fast);
 // Huffman literals of the fast path: one wave per ZDEC_LIT_GROUP block slots (tables in LDS, one stream per lane) -> lits[]
 __global__ void zarc_zdec_literals(const uint8_t *frames_base, const uint64_t *frame_off, uint64_t n_slots, const uint64_t *slot_prefix,
-                                   const ZdecBlock *zblocks, const uint64_t *lit_index, uint8_t *lits, uint32_t *fast);
+                                   const ZdecBlock *zblocks, const uint64_t *lit_index, uint8_t *lits, uint32_t *fast, uint64_t slot_base);
 // stage 2 with the tables in LDS: one wave of ZDEC_LDS_LANES active lanes per workgroup
 __global__ void zarc_zdec_seqs_lds(const uint8_t *frames_base, const uint64_t *frame_off, uint64_t n_slots, const uint64_t *slot_prefix,
                                    ZdecBlock *zblocks, const uint64_t *seq_index, uint64_t *seqs, uint32_t *fast, uint64_t slot_base);

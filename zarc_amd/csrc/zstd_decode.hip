@@ -1595,11 +1595,12 @@ __device__ bool huf_decode_stream_canon(const HufCanon &C, int max_bits, const u
 
 __global__ void __launch_bounds__(64) zarc_zdec_literals(const uint8_t *__restrict__ frames_base, const uint64_t *__restrict__ frame_off, uint64_t n_slots,
                                                          const uint64_t *__restrict__ slot_prefix, const ZdecBlock *__restrict__ zblocks,
-                                                         const uint64_t *__restrict__ lit_index, uint8_t *__restrict__ lits, uint32_t *__restrict__ fast)
+                                                         const uint64_t *__restrict__ lit_index, uint8_t *__restrict__ lits, uint32_t *__restrict__ fast,
+                                                         uint64_t slot_base /* slots [slot_base, n_slots) */)
 {
     __shared__ LitLds S;
     const int lane = zd::lane_id();
-    const uint64_t s0 = (uint64_t)blockIdx.x * ZDEC_LIT_GROUP;
+    const uint64_t s0 = slot_base + (uint64_t)blockIdx.x * ZDEC_LIT_GROUP;
     // ---- phase 1: tables ----
     for (int i = 0; i < ZDEC_LIT_GROUP; i++) {
         const uint64_t s = s0 + (uint64_t)i;
