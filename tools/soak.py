@@ -20,6 +20,7 @@ while time.time() < t_end:
     eng = Engine(0)
     eng.set_parameter(_lib.P_COMPRESSION_LEVEL, level)
     eng.set_parameter(_lib.P_CHECKSUM_FLAG, checksum)
+    eng.set_parameter(_lib.PX_DEC_GROUPS, rnd.choice([0, 0, 1, 2, 3, 4]))   # unpack in size groups (0 = the engine's own rule)
     n = rnd.randrange(1, 40)
     ents = []
     for _ in range(n):

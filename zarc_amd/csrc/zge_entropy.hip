@@ -29,18 +29,6 @@ namespace {
 constexpr int HUF_MAXBITS = 11;
 constexpr uint32_t MIN_HUF_LITERALS = 64;
 
-__constant__ const uint32_t E_LL_BASE[36] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18,
-                                             20, 22, 24, 28, 32, 40, 48, 64, 128, 256, 512, 1024, 2048,
-                                             4096, 8192, 16384, 32768, 65536};
-__constant__ const uint8_t E_LL_BITS[36] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1,
-                                            1, 1, 2, 2, 3, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
-__constant__ const uint32_t E_ML_BASE[53] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19,
-                                             20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34,
-                                             35, 37, 39, 41, 43, 47, 51, 59, 67, 83, 99, 131, 259, 515,
-                                             1027, 2051, 4099, 8195, 16387, 32771, 65539};
-__constant__ const uint8_t E_ML_BITS[53] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
-                                            0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1,
-                                            2, 2, 3, 3, 4, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
 __constant__ const int16_t E_LL_DEFAULT[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2,
                                                2, 2, 2, 2, 2, 2, 2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1};
 __constant__ const int16_t E_ML_DEFAULT[53] = {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1,
@@ -48,23 +36,42 @@ __constant__ const int16_t E_ML_DEFAULT[53] = {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 
                                                1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1};
 __constant__ const int16_t E_OF_DEFAULT[29] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1,
                                                1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1};
-__constant__ const uint8_t E_LL_CODE_16_63[48] = {16, 16, 17, 17, 18, 18, 19, 19, 20, 20, 20, 20, 21, 21, 21, 21,
-                                                  22, 22, 22, 22, 22, 22, 22, 22, 23, 23, 23, 23, 23, 23, 23, 23,
-                                                  24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24};
-__constant__ const uint8_t E_ML_LIM[11] = {34, 36, 38, 40, 44, 48, 56, 64, 80, 96, 128};
-
+// Literal-length / match-length codes (RFC 8878 3.1.1.3.2.1.1), and the extra bits of a value, worked out arithmetically: the code
+// tables have a regular shape (runs of 2, 4, 8, ... values per code, then one code per power of two), and a table in memory would be a
+// vector load per sequence in two passes of the coder.
 __device__ __forceinline__ uint32_t ll_code(uint32_t ll)
 {
     if (ll < 16) return ll;
-    if (ll < 64) return E_LL_CODE_16_63[ll - 16];
-    return (uint32_t)zd::hb32(ll) + 19;
+    if (ll >= 64) return (uint32_t)zd::hb32(ll) + 19;
+    if (ll < 24) return 16 + ((ll - 16) >> 1);   // 16..19: two values each
+    if (ll < 32) return 20 + ((ll - 24) >> 2);   // 20, 21: four
+    if (ll < 48) return 22 + ((ll - 32) >> 3);   // 22, 23: eight
+    return 24;                                   // 48..63
 }
 __device__ __forceinline__ uint32_t ml_code(uint32_t ml)
 {
     const uint32_t b = ml - 3;
     if (b < 32) return b;
-    if (b < 128) { uint32_t c = 0; while (b >= E_ML_LIM[c]) c++; return 32 + c; }
-    return (uint32_t)zd::hb32(b) + 36;
+    if (b >= 128) return (uint32_t)zd::hb32(b) + 36;
+    if (b < 40) return 32 + ((b - 32) >> 1);     // 32..35: two values each
+    if (b < 48) return 36 + ((b - 40) >> 2);     // 36, 37: four
+    if (b < 64) return 38 + ((b - 48) >> 3);     // 38, 39: eight
+    if (b < 96) return 40 + ((b - 64) >> 4);     // 40, 41: sixteen
+    return 42;                                   // 96..127
+}
+// number of extra bits of a code and the extra-bits value of `v` (v minus the code's baseline = its low bits: every run of a code
+// starts at a multiple of its length)
+__device__ __forceinline__ uint32_t ll_extra(uint32_t ll, uint32_t code, uint32_t *bits)
+{
+    const uint32_t nb = code < 16 ? 0u : (code >= 25 ? code - 19 : (uint32_t)((0x433221111ull >> (4 * (code - 16))) & 15));
+    *bits = nb;
+    return ll & ((1u << nb) - 1); // baselines 16, 18, .. 24, 28, 32, 40, 48, 64, 128, ..: all multiples of 2^nb
+}
+__device__ __forceinline__ uint32_t ml_extra(uint32_t ml, uint32_t code, uint32_t *bits)
+{
+    const uint32_t nb = code < 32 ? 0u : (code >= 43 ? code - 36 : (uint32_t)((0x54433221111ull >> (4 * (code - 32))) & 15));
+    *bits = nb;
+    return (ml - 3) & ((1u << nb) - 1); // baselines - 3 = 32, 34, .. 40, 44, 48, 56, 64, 80, 96, 128, ..: multiples of 2^nb
 }
 
 // ---- lane-serial bit writer into a byte buffer (LDS or global) ----
@@ -108,7 +115,7 @@ struct EntLds {
             uint8_t tmp[192], hdesc[192];
         } h;
         struct {
-            uint16_t st_ll[512], st_ml[512], st_of[256];
+            uint16_t st[1280];     // state tables: LL at 0, ML at 512, OF at 1024 (one array: the chains index it with the table's start folded into the symbol constant)
             int32_t dnb_ll[36], dfs_ll[36], dnb_ml[53], dfs_ml[53], dnb_of[32], dfs_of[32];
             uint32_t cl[36], co[32], cm[53];
             int16_t norm[3][64];
@@ -117,6 +124,7 @@ struct EntLds {
         } s;
     };
 };
+enum { ST_LL = 0, ST_ML = 512, ST_OF = 1024 };
 enum { X_TMP = 0, X_DLEN = 1, X_MODE_L = 2, X_MODE_O = 3, X_MODE_M = 4, X_AL_L = 5, X_AL_O = 6, X_AL_M = 7, X_DL_L = 8, X_DL_O = 9,
        X_DL_M = 10, X_RLE_L = 11, X_RLE_O = 12, X_RLE_M = 13, X_NSYM_L = 14, X_NSYM_O = 15, X_NSYM_M = 16, X_MAXBITS = 17, X_NSYM_LAST = 18 };
 
@@ -706,8 +714,8 @@ __global__ void __launch_bounds__(64, 5) zarc_zge_entropy(uint32_t n_blocks, Zge
                 const int16_t *def = which == 0 ? E_LL_DEFAULT : (which == 1 ? E_OF_DEFAULT : E_ML_DEFAULT);
                 choose_table(L, which, cnt, which == 0 ? 35 : (which == 1 ? 31 : 52), nseq, def, which == 0 ? 36 : (which == 1 ? 29 : 53),
                              which == 1 ? 5 : 6, which == 1 ? 8 : 9);
-                FseCtab tt = which == 0 ? FseCtab{L.s.st_ll, L.s.dnb_ll, L.s.dfs_ll, 0}
-                                        : (which == 1 ? FseCtab{L.s.st_of, L.s.dnb_of, L.s.dfs_of, 0} : FseCtab{L.s.st_ml, L.s.dnb_ml, L.s.dfs_ml, 0});
+                FseCtab tt = which == 0 ? FseCtab{L.s.st + ST_LL, L.s.dnb_ll, L.s.dfs_ll, 0}
+                                        : (which == 1 ? FseCtab{L.s.st + ST_OF, L.s.dnb_of, L.s.dfs_of, 0} : FseCtab{L.s.st + ST_ML, L.s.dnb_ml, L.s.dfs_ml, 0});
                 uint8_t *cells = (uint8_t *)L.s.pre + (which == 0 ? 0 : (which == 1 ? 512 : 768)); // 512 + 256 + 512 bytes
                 if (L.ctrl[X_MODE_L + which] != 1) fse_build_ctab(tt, L.s.norm[which], L.ctrl[X_NSYM_L + which], L.ctrl[X_AL_L + which], cells);
             }
@@ -727,11 +735,7 @@ __global__ void __launch_bounds__(64, 5) zarc_zge_entropy(uint32_t n_blocks, Zge
                 }
                 pos += 1 + (mode_l == 1 ? 1u : dl_l) + (mode_o == 1 ? 1u : dl_o) + (mode_m == 1 ? 1u : dl_m);
                 // FSE state chains: lane 0 = LL, lane 1 = OF, lane 2 = ML; 64 sequences per round, last -> first
-                FseCtab ct;
-                int my_mode = 1;
-                if (lane == 0) { ct = FseCtab{L.s.st_ll, L.s.dnb_ll, L.s.dfs_ll, al_l}; my_mode = mode_l; }
-                else if (lane == 1) { ct = FseCtab{L.s.st_of, L.s.dnb_of, L.s.dfs_of, al_o}; my_mode = mode_o; }
-                else { ct = FseCtab{L.s.st_ml, L.s.dnb_ml, L.s.dfs_ml, al_m}; my_mode = lane == 2 ? mode_m : 1; }
+                const int my_mode = lane == 0 ? mode_l : (lane == 1 ? mode_o : (lane == 2 ? mode_m : 1));
                 uint32_t state = 0;
                 WavePacker pk;
                 pk.begin(L.stage, so + pos, scap - pos, lane);
@@ -745,33 +749,34 @@ __global__ void __launch_bounds__(64, 5) zarc_zge_entropy(uint32_t n_blocks, Zge
                         llc = ll_code(ll); mlc = ml_code(ml); ofc = (uint32_t)zd::hb32(ofv);
                         // per-symbol transition constants fetched by all lanes at once: the serial loop below then has a
                         // single dependent LDS access per step (the state table)
-                        L.s.pre[0][lane] = (uint32_t)L.s.dnb_ll[llc] | ((uint64_t)(uint32_t)L.s.dfs_ll[llc] << 32);
-                        L.s.pre[1][lane] = (uint32_t)L.s.dnb_of[ofc] | ((uint64_t)(uint32_t)L.s.dfs_of[ofc] << 32);
-                        L.s.pre[2][lane] = (uint32_t)L.s.dnb_ml[mlc] | ((uint64_t)(uint32_t)L.s.dfs_ml[mlc] << 32);
+                        L.s.pre[0][lane] = (uint32_t)L.s.dnb_ll[llc] | ((uint64_t)(uint32_t)(2 * (L.s.dfs_ll[llc] + ST_LL)) << 32); // byte offset into st[]
+                        L.s.pre[1][lane] = (uint32_t)L.s.dnb_of[ofc] | ((uint64_t)(uint32_t)(2 * (L.s.dfs_of[ofc] + ST_OF)) << 32);
+                        L.s.pre[2][lane] = (uint32_t)L.s.dnb_ml[mlc] | ((uint64_t)(uint32_t)(2 * (L.s.dfs_ml[mlc] + ST_ML)) << 32);
                     }
                     zd::wave_sync();
                     if (lane < 3 && my_mode != 1) {
                         // The chain does the bare minimum per step -- remember the state, find the next one (one dependent LDS access);
                         // the bits each step emits follow from (state before, symbol constant) and are worked out by all lanes below.
-                        uint64_t nxt = L.s.pre[lane][0];
+                        // Four steps per trip: their symbol constants are fetched together and the loop bookkeeping is paid once.
+                        uint64_t *const pp = L.s.pre[lane];
                         uint32_t e = 0;
                         if (done == 0) { // first symbol coded: the state that needs no bits (fse_init_state)
-                            const int32_t d = (int32_t)(uint32_t)nxt, f = (int32_t)(uint32_t)(nxt >> 32);
+                            const uint64_t c0 = pp[0];
+                            const int32_t d = (int32_t)(uint32_t)c0, f = (int32_t)(uint32_t)(c0 >> 32);
                             const int nb0 = (d + (1 << 15)) >> 16;
                             const int value = (nb0 << 16) - d;
-                            state = ct.state_tab[(value >> nb0) + f];
+                            state = *(const uint16_t *)((const uint8_t *)L.s.st + (2 * (value >> nb0) + f));
                             e = 1;
-                            if (cnt > 1) nxt = L.s.pre[lane][1];
                         }
-                        for (; e < cnt; e++) {
-                            const uint64_t cur = nxt;
-                            if (e + 1 < cnt) nxt = L.s.pre[lane][e + 1]; // independent of the state: in flight during the step
-                            const uint32_t d = (uint32_t)cur;
-                            const int32_t f = (int32_t)(uint32_t)(cur >> 32);
-                            ((uint32_t *)&L.s.pre[lane][e])[1] = state; // the state this step starts from, in place of dfs
-                            const uint32_t nb_ = (state + d) >> 16;
-                            state = ct.state_tab[(int)(state >> nb_) + f];
+#define CHAIN_STEP(cur, at) do { ((uint32_t *)&pp[at])[1] = state; /* the state this step starts from, in place of dfs */ \
+                                 const uint32_t nb_ = (state + (uint32_t)(cur)) >> 16;                                     \
+                                 state = *(const uint16_t *)((const uint8_t *)L.s.st + ((int)((state >> nb_) << 1) + (int32_t)(uint32_t)((cur) >> 32))); } while (0)
+                        for (; e + 4 <= cnt; e += 4) {
+                            const uint64_t c0 = pp[e], c1 = pp[e + 1], c2 = pp[e + 2], c3 = pp[e + 3];
+                            CHAIN_STEP(c0, e); CHAIN_STEP(c1, e + 1); CHAIN_STEP(c2, e + 2); CHAIN_STEP(c3, e + 3);
                         }
+                        for (; e < cnt; e++) { const uint64_t c0 = pp[e]; CHAIN_STEP(c0, e); }
+#undef CHAIN_STEP
                     }
                     zd::wave_sync();
                     uint64_t lo = 0;
@@ -790,8 +795,9 @@ __global__ void __launch_bounds__(64, 5) zarc_zge_entropy(uint32_t n_blocks, Zge
                         uint64_t acc = bo & 0xFFFF; uint32_t sh = bo >> 16;
                         acc |= (uint64_t)(bm & 0xFFFF) << sh; sh += bm >> 16;
                         acc |= (uint64_t)(bl & 0xFFFF) << sh; sh += bl >> 16;                     // <= 27 bits
-                        acc |= (uint64_t)(ll - E_LL_BASE[llc]) << sh; sh += E_LL_BITS[llc];      // <= 43
-                        acc |= (uint64_t)(ml - E_ML_BASE[mlc]) << sh; sh += E_ML_BITS[mlc];      // <= 59
+                        uint32_t xb;
+                        acc |= (uint64_t)ll_extra(ll, llc, &xb) << sh; sh += xb;                  // <= 43
+                        acc |= (uint64_t)ml_extra(ml, mlc, &xb) << sh; sh += xb;                  // <= 59
                         const uint64_t ofx = (uint64_t)(ofv - (1u << ofc));
                         lo = acc | (ofx << sh);
                         hi = sh == 0 ? 0u : (uint32_t)(ofx >> (64 - sh));
