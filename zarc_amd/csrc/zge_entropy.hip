@@ -435,7 +435,11 @@ struct WavePacker {
         const uint32_t bits = carry + total, full = bits >> 3;
         const uint8_t *sb = (const uint8_t *)stage;
         if (pos + full + 1 > cap) overflow = true; // keep one byte for the final partial byte
-        if (!overflow) for (uint32_t i = (uint32_t)lane; i < full; i += 64) dst[pos + i] = sb[i];
+        if (!overflow) { // whole words first (no alignment needed for the store), then the last 1..3 bytes
+            const uint32_t fw = full >> 2;
+            for (uint32_t i = (uint32_t)lane; i < fw; i += 64) { const uint32_t w = stage[i]; __builtin_memcpy(dst + pos + 4 * i, &w, 4); }
+            if ((uint32_t)lane < (full & 3)) dst[pos + 4 * fw + (uint32_t)lane] = sb[4 * fw + (uint32_t)lane];
+        }
         const uint32_t keep = (bits & 7) ? (uint32_t)sb[full] : 0u;
         zd::wave_sync();
         const uint32_t words = (bits + 31) / 32 + 1;
@@ -488,10 +492,17 @@ __global__ void __launch_bounds__(64, 5) zarc_zge_entropy(uint32_t n_blocks, Zge
         { // literal buffers start 16-byte aligned: four bytes per load
             const uint32_t n4 = n / 4;
             const uint32_t *l4 = (const uint32_t *)lit;
-            for (uint32_t i = (uint32_t)lane; i < n4; i += 64) {
-                const uint32_t w = l4[i];
-                atomicAdd(&L.h.count[w & 0xFF], 1u); atomicAdd(&L.h.count[(w >> 8) & 0xFF], 1u);
-                atomicAdd(&L.h.count[(w >> 16) & 0xFF], 1u); atomicAdd(&L.h.count[w >> 24], 1u);
+            for (uint32_t i0 = 0; i0 < n4; i0 += 256) { // four loads in flight per lane
+                uint32_t wv[4];
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) { const uint32_t i = i0 + 64 * k + (uint32_t)lane; wv[k] = i < n4 ? l4[i] : 0u; }
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) {
+                    if (i0 + 64 * k + (uint32_t)lane >= n4) continue;
+                    const uint32_t w = wv[k];
+                    atomicAdd(&L.h.count[w & 0xFF], 1u); atomicAdd(&L.h.count[(w >> 8) & 0xFF], 1u);
+                    atomicAdd(&L.h.count[(w >> 16) & 0xFF], 1u); atomicAdd(&L.h.count[w >> 24], 1u);
+                }
             }
             for (uint32_t i = n4 * 4 + (uint32_t)lane; i < n; i += 64) atomicAdd(&L.h.count[lit[i]], 1u);
         }
@@ -536,15 +547,24 @@ __global__ void __launch_bounds__(64, 5) zarc_zge_entropy(uint32_t n_blocks, Zge
                     if (k >= nstreams) break;
                     const uint32_t beg = k * per, cnt = single ? n : (k < 3 ? per : n - 3 * per);
                     pk.begin(L.stage, body + pos, out_cap - hdr - pos, lane);
-                    for (uint32_t j0 = 0; j0 < cnt; j0 += 256) { // four symbols (<= 44 bits) per lane and step: a quarter of the prefix sums / flushes
-                        const uint32_t j = j0 + 4 * (uint32_t)lane;
-                        uint64_t cv = 0;
-                        uint32_t cl_ = 0;
+                    for (uint32_t j0 = 0; j0 < cnt; j0 += 512) { // eight symbols (<= 88 bits) per lane and step: an eighth of the prefix sums / flushes
+                        const uint32_t j = j0 + 8 * (uint32_t)lane;
+                        uint64_t ca = 0, cb = 0;     // codes of symbols 0..3 and 4..7 of this lane (the stream runs from the last literal down)
+                        uint32_t na = 0, nb_ = 0;
+                        if (j + 8 <= cnt) {          // the eight bytes in one load (literal buffers are plain memory: no alignment needed)
+                            uint64_t w;
+                            __builtin_memcpy(&w, lit + beg + cnt - 8 - j, 8);
 #pragma unroll
-                        for (uint32_t q = 0; q < 4; q++) {
-                            if (j + q < cnt) { const uint32_t e = L.code[lit[beg + cnt - 1 - j - q]]; cv |= (uint64_t)(e & 0x7FF) << cl_; cl_ += e >> 11; }
+                            for (uint32_t q = 0; q < 4; q++) { const uint32_t e = L.code[(w >> (8 * (7 - q))) & 0xFF]; ca |= (uint64_t)(e & 0x7FF) << na; na += e >> 11; }
+#pragma unroll
+                            for (uint32_t q = 4; q < 8; q++) { const uint32_t e = L.code[(w >> (8 * (7 - q))) & 0xFF]; cb |= (uint64_t)(e & 0x7FF) << nb_; nb_ += e >> 11; }
+                        } else if (j < cnt) {
+                            for (uint32_t q = 0; q < 4 && j + q < cnt; q++) { const uint32_t e = L.code[lit[beg + cnt - 1 - j - q]]; ca |= (uint64_t)(e & 0x7FF) << na; na += e >> 11; }
+                            for (uint32_t q = 4; q < 8 && j + q < cnt; q++) { const uint32_t e = L.code[lit[beg + cnt - 1 - j - q]]; cb |= (uint64_t)(e & 0x7FF) << nb_; nb_ += e >> 11; }
                         }
-                        pk.put(cv, 0, cl_, lane);
+                        const uint64_t lo = ca | (na < 64 ? cb << na : 0ull);
+                        const uint32_t hi = na ? (uint32_t)(cb >> (64 - na)) : 0u; // na <= 44 and cb < 2^44: at most 24 bits
+                        pk.put(lo, hi, na + nb_, lane);
                     }
                     ssz[k] = pk.finish(lane);
                     if (pk.overflow) fail = true;
@@ -609,10 +629,12 @@ __global__ void __launch_bounds__(64, 5) zarc_zge_entropy(uint32_t n_blocks, Zge
         uint32_t out = 0;                       // heads so far, including the pending one
         uint32_t pend_lp = 0, pend_ml = 0, pend_o = 0, c_lp = 0, c_o = 0; // pending head; literal position / offset of the previous round's last sequence
         bool have_pend = false;
+        uint64_t s_next = (uint32_t)lane < nseq ? seq[lane] : 0; // every pass over the sequences requests its next round before it works on this one
         for (uint32_t base = 0; base < nseq; base += 64) {
             const uint32_t cnt = nseq - base < 64 ? nseq - base : 64;
             const bool valid = (uint32_t)lane < cnt;
-            const uint64_t s = valid ? seq[base + (uint32_t)lane] : 0;
+            const uint64_t s = valid ? s_next : 0;
+            if (base + 64 + (uint32_t)lane < nseq) s_next = seq[base + 64 + (uint32_t)lane]; // (this round stores below base + 64 only)
             const uint32_t lp = zge_seq_ll(s), ml = valid ? zge_seq_ml(s) : 0u, o = zge_seq_ofv(s);
             uint32_t plp = zd::shfl_up(lp, 1), po = zd::shfl_up(o, 1);
             if (lane == 0) { plp = c_lp; po = c_o; }
@@ -642,10 +664,12 @@ __global__ void __launch_bounds__(64, 5) zarc_zge_entropy(uint32_t n_blocks, Zge
     }
     {
         uint32_t r0 = 0, r1 = 0, r2 = 0, carry = 0; // wave-uniform history / literal position carried between rounds
+        uint64_t s_next = (uint32_t)lane < nseq ? seq[lane] : 0;
         for (uint32_t base = 0; base < nseq; base += 64) {
             const uint32_t cnt = nseq - base < 64 ? nseq - base : 64;
             const bool valid = (uint32_t)lane < cnt;
-            const uint64_t s = valid ? seq[base + (uint32_t)lane] : 0;
+            const uint64_t s = valid ? s_next : 0;
+            if (base + 64 + (uint32_t)lane < nseq) s_next = seq[base + 64 + (uint32_t)lane];
             const uint32_t litpos = zge_seq_ll(s), ml = zge_seq_ml(s), o = zge_seq_ofv(s);
             uint32_t prev = zd::shfl_up(litpos, 1);
             if (lane == 0) prev = carry;
@@ -699,11 +723,17 @@ __global__ void __launch_bounds__(64, 5) zarc_zge_entropy(uint32_t n_blocks, Zge
             for (int i = lane; i < 32; i += 64) L.s.co[i] = 0;
             for (int i = lane; i < 53; i += 64) L.s.cm[i] = 0;
             zd::wave_sync();
-            for (uint32_t i = (uint32_t)lane; i < nseq; i += 64) {
-                const uint64_t s = seq[i];
-                atomicAdd(&L.s.cl[ll_code(zge_seq_ll(s))], 1u);
-                atomicAdd(&L.s.cm[ml_code(zge_seq_ml(s))], 1u);
-                atomicAdd(&L.s.co[zd::hb32(zge_seq_ofv(s))], 1u);
+            for (uint32_t i0 = 0; i0 < nseq; i0 += 256) { // four loads in flight per lane
+                uint64_t sv[4];
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) { const uint32_t i = i0 + 64 * k + (uint32_t)lane; sv[k] = i < nseq ? seq[i] : 0; }
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) {
+                    if (i0 + 64 * k + (uint32_t)lane >= nseq) continue;
+                    atomicAdd(&L.s.cl[ll_code(zge_seq_ll(sv[k]))], 1u);
+                    atomicAdd(&L.s.cm[ml_code(zge_seq_ml(sv[k]))], 1u);
+                    atomicAdd(&L.s.co[zd::hb32(zge_seq_ofv(sv[k]))], 1u);
+                }
             }
             zd::wave_sync();
             if (lane < 3) {
@@ -739,12 +769,14 @@ __global__ void __launch_bounds__(64, 5) zarc_zge_entropy(uint32_t n_blocks, Zge
                 uint32_t state = 0;
                 WavePacker pk;
                 pk.begin(L.stage, so + pos, scap - pos, lane);
+                uint64_t s_next = (uint32_t)lane < nseq ? seq[nseq - 1 - (uint32_t)lane] : 0;
                 for (uint32_t done = 0; done < nseq; done += 64) {
                     const uint32_t cnt = nseq - done < 64 ? nseq - done : 64;
-                    // element e of this round is sequence index (nseq-1-done-e); lane e loads and classifies it
+                    // element e of this round is sequence index (nseq-1-done-e); lane e classifies it (requested a round ahead)
                     uint32_t ll = 0, ml = 3, ofv = 1, llc = 0, mlc = 0, ofc = 0;
+                    const uint64_t s = s_next;
+                    if (done + 64 + (uint32_t)lane < nseq) s_next = seq[nseq - 1 - done - 64 - (uint32_t)lane];
                     if ((uint32_t)lane < cnt) {
-                        const uint64_t s = seq[nseq - 1 - done - (uint32_t)lane];
                         ll = zge_seq_ll(s); ml = zge_seq_ml(s); ofv = zge_seq_ofv(s);
                         llc = ll_code(ll); mlc = ml_code(ml); ofc = (uint32_t)zd::hb32(ofv);
                         // per-symbol transition constants fetched by all lanes at once: the serial loop below then has a
