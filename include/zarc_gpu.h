@@ -80,7 +80,7 @@ enum {
     ZARC_GPU_P_DICT_ID_FLAG = 202,
     /* Engine tuning, not libzstd ids: how a batch is cut up, never what bytes come out (frames are identical for every value).
      * The library reads NO environment variable; these are the only switches. */
-    ZARC_GPU_PX_SCRATCH_MB = 9001,   /* encoder scratch budget in MiB (0 = up to 64 GiB / 45 % of free HBM): batches beyond it run as sub-batches */
+    ZARC_GPU_PX_SCRATCH_MB = 9001,   /* scratch budget in MiB (0 = encoder: up to 64 GiB / 45 % of free HBM; decoder: what the device has): batches beyond it run as sub-batches */
     ZARC_GPU_PX_STAGE_CHUNK = 9002,  /* host-pointer entry points: content bytes per staged chunk (0 = 2 GiB pack / 4 GiB unpack; >= 4096)         */
     ZARC_GPU_PX_STAGE_THREAD = 9003, /* 1 (default) = a helper thread moves neighbouring chunks over PCIe while the kernels run                     */
     ZARC_GPU_PX_COPY_THREADS = 9004, /* host threads that fill / drain the pinned staging ring (default 8)                                          */

@@ -87,6 +87,18 @@ def test_emu_pack_in_sub_batches(emu_engine, oracle, corpus, libzstds):
         emu_engine.set_parameter(_lib.PX_SCRATCH_MB, 0)
 
 
+def test_emu_unpack_in_sub_batches(emu_engine, oracle, corpus, golden_frames):
+    """A batch whose decoder scratch (sequences / literals decoded ahead, tables) exceeds the budget is unpacked in halves that may
+    split again (engine.hip, unpack_device_split): same bytes, digests, statuses, in the caller's order."""
+    emu_engine.set_parameter(_lib.PX_SCRATCH_MB, 1)
+    try:
+        pc.check_unpack_golden(emu_engine, oracle, corpus, golden_frames, limit=140000)
+        pc.check_unpack_errors(emu_engine, oracle, corpus, golden_frames)
+        pc.check_roundtrip(emu_engine, oracle, corpus, big=False)
+    finally:
+        emu_engine.set_parameter(_lib.PX_SCRATCH_MB, 0)
+
+
 def test_emu_level9_deep_finder_matches_model(emu_lib_path, oracle, corpus):
     """Level >= 9 launches the deep match finder (2^14-entry tables, one workgroup per CU): frames bit-identical to the model."""
     from zarc_amd import Engine, _lib

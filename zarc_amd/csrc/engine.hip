@@ -596,14 +596,14 @@ int zarc_gpu_pack_batch_device(zarc_gpu_t *h, size_t n, const void *d_src_base, 
 // descending size and dealt into up to DEC_GROUPS groups of equal bytes, each group with its own pair of streams: the frame pass and
 // the hashes of the large frames start as soon as THEIR sequences and literals are decoded and run beside the earlier stages of the
 // groups behind them.  Per-frame arrays are uploaded in that order (group = index range = slot range); results go back in the caller's.
-int zarc_gpu_unpack_batch_device(zarc_gpu_t *h, size_t n, const void *d_frames_base, const uint64_t *frame_off_in, const uint64_t *frame_len_in,
-                                 void *d_dst_base, const uint64_t *dst_off_in, const uint64_t *raw_len_in, const uint8_t *expect_in, uint8_t *digest,
-                                 int *status)
+namespace {
+constexpr int UNPACK_SPLIT = -1000; // internal: the decoder's scratch for this batch exceeds the budget, run it in two parts
+
+int unpack_device_once(zarc_gpu_t *h, size_t n, const void *d_frames_base, const uint64_t *frame_off_in, const uint64_t *frame_len_in,
+                       void *d_dst_base, const uint64_t *dst_off_in, const uint64_t *raw_len_in, const uint8_t *expect_in, uint8_t *digest,
+                       int *status)
 {
-    int rc = check_common(h, n);
-    if (rc) return rc;
-    if (n == 0) return ZARC_GPU_OK;
-    if (!d_frames_base || !frame_off_in || !frame_len_in || !d_dst_base || !dst_off_in || !raw_len_in || !digest || !status) return ZARC_GPU_E_PARAM;
+    int rc = 0;
     uint64_t total_raw = 0;
     for (size_t i = 0; i < n; i++) {
         if (dst_off_in[i] % ZARC_GPU_ALIGN) { set_error(h, "output offset not 16-byte aligned"); return ZARC_GPU_E_PARAM; }
@@ -698,6 +698,7 @@ int zarc_gpu_unpack_batch_device(zarc_gpu_t *h, size_t n, const void *d_frames_b
         uint64_t total = 0, lit_total = 0;
         for (size_t i = 0; i < nslots; i++) { seqidx[i] = total; total += counts[2 * i]; litidx[i] = lit_total; lit_total += counts[2 * i + 1]; }
         seqidx[nslots] = total; litidx[nslots] = lit_total;
+        if (h->scratch_budget && n > 1 && total * 8 + lit_total + nslots * (uint64_t)(ZDEC_TABLE_CELLS * 2 + sizeof(ZdecBlock) + 32) > h->scratch_budget) return UNPACK_SPLIT;
         if ((rc = upload_u64(h, h->d_seqidx, seqidx.data(), nslots))) return rc;
         if ((rc = upload_u64(h, h->d_litidx, litidx.data(), nslots))) return rc;
         ZHIP(h->d_seqs.reserve(std::max<uint64_t>(total, 1) * 8));
@@ -849,6 +850,48 @@ int zarc_gpu_unpack_batch_device(zarc_gpu_t *h, size_t n, const void *d_frames_b
     h->ms[ZARC_GPU_T_BLAKE3] = t_b3;
     h->ms[ZARC_GPU_T_TOTAL] = elapsed(h, e0, e3);
     return ZARC_GPU_OK;
+}
+
+// A batch whose decoder scratch (sequences and literals decoded ahead, tables) does not fit -- the budget of ZARC_GPU_PX_SCRATCH_MB, or
+// the device itself -- is unpacked in two halves, each of which may split again; the scratch is reused between them.  Frames are
+// independent, so nothing changes but the time.
+int unpack_device_split(zarc_gpu_t *h, size_t n, const void *d_frames_base, const uint64_t *frame_off, const uint64_t *frame_len,
+                        void *d_dst_base, const uint64_t *dst_off, const uint64_t *raw_len, const uint8_t *expect, uint8_t *digest, int *status)
+{
+    int rc = unpack_device_once(h, n, d_frames_base, frame_off, frame_len, d_dst_base, dst_off, raw_len, expect, digest, status);
+    if ((rc != UNPACK_SPLIT && rc != ZARC_GPU_E_NOMEM) || n < 2) return rc == UNPACK_SPLIT ? ZARC_GPU_E_NOMEM : rc;
+    (void)hipStreamSynchronize(h->stream);
+    DevBuf *big[] = {&h->d_seqs, &h->d_lits, &h->d_ztables, &h->d_zblocks, &h->d_cvs, &h->d_cvs_tmp, &h->d_seqidx, &h->d_litidx, &h->d_nseq};
+    if (rc == ZARC_GPU_E_NOMEM) for (DevBuf *b : big) b->release();
+    uint64_t total = 0, acc = 0;
+    for (size_t i = 0; i < n; i++) total += raw_len[i];
+    size_t k = 0;
+    while (k + 1 < n && (acc + raw_len[k]) * 2 <= total) acc += raw_len[k++];
+    if (k == 0) k = 1;
+    float ms[ZARC_GPU_T_COUNT];
+    const size_t part[3] = {0, k, n};
+    for (int i = 0; i < ZARC_GPU_T_COUNT; i++) ms[i] = 0;
+    for (int p = 0; p < 2; p++) {
+        const size_t a = part[p], m = part[p + 1] - a;
+        rc = unpack_device_split(h, m, d_frames_base, frame_off + a, frame_len + a, d_dst_base, dst_off + a, raw_len + a, expect ? expect + a * 32 : nullptr,
+                                 digest + a * 32, status + a);
+        if (rc) return rc;
+        for (int i = 0; i < ZARC_GPU_T_COUNT; i++) ms[i] += h->ms[i];
+    }
+    for (int i = 0; i < ZARC_GPU_T_COUNT; i++) h->ms[i] = ms[i];
+    return ZARC_GPU_OK;
+}
+} // namespace
+
+int zarc_gpu_unpack_batch_device(zarc_gpu_t *h, size_t n, const void *d_frames_base, const uint64_t *frame_off, const uint64_t *frame_len,
+                                 void *d_dst_base, const uint64_t *dst_off, const uint64_t *raw_len, const uint8_t *expect, uint8_t *digest,
+                                 int *status)
+{
+    int rc = check_common(h, n);
+    if (rc) return rc;
+    if (n == 0) return ZARC_GPU_OK;
+    if (!d_frames_base || !frame_off || !frame_len || !d_dst_base || !dst_off || !raw_len || !digest || !status) return ZARC_GPU_E_PARAM;
+    return unpack_device_split(h, n, d_frames_base, frame_off, frame_len, d_dst_base, dst_off, raw_len, expect, digest, status);
 }
 
 // ---- host-memory entry points: stage through engine-owned arenas -----------------------------------
