@@ -78,6 +78,7 @@ struct zarc_gpu {
     hipStream_t gs[2 * DEC_GROUPS] = {};
     hipEvent_t ev_g[DEC_GROUPS][11] = {};
     int dec_groups = 0;        // ZARC_GPU_PX_DEC_GROUPS: 0 = by the batch's shape
+    uint64_t dec_split_above = 0; // unpack: a batch of this many content bytes ran out of device memory; such batches are split at once
     float ms[ZARC_GPU_T_COUNT];
     size_t scratch_budget = 0; // 0 = derive from free memory (ZARC_GPU_PX_SCRATCH_MB)
     uint64_t stage_chunk = 0;  // 0 = default per entry point (ZARC_GPU_PX_STAGE_CHUNK)
@@ -858,13 +859,18 @@ int unpack_device_once(zarc_gpu_t *h, size_t n, const void *d_frames_base, const
 int unpack_device_split(zarc_gpu_t *h, size_t n, const void *d_frames_base, const uint64_t *frame_off, const uint64_t *frame_len,
                         void *d_dst_base, const uint64_t *dst_off, const uint64_t *raw_len, const uint8_t *expect, uint8_t *digest, int *status)
 {
-    int rc = unpack_device_once(h, n, d_frames_base, frame_off, frame_len, d_dst_base, dst_off, raw_len, expect, digest, status);
-    if ((rc != UNPACK_SPLIT && rc != ZARC_GPU_E_NOMEM) || n < 2) return rc == UNPACK_SPLIT ? ZARC_GPU_E_NOMEM : rc;
-    (void)hipStreamSynchronize(h->stream);
-    DevBuf *big[] = {&h->d_seqs, &h->d_lits, &h->d_ztables, &h->d_zblocks, &h->d_cvs, &h->d_cvs_tmp, &h->d_seqidx, &h->d_litidx, &h->d_nseq};
-    if (rc == ZARC_GPU_E_NOMEM) for (DevBuf *b : big) b->release();
     uint64_t total = 0, acc = 0;
     for (size_t i = 0; i < n; i++) total += raw_len[i];
+    int rc = UNPACK_SPLIT;
+    if (!(n >= 2 && h->dec_split_above && total >= h->dec_split_above)) // (a batch of this size ran out of device memory before: do not try again)
+        rc = unpack_device_once(h, n, d_frames_base, frame_off, frame_len, d_dst_base, dst_off, raw_len, expect, digest, status);
+    if ((rc != UNPACK_SPLIT && rc != ZARC_GPU_E_NOMEM) || n < 2) return rc == UNPACK_SPLIT ? ZARC_GPU_E_NOMEM : rc;
+    (void)hipStreamSynchronize(h->stream);
+    if (rc == ZARC_GPU_E_NOMEM) {
+        DevBuf *big[] = {&h->d_seqs, &h->d_lits, &h->d_ztables, &h->d_zblocks, &h->d_cvs, &h->d_cvs_tmp, &h->d_seqidx, &h->d_litidx, &h->d_nseq};
+        for (DevBuf *b : big) b->release();
+        if (!h->dec_split_above || total < h->dec_split_above) h->dec_split_above = total;
+    }
     size_t k = 0;
     while (k + 1 < n && (acc + raw_len[k]) * 2 <= total) acc += raw_len[k++];
     if (k == 0) k = 1;
