@@ -21,6 +21,13 @@ dig, st = np.zeros((n, 32), dtype=np.uint8), (ctypes.c_int * n)()
 out = np.zeros(n * size, dtype=np.uint8)
 optrs = (ctypes.c_void_p * n)(*[out.ctypes.data + i * size for i in range(n)])
 dig2 = np.zeros((n, 32), dtype=np.uint8)
+# optional: PX id=value pairs after the entry count, e.g. hostpath_rate.py 8192 9004=16 9002=1073741824
+for kv in sys.argv[2:]:
+    if kv == "store":   # --store frames: the kernels do next to nothing, the rate is the staging's own (N bytes in, N bytes out)
+        eng.lib.zarc_gpu_enable_compression(eng.h, 0)
+        continue
+    k, v = kv.split("=")
+    eng.set_parameter(int(k), int(v))
 best = [1e9, 1e9]
 for rep in range(3):
     t0 = time.perf_counter()
@@ -33,4 +40,4 @@ for rep in range(3):
     t3 = time.perf_counter()
     best = [min(best[0], t1 - t0), min(best[1], t3 - t2)]
 assert (out == src).all() and all(s == 0 for s in st)
-print("host-pointer entry points, %d x %d B, pageable host buffers: pack %.2f GiB/s, unpack %.2f GiB/s" % (n, size, n * size / best[0] / 2**30, n * size / best[1] / 2**30))
+print("host-pointer entry points, %d x %d B, pageable host buffers %s: pack %.2f GiB/s, unpack %.2f GiB/s" % (n, size, " ".join(sys.argv[2:]), n * size / best[0] / 2**30, n * size / best[1] / 2**30))

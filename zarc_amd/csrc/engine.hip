@@ -47,7 +47,7 @@ struct zarc_gpu {
     hipStream_t stream3 = nullptr;
     hipEvent_t ev_fork3 = nullptr, ev_join3 = nullptr;
     // pinned staging ring of the host-pointer entry points (allocated on first use)
-    static constexpr int PIN_SLOTS = 4;
+    static constexpr int PIN_SLOTS = 8; // slots 0..3: the ring of the way in (H2D); 4..7: the way out (D2H, two alternate) -- the two directions run at once
     static constexpr size_t PIN_PIECE = (size_t)32 << 20;
     uint8_t *pin[PIN_SLOTS] = {};
     hipEvent_t pin_ev[PIN_SLOTS] = {};
@@ -56,6 +56,7 @@ struct zarc_gpu {
     std::string last_error;
     std::mutex err_mu; // last_error is also written by the staging helper thread of the host-pointer entry points
     hipStream_t stream_stage = nullptr; // PCIe staging of the host-pointer entry points: its copies never queue behind side kernels
+    hipStream_t stream_stage_out = nullptr; // the way out has its own stream (and helper thread): PCIe carries both directions at once
     // descriptors
     DevBuf d_off, d_len, d_chunk_prefix, d_block_prefix, d_order, d_dst_off, d_dst_len, d_raw_len, d_frame_off, d_frame_len;
     // hashing
@@ -247,7 +248,7 @@ int zarc_gpu_create(zarc_gpu_t **out, int device)
     zarc_gpu *h = new (std::nothrow) zarc_gpu();
     if (!h) return ZARC_GPU_E_NOMEM;
     h->device = device;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess || hipStreamCreate(&h->stream2) != hipSuccess || create_low_priority_stream(&h->stream3) != hipSuccess || hipStreamCreate(&h->stream_stage) != hipSuccess ||
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess || hipStreamCreate(&h->stream2) != hipSuccess || create_low_priority_stream(&h->stream3) != hipSuccess || hipStreamCreate(&h->stream_stage) != hipSuccess || hipStreamCreate(&h->stream_stage_out) != hipSuccess ||
         hipEventCreate(&h->ev_fork3) != hipSuccess || hipEventCreate(&h->ev_join3) != hipSuccess ||
         hipEventCreate(&h->ev_fork) != hipSuccess || hipEventCreate(&h->ev_join) != hipSuccess) { delete h; return ZARC_GPU_E_DEVICE; }
     for (auto &e : h->ev)
@@ -291,6 +292,7 @@ void zarc_gpu_destroy(zarc_gpu_t *h)
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->stream3) (void)hipStreamDestroy(h->stream3);
     if (h->stream_stage) (void)hipStreamDestroy(h->stream_stage);
+    if (h->stream_stage_out) (void)hipStreamDestroy(h->stream_stage_out);
     if (h->ev_fork3) (void)hipEventDestroy(h->ev_fork3);
     if (h->ev_join3) (void)hipEventDestroy(h->ev_join3);
     for (int i = 0; i < zarc_gpu::PIN_SLOTS; i++) { if (h->pin[i]) (void)hipHostFree(h->pin[i]); if (h->pin_ev[i]) (void)hipEventDestroy(h->pin_ev[i]); }
@@ -954,7 +956,7 @@ int staged_h2d(zarc_gpu *h, hipStream_t stream, const std::vector<Seg> &segs, ui
     if (rc) return rc;
     size_t first = 0;
     int slot = 0;
-    for (uint64_t lo = 0; lo < total; lo += zarc_gpu::PIN_PIECE, slot = (slot + 1) % zarc_gpu::PIN_SLOTS) {
+    for (uint64_t lo = 0; lo < total; lo += zarc_gpu::PIN_PIECE, slot = (slot + 1) % 4) { // slots 0..3
         const uint64_t hi = std::min<uint64_t>(total, lo + zarc_gpu::PIN_PIECE);
         while (first < segs.size() && segs[first].dev + segs[first].len <= lo) first++;
         ZHIP(hipEventSynchronize(h->pin_ev[slot])); // the transfer that last used this slot is over
@@ -972,10 +974,10 @@ int staged_d2h(zarc_gpu *h, hipStream_t stream, const std::vector<Seg> &segs, co
     if (rc) return rc;
     struct Piece { uint64_t lo, hi; int slot; size_t first; };
     size_t first = 0;
-    int slot = 0;
+    int slot = 4;
     bool have_prev = false;
     Piece prev{};
-    for (uint64_t lo = 0; lo < total; lo += zarc_gpu::PIN_PIECE, slot = (slot + 1) % 2) { // two slots alternate
+    for (uint64_t lo = 0; lo < total; lo += zarc_gpu::PIN_PIECE, slot = 4 + ((slot - 3) & 1)) { // slots 4 and 5 alternate
         const uint64_t hi = std::min<uint64_t>(total, lo + zarc_gpu::PIN_PIECE);
         while (first < segs.size() && segs[first].dev + segs[first].len <= lo) first++;
         ZHIP(hipMemcpyAsync(h->pin[slot], dev_base + lo, hi - lo, hipMemcpyDeviceToHost, stream));
@@ -992,16 +994,29 @@ struct Chunk { size_t i0, i1; uint64_t in_bytes, out_bytes; };
 
 // cut [0, n) into chunks of about STAGE_CHUNK content bytes (at least one entry each)
 std::vector<Chunk> make_chunks(size_t n, const std::vector<uint64_t> &in_sz, const std::vector<uint64_t> &out_sz, const std::vector<uint64_t> &weight,
-                               uint64_t STAGE_CHUNK)
+                               uint64_t STAGE_CHUNK, bool ramp = false)
 {
+    // ramp: the first chunk's way in and the last chunk's way out overlap nothing, so a batch of several chunks starts and ends with a
+    // quarter-sized one (the kernels lose efficiency on it, the pipeline fills and drains four times sooner)
+    uint64_t total = 0;
+    for (size_t i = 0; i < n; i++) total += weight[i];
+    ramp = ramp && total >= 3 * STAGE_CHUNK;
+    const uint64_t small = STAGE_CHUNK / 4;
     std::vector<Chunk> cs;
     size_t i = 0;
+    uint64_t left = total;
     while (i < n) {
         Chunk c{i, i, 0, 0};
-        uint64_t w = 0;
-        while (c.i1 < n && (c.i1 == c.i0 || w + weight[c.i1] <= STAGE_CHUNK)) { w += weight[c.i1]; c.in_bytes += in_sz[c.i1]; c.out_bytes += out_sz[c.i1]; c.i1++; }
+        uint64_t w = 0, target = STAGE_CHUNK;
+        if (ramp) {
+            if (cs.empty()) target = small;
+            else if (left <= small + small / 2) target = left;                       // the last, small chunk
+            else if (left <= STAGE_CHUNK + small) target = left - small;             // the one before it leaves a quarter behind
+        }
+        while (c.i1 < n && (c.i1 == c.i0 || w + weight[c.i1] <= target)) { w += weight[c.i1]; c.in_bytes += in_sz[c.i1]; c.out_bytes += out_sz[c.i1]; c.i1++; }
         cs.push_back(c);
         i = c.i1;
+        left -= w;
     }
     return cs;
 }
@@ -1047,7 +1062,7 @@ int zarc_gpu_pack_batch(zarc_gpu_t *h, size_t n, const void *const *src, const s
         need += out_sz[i];
     }
     if (need > dst_cap) return ZARC_GPU_E_DSTSIZE;
-    const std::vector<Chunk> cs = make_chunks(n, in_sz, out_sz, in_sz, h->stage_chunk ? h->stage_chunk : (uint64_t)2 << 30); // measured: 1-2 GiB chunks pack fastest (27 vs 23 GiB/s at 4 GiB)
+    const std::vector<Chunk> cs = make_chunks(n, in_sz, out_sz, in_sz, h->stage_chunk ? h->stage_chunk : (uint64_t)2 << 30, /*ramp=*/true); // measured: 1-2 GiB chunks pack fastest (27 vs 23 GiB/s at 4 GiB)
     uint64_t max_in = 0, max_out = 0;
     for (const Chunk &c : cs) { max_in = std::max(max_in, c.in_bytes); max_out = std::max(max_out, c.out_bytes); }
     const uint64_t in_half = align_up(max_in + ZARC_GPU_PAD + 256, 256), out_half = align_up(max_out + ZARC_GPU_PAD, 256);
@@ -1055,7 +1070,7 @@ int zarc_gpu_pack_batch(zarc_gpu_t *h, size_t n, const void *const *src, const s
     ZHIP(h->d_arena_out.reserve(2 * out_half));
     uint8_t *const ain = h->d_arena_in.as<uint8_t>(), *const aout = h->d_arena_out.as<uint8_t>();
     const int device = h->device;
-    hipStream_t side = h->stream_stage;
+    hipStream_t side = h->stream_stage, side_out = h->stream_stage_out;
     std::vector<uint64_t> doff(n), dlen(n);
     auto copy_in = [&](size_t c) -> int { // entries of chunk c -> input half c & 1
         std::vector<Seg> segs;
@@ -1071,29 +1086,34 @@ int zarc_gpu_pack_batch(zarc_gpu_t *h, size_t n, const void *const *src, const s
         for (size_t k = 0; k < m; k++) { dense[k] = at; if (dlen[i0 + k]) segs.push_back(Seg{(uint8_t *)dst + dst_off[i0 + k], at, dlen[i0 + k]}); at += dlen[i0 + k]; }
         if (h->d_dense.reserve(at + 256) != hipSuccess || h->d_goff.reserve(m * 8) != hipSuccess || h->d_glen.reserve(m * 8) != hipSuccess ||
             h->d_gdense.reserve(m * 8) != hipSuccess) return ZARC_GPU_E_NOMEM;
-        if (hipMemcpyAsync(h->d_goff.p, doff.data() + i0, m * 8, hipMemcpyHostToDevice, side) != hipSuccess ||
-            hipMemcpyAsync(h->d_glen.p, dlen.data() + i0, m * 8, hipMemcpyHostToDevice, side) != hipSuccess ||
-            hipMemcpyAsync(h->d_gdense.p, dense.data(), m * 8, hipMemcpyHostToDevice, side) != hipSuccess) return ZARC_GPU_E_DEVICE;
-        hipLaunchKernelGGL(zarc_gather, dim3((unsigned)m), dim3(256), 0, side, aout + (c & 1) * out_half, h->d_goff.as<uint64_t>(), h->d_glen.as<uint64_t>(),
+        if (hipMemcpyAsync(h->d_goff.p, doff.data() + i0, m * 8, hipMemcpyHostToDevice, side_out) != hipSuccess ||
+            hipMemcpyAsync(h->d_glen.p, dlen.data() + i0, m * 8, hipMemcpyHostToDevice, side_out) != hipSuccess ||
+            hipMemcpyAsync(h->d_gdense.p, dense.data(), m * 8, hipMemcpyHostToDevice, side_out) != hipSuccess) return ZARC_GPU_E_DEVICE;
+        hipLaunchKernelGGL(zarc_gather, dim3((unsigned)m), dim3(256), 0, side_out, aout + (c & 1) * out_half, h->d_goff.as<uint64_t>(), h->d_glen.as<uint64_t>(),
                            h->d_gdense.as<uint64_t>(), (uint32_t)m, h->d_dense.as<uint8_t>());
         if (hipGetLastError() != hipSuccess) return ZARC_GPU_E_DEVICE;
-        const int r = staged_d2h(h, side, segs, h->d_dense.as<uint8_t>(), at);
-        if (hipStreamSynchronize(side) != hipSuccess) return ZARC_GPU_E_DEVICE; // `dense` is read by an async copy above
+        const int r = staged_d2h(h, side_out, segs, h->d_dense.as<uint8_t>(), at);
+        if (hipStreamSynchronize(side_out) != hipSuccess) return ZARC_GPU_E_DEVICE; // `dense` is read by an async copy above
         return r;
     };
     float sum[ZARC_GPU_T_COUNT] = {};
     if ((rc = copy_in(0))) return rc;
     ZHIP(hipStreamSynchronize(side));
     for (size_t c = 0; c < cs.size(); c++) {
-        int helper_rc = 0;
-        auto moves = [&] {
+        // chunk c+1 comes in and chunk c-1 goes out while chunk c is worked on: one helper thread and one stream per direction
+        int helper_rc = 0, helper_rc_out = 0;
+        auto move_in = [&] {
             (void)hipSetDevice(device);
             if (c + 1 < cs.size()) helper_rc = copy_in(c + 1);
-            if (!helper_rc && c > 0) helper_rc = copy_out(c - 1);
             if (hipStreamSynchronize(side) != hipSuccess) helper_rc = ZARC_GPU_E_DEVICE;
         };
-        std::thread helper;
-        if (h->stage_thread) helper = std::thread(moves); else moves();
+        auto move_out = [&] {
+            (void)hipSetDevice(device);
+            if (c > 0) helper_rc_out = copy_out(c - 1);
+            if (hipStreamSynchronize(side_out) != hipSuccess) helper_rc_out = ZARC_GPU_E_DEVICE;
+        };
+        std::thread helper, helper_out;
+        if (h->stage_thread) { helper = std::thread(move_in); helper_out = std::thread(move_out); } else { move_in(); move_out(); }
         const size_t m = cs[c].i1 - cs[c].i0, i0 = cs[c].i0;
         std::vector<uint64_t> off(m);
         uint64_t at = 0;
@@ -1101,13 +1121,15 @@ int zarc_gpu_pack_batch(zarc_gpu_t *h, size_t n, const void *const *src, const s
         rc = zarc_gpu_pack_batch_device(h, m, ain + (c & 1) * in_half, off.data(), l64.data() + i0, aout + (c & 1) * out_half, cs[c].out_bytes, doff.data() + i0,
                                         dlen.data() + i0, (uint8_t *)digest[i0], status ? status + i0 : nullptr);
         if (helper.joinable()) helper.join();
+        if (helper_out.joinable()) helper_out.join();
         if (rc) return rc;
         if (helper_rc) return helper_rc;
+        if (helper_rc_out) return helper_rc_out;
         for (size_t k = 0; k < m; k++) dst_len[i0 + k] = (size_t)dlen[i0 + k];
         for (int t = 0; t < ZARC_GPU_T_COUNT; t++) sum[t] += h->ms[t] > 0 ? h->ms[t] : 0;
     }
     if ((rc = copy_out(cs.size() - 1))) return rc;
-    ZHIP(hipStreamSynchronize(side));
+    ZHIP(hipStreamSynchronize(side_out));
     for (int t = 0; t < ZARC_GPU_T_COUNT; t++) h->ms[t] = sum[t];
     return ZARC_GPU_OK;
 }
@@ -1136,7 +1158,7 @@ int zarc_gpu_unpack_batch(zarc_gpu_t *h, size_t n, const void *const *frame, con
     ZHIP(h->d_arena_out.reserve(2 * out_half));
     uint8_t *const ain = h->d_arena_in.as<uint8_t>(), *const aout = h->d_arena_out.as<uint8_t>();
     const int device = h->device;
-    hipStream_t side = h->stream_stage;
+    hipStream_t side = h->stream_stage, side_out = h->stream_stage_out;
     auto copy_in = [&](size_t c) -> int {
         std::vector<Seg> segs;
         uint64_t at = 0;
@@ -1152,21 +1174,26 @@ int zarc_gpu_unpack_batch(zarc_gpu_t *h, size_t n, const void *const *frame, con
             if (decoded && raw_len[i]) segs.push_back(Seg{(uint8_t *)dst[i], at, raw_len[i]});
             at += out_sz[i];
         }
-        return staged_d2h(h, side, segs, aout + (c & 1) * out_half, at);
+        return staged_d2h(h, side_out, segs, aout + (c & 1) * out_half, at);
     };
     float sum[ZARC_GPU_T_COUNT] = {};
     if ((rc = copy_in(0))) return rc;
     ZHIP(hipStreamSynchronize(side));
     for (size_t c = 0; c < cs.size(); c++) {
-        int helper_rc = 0;
-        auto moves = [&] {
+        // chunk c+1 comes in and chunk c-1 goes out while chunk c is worked on: one helper thread and one stream per direction
+        int helper_rc = 0, helper_rc_out = 0;
+        auto move_in = [&] {
             (void)hipSetDevice(device);
             if (c + 1 < cs.size()) helper_rc = copy_in(c + 1);
-            if (!helper_rc && c > 0) helper_rc = copy_out(c - 1);
             if (hipStreamSynchronize(side) != hipSuccess) helper_rc = ZARC_GPU_E_DEVICE;
         };
-        std::thread helper;
-        if (h->stage_thread) helper = std::thread(moves); else moves();
+        auto move_out = [&] {
+            (void)hipSetDevice(device);
+            if (c > 0) helper_rc_out = copy_out(c - 1);
+            if (hipStreamSynchronize(side_out) != hipSuccess) helper_rc_out = ZARC_GPU_E_DEVICE;
+        };
+        std::thread helper, helper_out;
+        if (h->stage_thread) { helper = std::thread(move_in); helper_out = std::thread(move_out); } else { move_in(); move_out(); }
         const size_t m = cs[c].i1 - cs[c].i0, i0 = cs[c].i0;
         std::vector<uint64_t> foff(m), doff(m);
         uint64_t fa = 0, da = 0;
@@ -1174,12 +1201,14 @@ int zarc_gpu_unpack_batch(zarc_gpu_t *h, size_t n, const void *const *frame, con
         rc = zarc_gpu_unpack_batch_device(h, m, ain + (c & 1) * in_half, foff.data(), flen.data() + i0, aout + (c & 1) * out_half, doff.data(), rlen.data() + i0,
                                           expect ? (const uint8_t *)expect[i0] : nullptr, (uint8_t *)digest[i0], status + i0);
         if (helper.joinable()) helper.join();
+        if (helper_out.joinable()) helper_out.join();
         if (rc) return rc;
         if (helper_rc) return helper_rc;
+        if (helper_rc_out) return helper_rc_out;
         for (int t = 0; t < ZARC_GPU_T_COUNT; t++) sum[t] += h->ms[t] > 0 ? h->ms[t] : 0;
     }
     if ((rc = copy_out(cs.size() - 1))) return rc;
-    ZHIP(hipStreamSynchronize(side));
+    ZHIP(hipStreamSynchronize(side_out));
     for (int t = 0; t < ZARC_GPU_T_COUNT; t++) h->ms[t] = sum[t];
     return ZARC_GPU_OK;
 }
