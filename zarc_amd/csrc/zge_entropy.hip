@@ -143,7 +143,15 @@ __device__ void fse_build_ctab(FseCtab &t, const int16_t *norm, int nsym, int al
     // cumulative starts; dfs[] doubles as the running "next" index, then gets its final value
     int total = 0;
     for (int s = 0; s < nsym; s++) { t.dfs[s] = total; total += norm[s] == -1 ? 1 : norm[s]; }
-    for (int i = 0; i < T; i++) { const int s = cellsym[i]; t.state_tab[t.dfs[s]++] = (uint16_t)(T + i); }
+    // every cell takes the next slot of its symbol: an LDS atomic with return per cell -- LDS executes them in order, so the eight of a
+    // trip are in flight together instead of one read-modify-write round trip after the other
+    for (int i = 0; i < T; i += 8) {
+        int slot[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) slot[k] = atomicAdd(&t.dfs[cellsym[i + k]], 1);
+#pragma unroll
+        for (int k = 0; k < 8; k++) t.state_tab[slot[k]] = (uint16_t)(T + i + k);
+    }
     total = 0;
     for (int s = 0; s < nsym; s++) {
         const int n = norm[s];
@@ -274,22 +282,28 @@ __device__ void choose_table(EntLds &L, int which, const uint32_t *count, int ma
 // L.h.count -> L.h.len8 (code lengths).  Uniform; returns number of present symbols.
 __device__ int huf_build_lengths(EntLds &L, int lane)
 {
-    // rank by counting: order ascending by (count, symbol)
+    // rank by counting over the PRESENT symbols only: keys count << 8 | symbol, compacted (ascending (count, symbol) = ascending key);
+    // key i's rank is the number of smaller keys.  (w[256..] is free until the tree is built.)
     uint32_t present = 0;
+    uint32_t *const keys = &L.h.w[256];
+    {
+        const uint64_t lt = (1ull << lane) - 1;
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const int s = r * 64 + lane;
-        const uint32_t c = L.h.count[s];
-        L.h.len8[s] = 0;
-        if (c) {
-            uint32_t rank = 0;
-            for (int t = 0; t < 256; t++) {
-                const uint32_t ct = L.h.count[t];
-                rank += (ct != 0 && (ct < c || (ct == c && t < s))) ? 1u : 0u;
-            }
-            L.h.order[rank] = (uint16_t)s;
+        for (int r = 0; r < 4; r++) {
+            const int s = r * 64 + lane;
+            const uint32_t c = L.h.count[s];
+            L.h.len8[s] = 0;
+            const uint64_t m = zd::ballot(c != 0);
+            if (c) keys[present + (uint32_t)__popcll(m & lt)] = (c << 8) | (uint32_t)s;
+            present += (uint32_t)__popcll(m);
         }
-        present += (uint32_t)__popcll(zd::ballot(c != 0));
+    }
+    zd::wave_sync();
+    for (uint32_t i = (uint32_t)lane; i < present; i += 64) {
+        const uint32_t k = keys[i];
+        uint32_t rank = 0;
+        for (uint32_t t = 0; t < present; t++) rank += keys[t] < k ? 1u : 0u;
+        L.h.order[rank] = (uint16_t)(k & 0xFF);
     }
     zd::wave_sync();
     const int n = (int)present;
