@@ -81,6 +81,18 @@ def lib_sha16(path):
     return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
 
 
+def src_sha16():
+    """Hash of the kernel / engine sources the library is built from (zarc_amd/csrc + the ABI header): what ties a committed PMC profile to
+    the code it was taken on -- unlike the binary's own hash it does not depend on where or when the library was compiled."""
+    import glob
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "zarc_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "zarc_amd", "csrc", "*.h")) +
+                   [os.path.join(ROOT, "zarc_amd", "csrc", "Makefile"), os.path.join(ROOT, "include", "zarc_gpu.h")])
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0" + open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def workload(args, rank, world):
     """(sizes of this rank's entries, corpus index of each, kind, level, description) -- the global list dealt by the product's sharder."""
     from zarc_amd import shard
@@ -267,20 +279,20 @@ def main():
         u_achieved = alg_bytes / (u_ms[udom] * 1e-3) / 1e9 if u_ms[udom] > 0 else 0.0
         # HBM traffic of those kernels from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs;
         # FETCH_SIZE doubled per MI355X_MICROARCH.md -- calibrated on zarc_xxh64, which reads exactly N bytes and reports N/2).
-        # Only quoted when the profile was taken on THIS build of the library (sha256 recorded by tools/profile.sh) and this workload.
+        # Only quoted when the profile was taken on THESE kernel sources (hash recorded by tools/profile.sh) and this workload.
         traffic = u_traffic = None
         traffic_src = "none: no PMC profile of this library build under profiles/"
         pmc_file = os.path.join(ROOT, "profiles", "r02_bench_pmc_summary.json")
         if os.path.exists(pmc_file):
             pmc = json.load(open(pmc_file))
-            same = pmc.get("lib_sha16") == lib_sha16(eng.lib_path) and pmc.get("entries") == n and pmc.get("entry_bytes") == args.size and args.config == "c2"
+            same = pmc.get("src_sha16") == src_sha16() and pmc.get("entries") == n and pmc.get("entry_bytes") == args.size and args.config == "c2"
             if same:
                 def tr(kname):
                     if kname in pmc.get("fetch", {}) and kname in pmc.get("write", {}):
                         return (2.0 * pmc["fetch"][kname]["per_dispatch"] + pmc["write"][kname]["per_dispatch"]) * 1024.0
                     return None
                 traffic, u_traffic = tr("zarc_" + names[dom]), tr("zarc_" + unames[udom])
-                traffic_src = "profiles/r02_bench_pmc_summary.json (same library build %s, same workload)" % pmc["lib_sha16"]
+                traffic_src = "profiles/r02_bench_pmc_summary.json (same kernel sources %s, same workload)" % pmc["src_sha16"]
             else:
                 traffic_src = "none: profiles/r02_bench_pmc_summary.json is of another build or workload"
         line = {
@@ -303,7 +315,7 @@ def main():
             "unpack_roofline": {"bound": "hbm", "kernel": unames[udom], "achieved": round(u_achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": round(u_achieved / HBM_PEAK_GBS, 5), "traffic": u_traffic,
                                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(float(u_ms[udom]), 3)},
-            "library_sha16": lib_sha16(eng.lib_path),
+            "library_sha16": lib_sha16(eng.lib_path), "source_sha16": src_sha16(),
         }
         if world == 1 and args.config == "c2" and not args.no_host_path:
             nh = min(args.host_entries, n)

@@ -30,6 +30,10 @@ out["entries"] = $N
 out["entry_bytes"] = 1 << 20
 import hashlib
 out["lib_sha16"] = hashlib.sha256(open("$R/zarc_amd/libzarc_gpu.so", "rb").read()).hexdigest()[:16]
+import sys
+sys.path.insert(0, "$R")
+import bench
+out["src_sha16"] = bench.src_sha16()
 sq = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
 for f in glob.glob("$O/sq*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):

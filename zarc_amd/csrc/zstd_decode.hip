@@ -984,8 +984,8 @@ __device__ __forceinline__ void decode_frame(Lds &L, const int lane, const uint3
                         // (3) near matches.  Those whose source touches no UNRESOLVED near match's output run together, one lane each, round
                         // after round (records: every field copies the previous record's, so a round retires one record's matches and
                         // a batch takes as many rounds as it holds records, not one step per match).  Outputs are ordered like the lanes,
-                        // so "the near matches that start below my source's end" is a lane count (binary search over the match positions,
-                        // once per batch) and only the last unresolved one of them can reach up to my source's start.  A round that finds
+                        // so "the near matches whose output overlaps my source" is a lane range (two binary searches over the match positions,
+                        // once per batch) and a round only tests it against the unresolved set.  A round that finds
                         // nothing (long, overlapping or straddling matches) runs the lowest unresolved match wave-wide: all below it is final.
                         uint64_t near = (dbg & 8) ? 0ull : zd::ballot(have && !far);
                         if (near) {
@@ -1000,11 +1000,17 @@ __device__ __forceinline__ void decode_frame(Lds &L, const int lane, const uint3
                                 if (probe < s_end) jb += step;
                             }
                             if (zd::shfl(o_mat, 63) < s_end) jb = 64;
-                            const uint64_t below = jb >= 64 ? ~0ull : ((1ull << jb) - 1);
+                            uint32_t jl = 0;                                          // lanes whose match ends at or below my source's start
+#pragma unroll
+                            for (uint32_t step = 32; step; step >>= 1) {
+                                const uint32_t probe = zd::shfl(o_end, (int)((jl + step - 1) & 63));
+                                if (probe <= (uint32_t)s_rel) jl += step;
+                            }
+                            if (zd::shfl(o_end, 63) <= (uint32_t)s_rel) jl = 64;
+                            // the lanes whose output overlaps my source: [jl, jb) -- fixed for the batch, so a round is a mask test
+                            const uint64_t deps = (jb >= 64 ? ~0ull : ((1ull << jb) - 1)) & ~(jl >= 64 ? ~0ull : ((1ull << jl) - 1));
                             while (near) {
-                                const uint64_t before = near & below;
-                                const uint32_t last_end = zd::shfl(o_end, before ? 63 - __clzll((long long)before) : 0);
-                                const bool indep = cand && ((near >> lane) & 1) && (before == 0 || last_end <= (uint32_t)s_rel);
+                                const bool indep = cand && ((near >> lane) & 1) && (near & deps) == 0;
                                 const uint64_t im = zd::ballot(indep);
                                 if (im) {
                                     if (indep) lane_move32(ob + o_mat, ob + s_rel, ml);
