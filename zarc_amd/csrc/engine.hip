@@ -774,7 +774,7 @@ int unpack_device_once(zarc_gpu_t *h, size_t n, const void *d_frames_base, const
         ZHIP(hipEventRecord(ev[4], sa));
         const size_t grid_g = std::max<size_t>(1, std::min<size_t>(ng, dec_grid / (size_t)groups));
         if (fastpath) {
-            hipLaunchKernelGGL(zarc_zstd_frames, dim3((unsigned)std::min<size_t>(ng, dec_grid)), dim3(64), 0, sa, (const uint8_t *)d_frames_base, h->d_frame_off.as<uint64_t>(),
+            hipLaunchKernelGGL(zarc_zstd_frames, dim3((unsigned)std::min<size_t>(ng, (size_t)h->num_cus * 16)), dim3(64), 0, sa, /* four waves per SIMD (its launch bounds) */ (const uint8_t *)d_frames_base, h->d_frame_off.as<uint64_t>(),
                                h->d_frame_len.as<uint64_t>(), (uint8_t *)d_dst_base, h->d_dst_off.as<uint64_t>(), h->d_raw_len.as<uint64_t>(),
                                h->d_order.as<uint32_t>() + f0, (uint32_t)ng, h->d_status.as<int32_t>(), h->d_stored_ck.as<uint32_t>(), dec_dbg, h->d_queue.as<uint32_t>() + 2 * g,
                                h->d_fast.as<uint32_t>(), h->d_slot_prefix.as<uint64_t>(), h->d_zblocks.as<ZdecBlock>(), h->d_seqidx.as<uint64_t>(),

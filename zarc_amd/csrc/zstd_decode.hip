@@ -1162,7 +1162,7 @@ __global__ void __launch_bounds__(64, 5) zarc_zstd_decode(const uint8_t *__restr
 }
 
 // The frame pass of the fast path: same queue discipline, frames whose sequences and literals were decoded ahead.
-__global__ void __launch_bounds__(64, 5) zarc_zstd_frames(const uint8_t *__restrict__ frames_base, const uint64_t *__restrict__ frame_off,
+__global__ void __launch_bounds__(64, 4) zarc_zstd_frames(const uint8_t *__restrict__ frames_base, const uint64_t *__restrict__ frame_off,
                                                        const uint64_t *__restrict__ frame_len, uint8_t *__restrict__ dst_base,
                                                        const uint64_t *__restrict__ dst_off, const uint64_t *__restrict__ raw_len,
                                                        const uint32_t *__restrict__ order, uint32_t n_frames, int32_t *__restrict__ status,
