@@ -623,7 +623,7 @@ int unpack_device_once(zarc_gpu_t *h, size_t n, const void *d_frames_base, const
     if ((rc = upload_u64(h, h->d_dst_off, dst_off.data(), n))) return rc;
     if ((rc = upload_u64(h, h->d_raw_len, raw_len.data(), n))) return rc;
     { std::vector<uint32_t> ident(n); std::iota(ident.begin(), ident.end(), 0u); if ((rc = upload_u32(h, h->d_order, ident.data(), n))) return rc; } // the queues walk the (sorted) indices
-    const size_t dec_grid = std::min<size_t>(n, (size_t)h->num_cus * 20); // 5 waves per SIMD (launch bounds of the decoder)
+    const size_t dec_grid = std::min<size_t>(n, (size_t)h->num_cus * 16); // 4 waves per SIMD (launch bounds of the frame kernels: 128 VGPRs, no spills)
     ZHIP(h->d_declit.reserve(dec_grid * (size_t)(ZARC_BLOCK + 64)));
     ZHIP(h->d_queue.reserve(256));
     ZHIP(h->d_status.reserve(n * 4));
@@ -774,7 +774,7 @@ int unpack_device_once(zarc_gpu_t *h, size_t n, const void *d_frames_base, const
         ZHIP(hipEventRecord(ev[4], sa));
         const size_t grid_g = std::max<size_t>(1, std::min<size_t>(ng, dec_grid / (size_t)groups));
         if (fastpath) {
-            hipLaunchKernelGGL(zarc_zstd_frames, dim3((unsigned)std::min<size_t>(ng, (size_t)h->num_cus * 16)), dim3(64), 0, sa, /* four waves per SIMD (its launch bounds) */ (const uint8_t *)d_frames_base, h->d_frame_off.as<uint64_t>(),
+            hipLaunchKernelGGL(zarc_zstd_frames, dim3((unsigned)std::min<size_t>(ng, dec_grid)), dim3(64), 0, sa, (const uint8_t *)d_frames_base, h->d_frame_off.as<uint64_t>(),
                                h->d_frame_len.as<uint64_t>(), (uint8_t *)d_dst_base, h->d_dst_off.as<uint64_t>(), h->d_raw_len.as<uint64_t>(),
                                h->d_order.as<uint32_t>() + f0, (uint32_t)ng, h->d_status.as<int32_t>(), h->d_stored_ck.as<uint32_t>(), dec_dbg, h->d_queue.as<uint32_t>() + 2 * g,
                                h->d_fast.as<uint32_t>(), h->d_slot_prefix.as<uint64_t>(), h->d_zblocks.as<ZdecBlock>(), h->d_seqidx.as<uint64_t>(),

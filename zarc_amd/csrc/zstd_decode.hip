@@ -1136,7 +1136,7 @@ __device__ __forceinline__ void decode_frame(Lds &L, const int lane, const uint3
 // queue (frames are ordered largest first), so slow and fast frames balance across XCDs whatever their order.
 // Every wave leaves as soon as the queue is empty.  zarc_zstd_decode is the general kernel (everything decoded inline);
 // when the fast path is on it only takes the frames stage 1/2 turned down, and zarc_zstd_frames takes the others.
-__global__ void __launch_bounds__(64, 5) zarc_zstd_decode(const uint8_t *__restrict__ frames_base, const uint64_t *__restrict__ frame_off,
+__global__ void __launch_bounds__(64, 4) zarc_zstd_decode(const uint8_t *__restrict__ frames_base, const uint64_t *__restrict__ frame_off,
                                                        const uint64_t *__restrict__ frame_len, uint8_t *__restrict__ dst_base,
                                                        const uint64_t *__restrict__ dst_off, const uint64_t *__restrict__ raw_len,
                                                        const uint32_t *__restrict__ order, uint32_t n_frames,
