@@ -50,6 +50,14 @@ def items():
     out["periodic_4m"] = bytes(range(200)) * 20000
     md = sorted(glob.glob("/opt/skills/guides/*.md"))
     out["guides_md"] = _tarlike(md, 1 << 20) if md else None
+    # ordinary x86 machine code / byte code, and GPU code objects (huge numbers of near-identical kernels): the items on which the
+    # level-3 finder is OUTSIDE the contract (see BOUND)
+    for name, path in (("libc_2m", "/usr/lib/x86_64-linux-gnu/libc.so.6"), ("python_bin_2m", "/usr/bin/python3.10")):
+        out[name] = _slice(path, 0, 2 << 20) if os.path.exists(path) and os.path.getsize(path) >= (2 << 20) else None
+    pyc = sorted(glob.glob("/usr/lib/python3.10/__pycache__/*.pyc"))
+    out["pyc_2m"] = _tarlike(pyc, 2 << 20) if len(pyc) > 50 else None
+    co = sorted(glob.glob("/opt/rocm/lib/**/*.hsaco", recursive=True)) + sorted(glob.glob("/opt/rocm/lib/rocblas/library/*.co"))
+    out["hsaco_2m"] = _tarlike(co, 2 << 20) if co else None
     return out
 
 
@@ -57,7 +65,13 @@ def items():
 # above it are argued in DESIGN.md section 4.1 (level 9 on machine code and on hundreds of tiny JSON files: libzstd's lazy2 parser
 # walks a 16-deep hash chain and tries the live repeat offset at every position, the tile-parallel finder sees four table ways and
 # the repeat offsets of the previous tile).  The numbers are measured values plus a little slack, so that a regression shows.
-BOUND = {3: {"guides_md": 1.06}, 9: {"elf_head_4m": 1.09, "elf_mid_4m": 1.18, "json_node_2m": 1.10}}
+# Machine code and byte code are outside the contract at BOTH levels (5 - 8 %): their repeats are short (5 - 8 bytes) and tens of KiB
+# apart, and the finder's short-hash table remembers 2^13 positions where libzstd -3 keeps 2^16 (chainLog 16); the model says 2^15
+# entries would bring all three within 4 %, 64 KiB of LDS per workgroup do not hold them.  GPU code objects (thousands
+# of near-identical kernels, 70x compressible) lose more: their repeats of 10 - 40 bytes at MiB distances are what libzstd's 2^17-entry
+# long table finds and the sampled far table (repeats of 44 bytes and more) does not.
+BOUND = {3: {"guides_md": 1.06, "libc_2m": 1.06, "python_bin_2m": 1.075, "pyc_2m": 1.08, "hsaco_2m": 1.35},
+         9: {"elf_head_4m": 1.09, "elf_mid_4m": 1.18, "json_node_2m": 1.10, "libc_2m": 1.065, "python_bin_2m": 1.07, "pyc_2m": 1.085, "hsaco_2m": 1.56}}
 
 
 def bound(name, level):
