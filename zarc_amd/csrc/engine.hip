@@ -640,8 +640,20 @@ int unpack_device_once(zarc_gpu_t *h, size_t n, const void *d_frames_base, const
     ZHIP(t.mark(&e0));
     // ---- fast path: block scan (lane per frame), then sequence entropy decoding with one lane per block ----
     bool fastpath = diag_env("ZARC_GPU_DEC_FAST", 1) != 0;
+    // slots of the fast path: one per block, counted on the device first (a frame the count turns down keeps one slot and goes to the
+    // general decoder)
     std::vector<uint64_t> slot_prefix(n + 1, 0);
-    for (size_t i = 0; i < n; i++) slot_prefix[i + 1] = slot_prefix[i] + raw_len[i] / ZARC_BLOCK + 2; // blocks a well-formed frame needs, plus slack
+    if (fastpath) {
+        std::vector<uint32_t> nblk(n);
+        ZHIP(h->d_fast.reserve(n * 4));
+        hipLaunchKernelGGL(zarc_zdec_count, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, h->stream, (const uint8_t *)d_frames_base, h->d_frame_off.as<uint64_t>(),
+                           h->d_frame_len.as<uint64_t>(), h->d_raw_len.as<uint64_t>(), (uint32_t)n, h->d_fast.as<uint32_t>());
+        ZHIP(hipGetLastError());
+        ZHIP(hipMemcpyAsync(nblk.data(), h->d_fast.p, n * 4, hipMemcpyDeviceToHost, h->stream));
+        ZHIP(hipStreamSynchronize(h->stream));
+        for (size_t i = 0; i < n; i++) slot_prefix[i + 1] = slot_prefix[i] + std::max<uint32_t>(nblk[i], 1u);
+    } else
+        for (size_t i = 0; i < n; i++) slot_prefix[i + 1] = slot_prefix[i] + 1;
     const size_t nslots = (size_t)slot_prefix[n];
     if (nslots * (size_t)ZDEC_TABLE_CELLS * 2 > ((size_t)8 << 30)) fastpath = false; // table scratch out of proportion (millions of tiny frames)
     // groups: [gf[g], gf[g+1]) in sorted order, equal shares of the bytes.  One group (the stages simply follow each other) unless the

@@ -61,6 +61,7 @@ constexpr int ZDEC_LIT_GROUP = 16;  // block slots per wave of zarc_zdec_literal
 // as far as the block alone allows: bit 17 of the literal-length field set = the offset is (history slot at block start) - delta,
 // the offset field then holds slot | delta << 2; otherwise the offset field is the absolute offset.
 constexpr uint32_t ZDEC_LL_REF = 1u << 17;
+constexpr uint32_t ZDEC_MAX_DELTA = 1u << 20; // "history slot minus delta": repeated `first history entry - 1` codes add up (libzstd -9 .. -19 on records-like data)
 constexpr uint32_t ZDEC_REP_REF = 0x80000000u; // same idea for ZdecBlock::rep[]: REF | slot | delta << 2
 constexpr int ZDEC_TABLE_CELLS = 1280; // per block slot: LL 512 + ML 512 + OF 256 FSE decode cells (u16)
 
@@ -83,6 +84,8 @@ __global__ void zarc_gather(const uint8_t *src_base, const uint64_t *src_off, co
 __global__ void zarc_zge_store(const uint8_t *src_base, const uint64_t *src_off, const uint64_t *src_len, uint32_t n_frames, uint8_t *dst_base,
                                const uint64_t *dst_off, uint64_t *dst_len);
 // decoder fast path, stage 1: one LANE per frame walks the block headers (no payload is touched) -> block slots, nseq[], fast[]
+__global__ void zarc_zdec_count(const uint8_t *frames_base, const uint64_t *frame_off, const uint64_t *frame_len, const uint64_t *raw_len, uint32_t n_frames,
+                                uint32_t *nblocks);
 __global__ void zarc_zdec_scan(const uint8_t *frames_base, const uint64_t *frame_off, const uint64_t *frame_len, const uint64_t *raw_len,
                                uint32_t n_frames, const uint64_t *slot_prefix, ZdecBlock *zblocks, uint32_t *counts /* per slot: nseq, Huffman literal bytes */,
                                uint32_t *fast);

@@ -1189,6 +1189,39 @@ __global__ void __launch_bounds__(64, 4) zarc_zstd_frames(const uint8_t *__restr
     }
 }
 
+// Stage 0 of the fast path: how many blocks does every frame hold?  (One lane per frame walks the block headers only.)  The slots of
+// the fast path are then sized exactly: libzstd 1.5.7 splits blocks below 128 KiB at most levels, so "content / 128 KiB" undercounts,
+// and generous guesses would leave the lane-per-slot kernels with mostly empty waves.  0 = not a frame the fast path takes.
+__global__ void __launch_bounds__(64) zarc_zdec_count(const uint8_t *__restrict__ frames_base, const uint64_t *__restrict__ frame_off,
+                                                      const uint64_t *__restrict__ frame_len, const uint64_t *__restrict__ raw_len, uint32_t n_frames,
+                                                      uint32_t *__restrict__ nblocks)
+{
+    const uint32_t f = blockIdx.x * 64u + threadIdx.x;
+    if (f >= n_frames) return;
+    nblocks[f] = 0;
+    const uint8_t *src = frames_base + frame_off[f];
+    const uint32_t slen = (uint32_t)frame_len[f];
+    if (slen < 6 || !(src[0] == 0x28 && src[1] == 0xB5 && src[2] == 0x2F && src[3] == 0xFD)) return;
+    const uint32_t desc = src[4];
+    const uint32_t fcs_flag = desc >> 6, ss = (desc >> 5) & 1, did_flag = desc & 3;
+    if (desc & 8) return;
+    const uint32_t did_bytes = did_flag == 3 ? 4u : did_flag, fcs_bytes = fcs_flag == 0 ? ss : (1u << fcs_flag);
+    uint32_t pos = 5 + (ss ? 0u : 1u) + did_bytes + fcs_bytes;
+    const uint64_t cap = raw_len[f] / 512 + 64; // a frame cut into blocks of under 512 bytes on average is left to the general decoder
+    uint32_t nb = 0;
+    for (bool last = false; !last;) {
+        if (pos + 3 > slen || nb >= cap) return;
+        const uint32_t bh = (uint32_t)src[pos] | ((uint32_t)src[pos + 1] << 8) | ((uint32_t)src[pos + 2] << 16);
+        last = bh & 1;
+        const uint32_t btype = (bh >> 1) & 3, bsize = bh >> 3;
+        if (btype == 3 || bsize > BLOCK_MAX) return;
+        pos += 3 + (btype == 1 ? 1u : bsize);
+        if (pos > slen) return;
+        nb++;
+    }
+    nblocks[f] = nb;
+}
+
 // Stage 1 of the fast path: one lane per frame reads the frame header and walks the block headers.
 __global__ void __launch_bounds__(64) zarc_zdec_scan(const uint8_t *__restrict__ frames_base, const uint64_t *__restrict__ frame_off,
                                                      const uint64_t *__restrict__ frame_len, const uint64_t *__restrict__ raw_len, uint32_t n_frames,
@@ -1345,7 +1378,7 @@ __global__ void __launch_bounds__(64) zarc_zdec_seqs(const uint8_t *__restrict__
                     else if (idx == 2) { ov = hv2; orf = hr2; }
                     else { // first history entry minus one
                         ov = hv0; orf = hr0;
-                        if (orf) { if ((ov >> 2) >= 3) { ok = false; break; } ov += 4; } // delta + 1 (deeper chains: left to the frame pass)
+                        if (orf) { if ((ov >> 2) >= ZDEC_MAX_DELTA) { ok = false; break; } ov += 4; } // delta + 1 (only absurd chains are left to the frame pass)
                         else { if (ov <= 1) { ok = false; break; } ov -= 1; }
                     }
                     if (idx > 1) { hv2 = hv1; hr2 = hr1; }
@@ -1429,7 +1462,7 @@ __global__ void __launch_bounds__(ZDEC_LDS_LANES) zarc_zdec_seqs_lds(const uint8
                     else if (idx == 2) { ov = hv2; orf = hr2; }
                     else { // first history entry minus one
                         ov = hv0; orf = hr0;
-                        if (orf) { if ((ov >> 2) >= 3) { ok = false; break; } ov += 4; } // delta + 1 (deeper chains: left to the frame pass)
+                        if (orf) { if ((ov >> 2) >= ZDEC_MAX_DELTA) { ok = false; break; } ov += 4; } // delta + 1 (only absurd chains are left to the frame pass)
                         else { if (ov <= 1) { ok = false; break; } ov -= 1; }
                     }
                     if (idx > 1) { hv2 = hv1; hr2 = hr1; }
