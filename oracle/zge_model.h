@@ -11,6 +11,7 @@ extern "C" {
 #endif
 
 #define ZGE_BLOCK (128 * 1024)
+#define ZGE_SPLIT_MIN ((size_t)4 << 20) /* zarc_kernels.h: ZARC_SPLIT_MIN */
 #define ZGE_MIN_HUF_LITERALS 64
 
 typedef struct {

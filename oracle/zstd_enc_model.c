@@ -980,6 +980,10 @@ int zge_encode_frame(const zge_params *P, const void *src_, size_t n, void *dst_
             }
             memset(c.tl, 0, sizeof(uint32_t) << P->long_log);
             memset(c.ts, 0, sizeof(uint32_t) << P->short_log);
+            /* in a frame larger than ZGE_SPLIT_MIN a segment is a unit of work of its own in the engine (zge_match.hip: one workgroup
+             * per segment, so that the segments of a large frame are searched side by side): what the finder carries from tile to
+             * tile starts afresh as well */
+            if (n > ZGE_SPLIT_MIN) { c.erep0 = c.erep1 = 0; c.cold = 0; c.skip_left = 0; }
         }
         for (i = 1; i < blen; i++) if (src[bs + i] != src[bs]) { all_same = 0; break; }
         if (all_same && blen >= 2) {

@@ -120,3 +120,19 @@ def test_emu_sequence_stage_split_between_both_kernels(emu_engine, oracle, corpu
     monkeypatch.setenv("ZARC_GPU_SEQ_LDS_FRAC", "0.5")
     pc.check_unpack_golden(emu_engine, oracle, corpus, golden_frames)
     pc.check_roundtrip(emu_engine, oracle, corpus, big=False)
+
+
+def test_emu_large_frame_is_searched_segment_by_segment(emu_engine, oracle, corpus, libzstds):
+    """A frame above ZARC_SPLIT_MIN (4 MiB) is dealt to the match finder's workgroups one 2 MiB segment at a time (zge_match.hip: units);
+    the model restarts the finder's carried state at the same places.  Bit-exact, valid for libzstd, round trip."""
+    raw = corpus.entry(4242, (4 << 20) + 2300000, 2) [: (4 << 20) + 2300000]
+    raw = raw[:3 << 20] + raw[:2 << 20] + raw[3 << 20:]          # a repeat across segment boundaries
+    raw = raw[:(4 << 20) + 2300000]
+    small = corpus.entry(4243, 70000, 0)
+    packed = emu_engine.pack([small, raw, small])
+    assert packed[1][0] == oracle.zge_encode(raw)
+    assert packed[0][0] == packed[2][0] == oracle.zge_encode(small)
+    for z in libzstds:
+        assert z.decompress(packed[1][0], len(raw))[0] == raw
+    res = emu_engine.unpack([p[0] for p in packed], [len(small), len(raw), len(small)], [p[1] for p in packed])
+    assert [r[2] for r in res] == [0, 0, 0] and res[1][0] == raw

@@ -58,6 +58,7 @@ struct zarc_gpu {
     hipStream_t stream_stage = nullptr; // PCIe staging of the host-pointer entry points: its copies never queue behind side kernels
     hipStream_t stream_stage_out = nullptr; // the way out has its own stream (and helper thread): PCIe carries both directions at once
     // descriptors
+    DevBuf d_units; // encoder: (queue slot, first block) of every 2 MiB segment
     DevBuf d_off, d_len, d_chunk_prefix, d_block_prefix, d_order, d_dst_off, d_dst_len, d_raw_len, d_frame_off, d_frame_len;
     // hashing
     DevBuf d_cvs, d_cvs_tmp, d_digests, d_xxh, d_expect;
@@ -282,7 +283,7 @@ void zarc_gpu_destroy(zarc_gpu_t *h)
     DevBuf *all[] = {&h->d_off, &h->d_len, &h->d_chunk_prefix, &h->d_block_prefix, &h->d_order, &h->d_dst_off, &h->d_dst_len, &h->d_raw_len,
                      &h->d_frame_off, &h->d_frame_len, &h->d_cvs, &h->d_cvs_tmp, &h->d_digests, &h->d_xxh, &h->d_expect, &h->d_blocks, &h->d_seq,
                      &h->d_lit, &h->d_out, &h->d_far, &h->d_declit, &h->d_status, &h->d_stored_ck, &h->d_arena_in, &h->d_arena_out, &h->d_queue,
-                     &h->d_slot_prefix, &h->d_zblocks, &h->d_nseq, &h->d_fast, &h->d_seqidx, &h->d_seqs, &h->d_ztables, &h->d_litidx, &h->d_lits};
+                     &h->d_units, &h->d_slot_prefix, &h->d_zblocks, &h->d_nseq, &h->d_fast, &h->d_seqidx, &h->d_seqs, &h->d_ztables, &h->d_litidx, &h->d_lits};
     for (DevBuf *b : all) b->release();
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
     for (auto &row : h->ev_g) for (auto &e : row) if (e) (void)hipEventDestroy(e);
@@ -528,13 +529,38 @@ int zarc_gpu_pack_batch_device(zarc_gpu_t *h, size_t n, const void *d_src_base, 
         ZHIP(t.mark(&a));
         ZHIP(hipMemsetAsync(h->d_queue.p, 0, 256, h->stream));
         const bool deep = P.long_log == 14;
-        const size_t match_grid = std::min<size_t>(m, (size_t)h->num_cus * (deep ? 1 : 2)); // two 80 KiB workgroups fit a CU, one of 145 KiB
+        // the match finder's units of work: the 2^seg_log segments (16 blocks) of every frame, largest frames first
+        std::vector<uint32_t> units;
+        {
+            const uint32_t seg_blocks = (1u << P.seg_log) / ZARC_BLOCK;
+            // longest unit first (the queue is a longest-processing-time-first schedule): an unsplit frame of 8 MiB is a longer piece of
+            // work than a 2 MiB segment of a split one and has to start before them; the segments of split frames are interleaved frame
+            // by frame (equal size: the stable sort keeps that order)
+            struct U { uint64_t bytes; uint32_t slot, b0; };
+            std::vector<U> us;
+            size_t n_split = 0;
+            uint64_t max_blocks = 0;
+            while (n_split < m && src_len[order[start + n_split]] > ZARC_SPLIT_MIN) { max_blocks = std::max<uint64_t>(max_blocks, bp[n_split + 1] - bp[n_split]); n_split++; }
+            for (uint64_t b0 = 0; b0 < max_blocks; b0 += seg_blocks)
+                for (size_t j = 0; j < n_split; j++)
+                    if (b0 < bp[j + 1] - bp[j]) {
+                        const uint64_t len = src_len[order[start + j]], at = b0 * (uint64_t)ZARC_BLOCK;
+                        us.push_back(U{std::min<uint64_t>(len - at, (uint64_t)seg_blocks * ZARC_BLOCK), (uint32_t)j, (uint32_t)b0});
+                    }
+            for (size_t j = n_split; j < m; j++) us.push_back(U{src_len[order[start + j]], (uint32_t)j, 0u}); // smaller frames are one unit (zge_match.hip)
+            std::stable_sort(us.begin(), us.end(), [](const U &x, const U &y) { return x.bytes > y.bytes; });
+            units.reserve(us.size() * 2);
+            for (const U &u : us) { units.push_back(u.slot); units.push_back(u.b0); }
+        }
+        const size_t n_units = units.size() / 2;
+        if ((rc = upload_u32(h, h->d_units, units.data(), units.size()))) return rc;
+        const size_t match_grid = std::min<size_t>(n_units, (size_t)h->num_cus * (deep ? 1 : 2)); // two 80 KiB workgroups fit a CU, one of 145 KiB
         ZHIP(h->d_far.reserve(match_grid * zge_far_words(P) * 4 + 16)); // one far-table slab per resident workgroup (cleared by the kernel per frame)
         auto match_kernel = deep ? zarc_zge_match_deep : zarc_zge_match;
 #ifdef ZARC_GPU_DIAG
         if (!deep && P.dbg) match_kernel = zarc_zge_match_diag;
 #endif
-        hipLaunchKernelGGL(match_kernel, dim3((unsigned)match_grid), dim3(512), 0, h->stream, P, base, d_off, d_len, h->d_order.as<uint32_t>(), (uint32_t)m,
+        hipLaunchKernelGGL(match_kernel, dim3((unsigned)match_grid), dim3(512), 0, h->stream, P, base, d_off, d_len, h->d_order.as<uint32_t>(), h->d_units.as<uint32_t>(), (uint32_t)n_units,
                            h->d_block_prefix.as<uint64_t>(), h->d_blocks.as<ZgeBlock>(), h->d_seq.as<uint64_t>(), h->d_lit.as<uint8_t>(),
                            h->d_queue.as<uint32_t>(), h->d_far.as<uint32_t>());
         ZHIP(hipGetLastError());

@@ -60,6 +60,7 @@ constexpr int ZDEC_LIT_GROUP = 16;  // block slots per wave of zarc_zdec_literal
 // Fast-path sequences are stored with zge_pack_seq(); the offset field is already resolved against the repeat-offset history
 // as far as the block alone allows: bit 17 of the literal-length field set = the offset is (history slot at block start) - delta,
 // the offset field then holds slot | delta << 2; otherwise the offset field is the absolute offset.
+constexpr uint32_t ZARC_SPLIT_MIN = 4u << 20; // encoder: frames larger than this are searched segment by segment (2 MiB) by different workgroups
 constexpr uint32_t ZDEC_LL_REF = 1u << 17;
 constexpr uint32_t ZDEC_MAX_DELTA = 1u << 20; // "history slot minus delta": repeated `first history entry - 1` codes add up (libzstd -9 .. -19 on records-like data)
 constexpr uint32_t ZDEC_REP_REF = 0x80000000u; // same idea for ZdecBlock::rep[]: REF | slot | delta << 2
@@ -105,15 +106,15 @@ __global__ void zarc_corpus_fill(uint8_t *base, const uint64_t *off, const uint6
 
 // encoder
 __global__ void zarc_zge_match(ZgeParams P, const uint8_t *src_base, const uint64_t *src_off, const uint64_t *src_len,
-                               const uint32_t *order, uint32_t n_frames, const uint64_t *block_prefix, ZgeBlock *blocks,
+                               const uint32_t *order, const uint32_t *units /* (queue slot, first block) per 2 MiB segment */, uint32_t n_units, const uint64_t *block_prefix, ZgeBlock *blocks,
                                uint64_t *seq_scratch, uint8_t *lit_scratch, uint32_t *queue, uint32_t *far_scratch);
 // the deep finder (level >= 9): same arguments, 2^14-entry tables (one workgroup per CU), 4-byte short hash
 __global__ void zarc_zge_match_diag(ZgeParams P, const uint8_t *src_base, const uint64_t *src_off, const uint64_t *src_len,
-                               const uint32_t *order, uint32_t n_frames, const uint64_t *block_prefix, ZgeBlock *blocks,
+                               const uint32_t *order, const uint32_t *units /* (queue slot, first block) per 2 MiB segment */, uint32_t n_units, const uint64_t *block_prefix, ZgeBlock *blocks,
                                uint64_t *seq_scratch, uint8_t *lit_scratch, uint32_t *queue, uint32_t *far_scratch);
 // the deep finder (level >= 9): same arguments, 2^14-entry tables (one workgroup per CU), 4-byte short hash
 __global__ void zarc_zge_match_deep(ZgeParams P, const uint8_t *src_base, const uint64_t *src_off, const uint64_t *src_len,
-                                    const uint32_t *order, uint32_t n_frames, const uint64_t *block_prefix, ZgeBlock *blocks,
+                                    const uint32_t *order, const uint32_t *units /* (queue slot, first block) per 2 MiB segment */, uint32_t n_units, const uint64_t *block_prefix, ZgeBlock *blocks,
                                     uint64_t *seq_scratch, uint8_t *lit_scratch, uint32_t *queue, uint32_t *far_scratch);
 __global__ void zarc_zge_entropy(uint32_t n_blocks, ZgeBlock *blocks, uint64_t *seq_scratch, const uint8_t *lit_scratch,
                                  uint8_t *out_scratch, unsigned long long *prof);

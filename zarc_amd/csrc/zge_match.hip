@@ -151,7 +151,7 @@ __device__ __forceinline__ uint32_t tile_end(uint32_t tile, uint32_t n)
 // offset of the repeat -- the memory requests per tile (what the far tables cost) go down by that factor.
 template <int TAB_LOG, int SHORT_BYTES, int MATCH_COST, int F_FAR_LOG, int FAR_WAYS, bool FAR_SHORT, int FAR_STEP_LOG, int FAR_RES_LOG, int FAR_SKIP, int FAR_BACK, bool DIAG>
 __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgeParams &P, const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off,
-                                               const uint64_t *__restrict__ src_len, const uint32_t *__restrict__ order, uint32_t n_frames,
+                                               const uint64_t *__restrict__ src_len, const uint32_t *__restrict__ order, const uint32_t *__restrict__ units, uint32_t n_units,
                                                const uint64_t *__restrict__ block_prefix, ZgeBlock *__restrict__ blocks,
                                                uint64_t *__restrict__ seq_scratch, uint8_t *__restrict__ lit_scratch, uint32_t *__restrict__ queue,
                                                uint32_t *__restrict__ far_scratch)
@@ -173,13 +173,19 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
     unsigned long long tprev = ZGE_CLOCK();
     if (tid < 12) L.prof[tid] = 0;
 
-    // Persistent workgroups: the grid is what the chip holds at once (two per CU); every workgroup takes the next frame
-    // from a queue (largest first), so slow and fast frames balance across XCDs whatever their order in the batch.
+    // Persistent workgroups: the grid is what the chip holds at once (two per CU); every workgroup takes the next UNIT from a queue
+    // (largest frames first), so slow and fast frames balance across XCDs whatever their order in the batch.  A unit is one 2^seg_log
+    // segment (16 blocks) of a frame: the tables restart at every segment anyway, so the segments of a large frame are independent
+    // pieces of work -- a 1 GiB entry is 512 units for 512 workgroups, not a 10-second chain for one.  Everything the finder carries
+    // from tile to tile (tables, recent-offset guesses, the cold-stretch counters) starts afresh with a unit (model: the same resets at
+    // every segment boundary).
+    constexpr uint32_t SEG_BLOCKS = (1u << F_SEG_LOG) / ZARC_BLOCK;
     for (;;) {
     if (tid == 0) L.ctrl[K_SLOT] = atomicAdd(queue, 1u);
     zd::lds_barrier();
-    const uint32_t slot = L.ctrl[K_SLOT];
-    if (slot >= n_frames) break; // uniform: every wave leaves once the queue is empty
+    const uint32_t unit = L.ctrl[K_SLOT];
+    if (unit >= n_units) break; // uniform: every wave leaves once the queue is empty
+    const uint32_t slot = units[2 * unit], ub0 = units[2 * unit + 1]; // queue slot of the frame, first block of the segment
     const uint32_t f = order[slot];
     const uint8_t *src = src_base + src_off[f];
     const uint32_t n = (uint32_t)src_len[f]; // the engine rejects entries of 4 GiB or more: positions are 32-bit
@@ -222,7 +228,10 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
 #pragma unroll
         for (int k = 0; k < (NFAR ? NFAR : 1); k++) fnext[u][k] = 0;
 
-    for (uint32_t b = 0; b < nblocks; b++) {
+    // (frames up to ZARC_SPLIT_MIN stay one unit: their recent-offset guesses run on across segment boundaries, which is worth a few
+    // hundred bytes per boundary on periodic data -- nothing for a large frame, a third of a 4 MB periodic buffer's 600 bytes)
+    const uint32_t ub1 = (n > ZARC_SPLIT_MIN && ub0 + SEG_BLOCKS < nblocks) ? ub0 + SEG_BLOCKS : nblocks;
+    for (uint32_t b = ub0; b < ub1; b++) {
         const uint32_t bs = b * ZARC_BLOCK;
         const uint32_t be = n - bs > ZARC_BLOCK ? bs + ZARC_BLOCK : n;
         const uint32_t blen = (uint32_t)(be - bs);
@@ -230,7 +239,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
         uint64_t *seq_out = seq_scratch + (first_block + b) * (uint64_t)ZARC_MAX_SEQ;
         uint8_t *lit_out = lit_scratch + (first_block + b) * (uint64_t)(ZARC_BLOCK + 64);
 
-        if (bs > 0 && (bs & seg_mask) == 0) { // new 2^seg_log segment (a multiple of the block size): table positions restart
+        if (b > ub0 && (bs & seg_mask) == 0) { // a frame that is one unit: new 2^seg_log segment (a multiple of the block size), table positions restart
             for (int i = tid; i < (1 << TAB_LOG); i += THREADS) { L.tl[i] = 0; L.ts[i] = 0; }
             if (NFAR) {
                 uint4 *f4 = (uint4 *)far_l;
@@ -820,35 +829,35 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
 #undef score_of
 
 __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off,
-                                                      const uint64_t *__restrict__ src_len, const uint32_t *__restrict__ order, uint32_t n_frames,
+                                                      const uint64_t *__restrict__ src_len, const uint32_t *__restrict__ order, const uint32_t *__restrict__ units, uint32_t n_units,
                                                       const uint64_t *__restrict__ block_prefix, ZgeBlock *__restrict__ blocks,
                                                       uint64_t *__restrict__ seq_scratch, uint8_t *__restrict__ lit_scratch, uint32_t *__restrict__ queue,
                                                       uint32_t *__restrict__ far_scratch)
 {
     __shared__ MatchLds<13> L;
-    zge_match_body<13, 5, 12, 16, 1, false, 5, 2, 64, 24, false>(L, P, src_base, src_off, src_len, order, n_frames, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
+    zge_match_body<13, 5, 12, 16, 1, false, 5, 2, 64, 24, false>(L, P, src_base, src_off, src_len, order, units, n_units, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
 }
 
 #ifdef ZARC_GPU_DIAG
 // the same kernel with the ZARC_GPU_DBG switches (stage clocks, timing-only ablations): only in the diagnostic build of the
 // library (make DIAG=1 -> libzarc_gpu_diag.so, used by tools/); the product library has no such code
 __global__ void __launch_bounds__(512, 4) zarc_zge_match_diag(ZgeParams P, const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off,
-                                                           const uint64_t *__restrict__ src_len, const uint32_t *__restrict__ order, uint32_t n_frames,
+                                                           const uint64_t *__restrict__ src_len, const uint32_t *__restrict__ order, const uint32_t *__restrict__ units, uint32_t n_units,
                                                            const uint64_t *__restrict__ block_prefix, ZgeBlock *__restrict__ blocks,
                                                            uint64_t *__restrict__ seq_scratch, uint8_t *__restrict__ lit_scratch, uint32_t *__restrict__ queue,
                                                            uint32_t *__restrict__ far_scratch)
 {
     __shared__ MatchLds<13> L;
-    zge_match_body<13, 5, 12, 16, 1, false, 5, 2, 64, 24, true>(L, P, src_base, src_off, src_len, order, n_frames, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
+    zge_match_body<13, 5, 12, 16, 1, false, 5, 2, 64, 24, true>(L, P, src_base, src_off, src_len, order, units, n_units, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
 }
 #endif
 
 __global__ void __launch_bounds__(512, 2) zarc_zge_match_deep(ZgeParams P, const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off,
-                                                           const uint64_t *__restrict__ src_len, const uint32_t *__restrict__ order, uint32_t n_frames,
+                                                           const uint64_t *__restrict__ src_len, const uint32_t *__restrict__ order, const uint32_t *__restrict__ units, uint32_t n_units,
                                                            const uint64_t *__restrict__ block_prefix, ZgeBlock *__restrict__ blocks,
                                                            uint64_t *__restrict__ seq_scratch, uint8_t *__restrict__ lit_scratch, uint32_t *__restrict__ queue,
                                                            uint32_t *__restrict__ far_scratch)
 {
     __shared__ MatchLds<14> L;
-    zge_match_body<14, 4, 10, 16, 2, true, 1, 0, 0, 8, false>(L, P, src_base, src_off, src_len, order, n_frames, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
+    zge_match_body<14, 4, 10, 16, 2, true, 1, 0, 0, 8, false>(L, P, src_base, src_off, src_len, order, units, n_units, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
 }
