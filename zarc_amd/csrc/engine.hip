@@ -59,6 +59,7 @@ struct zarc_gpu {
     hipStream_t stream_stage_out = nullptr; // the way out has its own stream (and helper thread): PCIe carries both directions at once
     // descriptors
     DevBuf d_units; // encoder: (queue slot, first block) of every 2 MiB segment
+    DevBuf d_pieces; // decoder: ZdecPiece per unit of work of the frame pass
     DevBuf d_off, d_len, d_chunk_prefix, d_block_prefix, d_order, d_dst_off, d_dst_len, d_raw_len, d_frame_off, d_frame_len;
     // hashing
     DevBuf d_cvs, d_cvs_tmp, d_digests, d_xxh, d_expect;
@@ -75,10 +76,10 @@ struct zarc_gpu {
     DevBuf d_arena_in, d_arena_out;
     hipEvent_t ev[16] = {};
     // decoder groups (zarc_gpu_unpack_batch_device): a pair of streams per group; events: 0/1 sequences, 2/3 literals, 4/5 frame passes, 6/7 checksum,
-    // 8/9 digest, 10 literals done (join)
+    // 8/9 digest, 10 literals done (join), 11 both stages ahead done (the host waits for it when it cuts frames into pieces)
     static constexpr int DEC_GROUPS = 4;
     hipStream_t gs[2 * DEC_GROUPS] = {};
-    hipEvent_t ev_g[DEC_GROUPS][11] = {};
+    hipEvent_t ev_g[DEC_GROUPS][12] = {};
     int dec_groups = 0;        // ZARC_GPU_PX_DEC_GROUPS: 0 = by the batch's shape
     uint64_t dec_split_above = 0; // unpack: a batch of this many content bytes ran out of device memory; such batches are split at once
     float ms[ZARC_GPU_T_COUNT];
@@ -283,7 +284,7 @@ void zarc_gpu_destroy(zarc_gpu_t *h)
     DevBuf *all[] = {&h->d_off, &h->d_len, &h->d_chunk_prefix, &h->d_block_prefix, &h->d_order, &h->d_dst_off, &h->d_dst_len, &h->d_raw_len,
                      &h->d_frame_off, &h->d_frame_len, &h->d_cvs, &h->d_cvs_tmp, &h->d_digests, &h->d_xxh, &h->d_expect, &h->d_blocks, &h->d_seq,
                      &h->d_lit, &h->d_out, &h->d_far, &h->d_declit, &h->d_status, &h->d_stored_ck, &h->d_arena_in, &h->d_arena_out, &h->d_queue,
-                     &h->d_units, &h->d_slot_prefix, &h->d_zblocks, &h->d_nseq, &h->d_fast, &h->d_seqidx, &h->d_seqs, &h->d_ztables, &h->d_litidx, &h->d_lits};
+                     &h->d_units, &h->d_pieces, &h->d_slot_prefix, &h->d_zblocks, &h->d_nseq, &h->d_fast, &h->d_seqidx, &h->d_seqs, &h->d_ztables, &h->d_litidx, &h->d_lits};
     for (DevBuf *b : all) b->release();
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
     for (auto &row : h->ev_g) for (auto &e : row) if (e) (void)hipEventDestroy(e);
@@ -746,6 +747,7 @@ int unpack_device_once(zarc_gpu_t *h, size_t n, const void *d_frames_base, const
         ZHIP(h->d_lits.reserve(std::max<uint64_t>(lit_total, 1) + 64));
     }
     ZHIP(hipMemsetAsync(h->d_queue.p, 0, 256, h->stream)); // two queues per group: the fast frame pass and the general decoder each walk the group's frames
+    ZHIP(hipMemsetAsync(h->d_status.p, 0, n * 4, h->stream)); // the pieces of a frame raise its status with atomicMax
     ZHIP(hipEventRecord(h->ev_fork, h->stream)); // descriptors are in place
     const int dec_dbg = diag_env("ZARC_GPU_DBG_DEC", 0);
     const bool side = diag_env("ZARC_GPU_DEC_SIDE", 1) != 0;
@@ -756,6 +758,16 @@ int unpack_device_once(zarc_gpu_t *h, size_t n, const void *d_frames_base, const
     if (lds_frac < 0) lds_frac = 0;
     if (lds_frac > 1) lds_frac = 1;
     bool have_seq_t[zarc_gpu::DEC_GROUPS] = {}, have_lit_t[zarc_gpu::DEC_GROUPS] = {};
+    std::vector<uint32_t> nblk_of(n); // blocks per frame (sorted order)
+    for (size_t i = 0; i < n; i++) nblk_of[i] = (uint32_t)(slot_prefix[i + 1] - slot_prefix[i]);
+    std::vector<ZdecPiece> pieces[zarc_gpu::DEC_GROUPS];
+    std::vector<ZdecBlock> hblocks;
+    std::vector<uint32_t> hfast;
+    ZHIP(h->d_pieces.reserve((nslots / 8 + n + 16) * sizeof(ZdecPiece)));
+    size_t piece_base = 0;
+    // phase 0 queues the stages ahead of every group, phase 1 the frame passes and hashes: in between the host may have to look at what
+    // stage 2 found out about a group's blocks (pieces, below), and the next group's stages ahead must be running by then
+    for (int phase = 0; phase < 2; phase++)
     for (int g = 0; g < groups; g++) {
         // The stages ahead (sequences, literals) of all groups follow each other on the engine's two streams -- several sequence kernels side
         // by side were measured and only slow each other down (they live on MALL / fabric latency) -- while the frame pass and the hashes
@@ -764,8 +776,8 @@ int unpack_device_once(zarc_gpu_t *h, size_t n, const void *d_frames_base, const
         hipStream_t sa = groups == 1 ? h->stream : h->gs[2 * g], sb = groups == 1 ? h->stream2 : h->gs[2 * g + 1];
         hipEvent_t *ev = h->ev_g[g];
         const size_t f0 = gf[g], f1 = gf[g + 1], ng = f1 - f0;
-        if (g == 0) ZHIP(hipStreamWaitEvent(pb, h->ev_fork, 0));
-        if (fastpath) {
+        if (phase == 0 && g == 0) ZHIP(hipStreamWaitEvent(pb, h->ev_fork, 0));
+        if (phase == 0 && fastpath) {
             hipStream_t sa_post = sa, sb_post = sb;
             sa = pa; sb = pb; // this block launches the stages ahead
             const uint64_t s0 = slot_prefix[f0], s1 = slot_prefix[f1];
@@ -808,13 +820,72 @@ int unpack_device_once(zarc_gpu_t *h, size_t n, const void *d_frames_base, const
             sa = sa_post; sb = sb_post;
             if (groups > 1) { ZHIP(hipEventRecord(ev[1], pa)); ZHIP(hipStreamWaitEvent(sa, ev[1], 0)); } // (re-recorded when the group has no sequences: it still orders the group behind the descriptors)
             if (g_lits && side) { ZHIP(hipEventRecord(ev[10], pb)); ZHIP(hipStreamWaitEvent(sa, ev[10], 0)); }
+            ZHIP(hipEventRecord(ev[11], sa));
+        }
+        if (phase == 0) continue;
+        // ---- pieces: the units of work of the frame pass.  A frame is a chain for one wave (its matches read what its earlier blocks
+        // wrote) -- unless stage 2's summaries show that from some block on nothing in front of that block is read: the engine's own
+        // frames are made of independent 2 MiB segments (zge_match.hip), libzstd's multi-threaded ones of independent jobs.  The host
+        // cuts such frames (4 MiB and more) at those blocks, gives every piece its output position and repeat-offset history, and the
+        // pieces decode side by side.
+        if (fastpath) {
+            const uint64_t s0 = slot_prefix[f0], s1 = slot_prefix[f1];
+            bool large = false;
+            for (size_t i = f0; i < f1 && !large; i++) large = nblk_of[i] >= 32;
+            if (large) {
+                ZHIP(hipEventSynchronize(ev[11]));
+                hblocks.resize(s1 - s0); hfast.resize(ng);
+                ZHIP(hipMemcpyAsync(hblocks.data(), h->d_zblocks.as<ZdecBlock>() + s0, (s1 - s0) * sizeof(ZdecBlock), hipMemcpyDeviceToHost, sa));
+                ZHIP(hipMemcpyAsync(hfast.data(), h->d_fast.as<uint32_t>() + f0, ng * 4, hipMemcpyDeviceToHost, sa));
+                ZHIP(hipStreamSynchronize(sa));
+            }
+            std::vector<ZdecPiece> &pc = pieces[g];
+            std::vector<uint64_t> start, need;
+            for (size_t i = f0; i < f1; i++) {
+                const uint32_t nb = nblk_of[i];
+                ZdecPiece whole{(uint32_t)i, 0u, 0xFFFFFFFFu, {1u, 4u, 8u}, 0ull, raw_len[i]};
+                if (!large || nb < 32 || !hfast[i - f0]) { pc.push_back(whole); continue; }
+                const ZdecBlock *zb = hblocks.data() + (slot_prefix[i] - s0);
+                // where every block's output starts, and the lowest position it reads
+                start.assign(nb + 1, 0); need.assign(nb + 1, ~0ull);
+                bool usable = true;
+                for (uint32_t j = 0; j < nb && usable; j++) {
+                    if (zb[j].type > 2 || (zb[j].type == 2 && zb[j].nseq && zb[j].state != 1)) usable = false;
+                    start[j + 1] = start[j] + zb[j].pad[1];
+                    need[j] = (zb[j].pad[0] == ZDEC_REACH_UNKNOWN || zb[j].pad[0] > start[j]) ? 0 : start[j] - zb[j].pad[0];
+                }
+                if (!usable || start[nb] != raw_len[i]) { pc.push_back(whole); continue; }
+                for (uint32_t j = nb; j-- > 0;) need[j] = std::min(need[j], need[j + 1]); // lowest position read by block j or any later one
+                uint32_t r[3] = {1u, 4u, 8u}, first = 0, rfirst[3] = {1u, 4u, 8u};
+                bool rep_ok = true;
+                for (uint32_t j = 0; j <= nb; j++) {
+                    const bool cut = j == nb || (j > first && j - first >= 8 && nb - j >= 8 && need[j] >= start[j] && rep_ok);
+                    if (cut) {
+                        pc.push_back(ZdecPiece{(uint32_t)i, first, j == nb ? 0xFFFFFFFFu : j - first, {rfirst[0], rfirst[1], rfirst[2]}, start[first], start[j] - start[first]});
+                        first = j; rfirst[0] = r[0]; rfirst[1] = r[1]; rfirst[2] = r[2];
+                    }
+                    if (j == nb) break;
+                    if (zb[j].type == 2 && zb[j].nseq) { // history after the block, from its symbolic summary
+                        uint32_t nr[3];
+                        for (int k = 0; k < 3; k++) {
+                            const uint32_t e = zb[j].rep[k];
+                            if (e & ZDEC_REP_REF) { const uint32_t hv = r[e & 3], delta = (e & ~ZDEC_REP_REF) >> 2; if ((e & 3) > 2 || hv <= delta) { rep_ok = false; nr[k] = 1; } else nr[k] = hv - delta; }
+                            else nr[k] = e;
+                        }
+                        r[0] = nr[0]; r[1] = nr[1]; r[2] = nr[2];
+                    }
+                }
+            }
+            std::stable_sort(pc.begin(), pc.end(), [](const ZdecPiece &x, const ZdecPiece &y) { return x.out_len > y.out_len; }); // longest first
+            ZHIP(hipMemcpyAsync(h->d_pieces.as<ZdecPiece>() + piece_base, pc.data(), pc.size() * sizeof(ZdecPiece), hipMemcpyHostToDevice, sa));
         }
         ZHIP(hipEventRecord(ev[4], sa));
         const size_t grid_g = std::max<size_t>(1, std::min<size_t>(ng, dec_grid / (size_t)groups));
         if (fastpath) {
-            hipLaunchKernelGGL(zarc_zstd_frames, dim3((unsigned)std::min<size_t>(ng, dec_grid)), dim3(64), 0, sa, (const uint8_t *)d_frames_base, h->d_frame_off.as<uint64_t>(),
+            const size_t np = pieces[g].size();
+            hipLaunchKernelGGL(zarc_zstd_frames, dim3((unsigned)std::min<size_t>(np, (size_t)h->num_cus * 16)), dim3(64), 0, sa, (const uint8_t *)d_frames_base, h->d_frame_off.as<uint64_t>(),
                                h->d_frame_len.as<uint64_t>(), (uint8_t *)d_dst_base, h->d_dst_off.as<uint64_t>(), h->d_raw_len.as<uint64_t>(),
-                               h->d_order.as<uint32_t>() + f0, (uint32_t)ng, h->d_status.as<int32_t>(), h->d_stored_ck.as<uint32_t>(), dec_dbg, h->d_queue.as<uint32_t>() + 2 * g,
+                               h->d_pieces.as<ZdecPiece>() + piece_base, (uint32_t)np, h->d_status.as<int32_t>(), h->d_stored_ck.as<uint32_t>(), dec_dbg, h->d_queue.as<uint32_t>() + 2 * g,
                                h->d_fast.as<uint32_t>(), h->d_slot_prefix.as<uint64_t>(), h->d_zblocks.as<ZdecBlock>(), h->d_seqidx.as<uint64_t>(),
                                h->d_seqs.as<uint64_t>(), h->d_litidx.as<uint64_t>(), h->d_lits.as<uint8_t>());
             ZHIP(hipGetLastError());
@@ -848,6 +919,7 @@ int unpack_device_once(zarc_gpu_t *h, size_t n, const void *d_frames_base, const
             ZHIP(hipGetLastError());
         }
         ZHIP(hipEventRecord(ev[9], sa));
+        piece_base += pieces[g].size();
     }
     // join: the decode time ends with the last group's frame pass, the whole call with the last hash
     for (int g = 0; g < groups; g++) if (groups > 1) ZHIP(hipStreamWaitEvent(h->stream, h->ev_g[g][5], 0));
@@ -872,7 +944,9 @@ int unpack_device_once(zarc_gpu_t *h, size_t n, const void *d_frames_base, const
         ZHIP(hipMemcpy(fl.data(), h->d_fast.p, n * 4, hipMemcpyDeviceToHost));
         size_t nf = 0;
         for (uint32_t v : fl) nf += v != 0;
-        fprintf(stderr, "zstd_decode: %zu of %zu frames on the fast path, %d group(s)\n", nf, n, groups);
+        size_t np = 0;
+        for (int g = 0; g < groups; g++) np += pieces[g].size();
+        fprintf(stderr, "zstd_decode: %zu of %zu frames on the fast path, %d group(s), %zu piece(s)\n", nf, n, groups, np);
     }
     h->ms[ZARC_GPU_T_DECODE] = elapsed(h, e0, e1);
     // per-kernel times: sums over the groups (with several groups the kernels of different groups overlap, so the sums exceed T_DECODE)

@@ -52,7 +52,7 @@ struct ZdecBlock {
     uint32_t lit_off;  // Huffman literals: frame offset of the section body (tree description, then the streams)
     uint32_t lit_comp; // Huffman literals: bytes of that body
     uint32_t lit_streams; // 1 or 4
-    uint32_t pad[3];
+    uint32_t pad[3];   // [0] reach: bytes in front of the block its matches read at most (ZDEC_REACH_UNKNOWN: anywhere); [1] bytes the block regenerates
 };
 static_assert(sizeof(ZdecBlock) == 72, "block slot layout");
 constexpr int ZDEC_LDS_LANES = 16;  // active lanes (= block slots) per wave of zarc_zdec_seqs_lds: 16 x 2.5 KiB of tables in LDS
@@ -63,6 +63,13 @@ constexpr int ZDEC_LIT_GROUP = 16;  // block slots per wave of zarc_zdec_literal
 constexpr uint32_t ZARC_SPLIT_MIN = 4u << 20; // encoder: frames larger than this are searched segment by segment (2 MiB) by different workgroups
 constexpr uint32_t ZDEC_LL_REF = 1u << 17;
 constexpr uint32_t ZDEC_MAX_DELTA = 1u << 20; // "history slot minus delta": repeated `first history entry - 1` codes add up (libzstd -9 .. -19 on records-like data)
+// A run of blocks of one frame that reads nothing in front of its first block: the unit of work of the fast frame pass (engine.hip).
+struct ZdecPiece {
+    uint32_t frame, first, count; // frame index; first block; number of blocks (a whole frame: first 0, count 0xFFFFFFFF)
+    uint32_t rep[3];              // repeat-offset history in front of the first block
+    uint64_t out_start, out_len;  // where the piece's output starts inside the frame's, and how many bytes its blocks regenerate
+};
+constexpr uint32_t ZDEC_REACH_UNKNOWN = 0xFFFFFFFFu; // ZdecBlock.pad[0]: the block's matches may reach anywhere in front of it
 constexpr uint32_t ZDEC_REP_REF = 0x80000000u; // same idea for ZdecBlock::rep[]: REF | slot | delta << 2
 constexpr int ZDEC_TABLE_CELLS = 1280; // per block slot: LL 512 + ML 512 + OF 256 FSE decode cells (u16)
 
@@ -77,7 +84,7 @@ __global__ void zarc_zstd_decode(const uint8_t *frames_base, const uint64_t *fra
                                  const uint32_t *fast /* per frame: handled by zarc_zstd_frames; null = take every frame */);
 // frame pass of the decoder fast path: frames whose sequences and literals were decoded ahead (fast[f] != 0)
 __global__ void zarc_zstd_frames(const uint8_t *frames_base, const uint64_t *frame_off, const uint64_t *frame_len, uint8_t *dst_base,
-                                 const uint64_t *dst_off, const uint64_t *raw_len, const uint32_t *order, uint32_t n_frames, int32_t *status,
+                                 const uint64_t *dst_off, const uint64_t *raw_len, const ZdecPiece *pieces, uint32_t n_pieces, int32_t *status,
                                  uint32_t *stored_checksum, int dbg, uint32_t *queue, const uint32_t *fast, const uint64_t *slot_prefix,
                                  const ZdecBlock *zblocks, const uint64_t *seq_index, const uint64_t *seqs, const uint64_t *lit_index,
                                  const uint8_t *lits);

@@ -667,7 +667,8 @@ __device__ __forceinline__ void decode_frame(Lds &L, const int lane, const uint3
                                              const uint64_t *__restrict__ dst_off, const uint64_t *__restrict__ raw_len,
                                              int32_t *__restrict__ status, uint32_t *__restrict__ stored_checksum, const int dbg,
                                              const ZdecBlock *__restrict__ fblocks, const uint64_t *__restrict__ fseq_index,
-                                             const uint64_t *__restrict__ seqs, const uint64_t *__restrict__ flit_index, const uint8_t *__restrict__ lits)
+                                             const uint64_t *__restrict__ seqs, const uint64_t *__restrict__ flit_index, const uint8_t *__restrict__ lits,
+                                             const ZdecPiece piece /* PRE: the blocks of the frame this call decodes (the whole frame: first 0, count ~0) */)
 {
     constexpr bool use_pre = PRE;
     const uint8_t *src = frames_base + frame_off[f];
@@ -717,11 +718,16 @@ __device__ __forceinline__ void decode_frame(Lds &L, const int lane, const uint3
     }
     err = (int)zd::uniform((uint32_t)err);
 
-    uint64_t opos = 0;          // bytes produced
-    uint32_t rep0 = 1, rep1 = 4, rep2 = 8;
+    // A piece starts at block piece.first with the output position and the repeat-offset history the host worked out from stage 2's
+    // block summaries (engine.hip: a piece's blocks read nothing in front of it, so the pieces of a frame decode side by side).
+    uint64_t opos = PRE ? piece.out_start : 0; // bytes produced
+    uint32_t rep0 = PRE ? piece.rep[0] : 1, rep1 = PRE ? piece.rep[1] : 4, rep2 = PRE ? piece.rep[2] : 8;
     bool last = false;
-    uint32_t bidx = 0; // block ordinal inside the frame (slot index of the fast path)
-    while (!err && !last) {
+    uint32_t bidx = PRE ? piece.first : 0; // block ordinal inside the frame (slot index of the fast path)
+    uint32_t blocks_left = PRE ? piece.count : 0xFFFFFFFFu;
+    if (PRE && piece.first) pos = fblocks[piece.first].payload - 3; // the piece's first block header
+    while (!err && !last && blocks_left) {
+        blocks_left--;
         const uint32_t my_b = bidx++;
         if (pos + 3 > slen) { err = ZARC_FRAME_SRCSIZE; break; }
         const uint32_t bh = zd::uniform((uint32_t)src[pos] | ((uint32_t)src[pos + 1] << 8) | ((uint32_t)src[pos + 2] << 16));
@@ -1118,6 +1124,11 @@ __device__ __forceinline__ void decode_frame(Lds &L, const int lane, const uint3
         if (opos - block_start > BLOCK_MAX) { err = ZARC_FRAME_CORRUPT; break; }
         zd::wave_sync_global(); // the next block may reference anything written so far; lit_buf is reused
     }
+    if (PRE && !last) { // a piece in front of the frame's last one: it must have produced exactly what the host expected of its blocks
+        if (!err && (blocks_left != 0 || opos != piece.out_start + piece.out_len)) err = ZARC_FRAME_CORRUPT;
+        if (lane == 0 && err) atomicMax(&status[f], err); // (statuses start at 0 = ok; the highest code of a frame's pieces wins, whatever their order)
+        return;
+    }
     if (!err && opos != cap) err = ZARC_FRAME_SRCSIZE;
     uint32_t ck = 0;
     if (!err && has_ck) {
@@ -1126,7 +1137,8 @@ __device__ __forceinline__ void decode_frame(Lds &L, const int lane, const uint3
     }
     if (!err && pos != slen) err = ZARC_FRAME_SRCSIZE;
     if (lane == 0) {
-        status[f] = err;
+        if (PRE) { if (err) atomicMax(&status[f], err); }
+        else status[f] = err;
         stored_checksum[2 * f] = has_ck;
         stored_checksum[2 * f + 1] = ck;
     }
@@ -1156,16 +1168,17 @@ __global__ void __launch_bounds__(64, 4) zarc_zstd_decode(const uint8_t *__restr
         const uint32_t f = order[slot];
         if (fast != nullptr && zd::uniform(fast[f]) != 0) continue; // zarc_zstd_frames has it
         decode_frame<false>(L, lane, f, lit_buf, frames_base, frame_off, frame_len, dst_base, dst_off, raw_len, status, stored_checksum, ZDEC_DBG(dbg), nullptr, nullptr,
-                            nullptr, nullptr, nullptr);
+                            nullptr, nullptr, nullptr, ZdecPiece{});
         zd::wave_sync_global(); // LDS tables and the literal buffer are reused by the next frame
     }
 }
 
-// The frame pass of the fast path: same queue discipline, frames whose sequences and literals were decoded ahead.
+// The frame pass of the fast path: same queue discipline over PIECES of frames whose sequences and literals were decoded ahead (a frame
+// that cannot be cut is one piece; pieces are listed longest first).
 __global__ void __launch_bounds__(64, 4) zarc_zstd_frames(const uint8_t *__restrict__ frames_base, const uint64_t *__restrict__ frame_off,
                                                        const uint64_t *__restrict__ frame_len, uint8_t *__restrict__ dst_base,
                                                        const uint64_t *__restrict__ dst_off, const uint64_t *__restrict__ raw_len,
-                                                       const uint32_t *__restrict__ order, uint32_t n_frames, int32_t *__restrict__ status,
+                                                       const ZdecPiece *__restrict__ pieces, uint32_t n_pieces, int32_t *__restrict__ status,
                                                        uint32_t *__restrict__ stored_checksum,
                                                        int dbg /* timing-only ablations: 1 no copies; 8 no near matches, 16 no flush, 32 no literal staging, 64 no far-match staging, 128 all near matches in order */,
                                                        uint32_t *__restrict__ queue, const uint32_t *__restrict__ fast,
@@ -1179,12 +1192,13 @@ __global__ void __launch_bounds__(64, 4) zarc_zstd_frames(const uint8_t *__restr
         uint32_t slot = 0;
         if (lane == 0) slot = atomicAdd(queue, 1u);
         slot = zd::uniform(slot);
-        if (slot >= n_frames) break;
-        const uint32_t f = order[slot];
+        if (slot >= n_pieces) break;
+        const ZdecPiece piece = pieces[slot];
+        const uint32_t f = piece.frame;
         if (zd::uniform(fast[f]) == 0) continue; // zarc_zstd_decode has it
         const uint64_t first = slot_prefix[f];
         decode_frame<true>(L, lane, f, nullptr, frames_base, frame_off, frame_len, dst_base, dst_off, raw_len, status, stored_checksum, ZDEC_DBG(dbg),
-                           zblocks + first, seq_index + first, seqs, lit_index + first, lits);
+                           zblocks + first, seq_index + first, seqs, lit_index + first, lits, piece);
         zd::wave_sync_global(); // the LDS staging buffer is reused by the next frame
     }
 }
@@ -1277,6 +1291,10 @@ __global__ void __launch_bounds__(64) zarc_zdec_scan(const uint8_t *__restrict__
             zb.seq_hdr = pos + lused + adv;
             pos += bsize;
         }
+        // pad[0] = how far in front of the block its matches reach (ZDEC_REACH_UNKNOWN until stage 2 has seen its sequences),
+        // pad[1] = the bytes the block regenerates: what the host needs to cut a frame into pieces that decode side by side
+        zb.pad[0] = (btype == 2 && zb.nseq) ? ZDEC_REACH_UNKNOWN : 0u;
+        zb.pad[1] = btype == 2 ? zb.lit_len : bsize;
         zblocks[first + bi] = zb;
         counts[2 * (first + bi)] = zb.nseq;
         counts[2 * (first + bi) + 1] = (btype == 2 && zb.lit_type >= 2) ? zb.lit_len : 0u;
@@ -1331,6 +1349,7 @@ __global__ void __launch_bounds__(64) zarc_zdec_seqs(const uint8_t *__restrict__
     int al[3] = {0, 0, 0};
     // repeat-offset history, symbolic: hv = offset (hr = 0) or hv = slot | delta << 2 of the history at block start (hr = 1)
     uint32_t hv0 = 0, hv1 = 1, hv2 = 2, hr0 = 1, hr1 = 1, hr2 = 1;
+    uint32_t bpos_ = 0, reach_ = 0, msum_ = 0; // output position inside the block, farthest reach in front of it, sum of the match lengths
     for (int t = 0; t < 3 && ok; t++) {
         uint32_t mode = own.mode[t], off = own.off[t], len = own.len[t];
         if (mode == 3) { // Repeat: the description lives in the nearest earlier block with sequences that set this table
@@ -1386,6 +1405,11 @@ __global__ void __launch_bounds__(64) zarc_zdec_seqs(const uint8_t *__restrict__
                     hv0 = ov; hr0 = orf;
                 }
             }
+            // where this match's source starts, relative to the block: in front of it by `reach` bytes at most (an offset that still
+            // refers to the history at the block's start is not known here)
+            bpos_ += ll;
+            if (orf) reach_ = ZDEC_REACH_UNKNOWN; else if (ov > bpos_ && ov - bpos_ > reach_) reach_ = ov - bpos_;
+            bpos_ += ml; msum_ += ml;
             zd::store_streaming(outp + i, zge_pack_seq(ll | (orf ? ZDEC_LL_REF : 0u), ml, ov)); // written once, read by the frame pass: keep it out of the way of the tables
             if (i + 1 < zb.nseq) {
                 sl = cell_base(cl, al[0]) + b.read((int)cell_nbits(cl, al[0]));
@@ -1400,6 +1424,8 @@ __global__ void __launch_bounds__(64) zarc_zdec_seqs(const uint8_t *__restrict__
         zblocks[s].rep[0] = hr0 ? (ZDEC_REP_REF | hv0) : hv0;
         zblocks[s].rep[1] = hr1 ? (ZDEC_REP_REF | hv1) : hv1;
         zblocks[s].rep[2] = hr2 ? (ZDEC_REP_REF | hv2) : hv2;
+        zblocks[s].pad[0] = reach_;
+        zblocks[s].pad[1] = zb.lit_len + msum_;
         zblocks[s].state = 1;
     }
     else fast[f] = 0; // the frame pass decodes this frame inline and reports whatever is wrong with it
@@ -1433,6 +1459,7 @@ __global__ void __launch_bounds__(ZDEC_LDS_LANES) zarc_zdec_seqs_lds(const uint8
     if (ok) { al_m = make_seq_table(&T[l][512], 2, own, src, s, f, slot_prefix, zblocks); ok = al_m >= 0; }
     // repeat-offset history, symbolic: hv = offset (hr = 0) or hv = slot | delta << 2 of the history at block start (hr = 1)
     uint32_t hv0 = 0, hv1 = 1, hv2 = 2, hr0 = 1, hr1 = 1, hr2 = 1;
+    uint32_t bpos_ = 0, reach_ = 0, msum_ = 0; // output position inside the block, farthest reach in front of it, sum of the match lengths
     if (ok) {
         Bits128 b;
         ok = b.init(src + own.bits_off, end - own.bits_off);
@@ -1470,6 +1497,11 @@ __global__ void __launch_bounds__(ZDEC_LDS_LANES) zarc_zdec_seqs_lds(const uint8
                     hv0 = ov; hr0 = orf;
                 }
             }
+            // where this match's source starts, relative to the block: in front of it by `reach` bytes at most (an offset that still
+            // refers to the history at the block's start is not known here)
+            bpos_ += ll;
+            if (orf) reach_ = ZDEC_REACH_UNKNOWN; else if (ov > bpos_ && ov - bpos_ > reach_) reach_ = ov - bpos_;
+            bpos_ += ml; msum_ += ml;
             zd::store_streaming(outp + i, zge_pack_seq(ll | (orf ? ZDEC_LL_REF : 0u), ml, ov)); // written once, read by the frame pass: keep it out of the way of the tables
             if (i + 1 < zb.nseq) {
                 sl = cell_base(cl, al_l) + b.take(cell_nbits(cl, al_l));
@@ -1484,6 +1516,8 @@ __global__ void __launch_bounds__(ZDEC_LDS_LANES) zarc_zdec_seqs_lds(const uint8
         zblocks[s].rep[0] = hr0 ? (ZDEC_REP_REF | hv0) : hv0;
         zblocks[s].rep[1] = hr1 ? (ZDEC_REP_REF | hv1) : hv1;
         zblocks[s].rep[2] = hr2 ? (ZDEC_REP_REF | hv2) : hv2;
+        zblocks[s].pad[0] = reach_;
+        zblocks[s].pad[1] = zb.lit_len + msum_;
         zblocks[s].state = 1;
     }
     else fast[f] = 0; // the frame pass decodes this frame inline and reports whatever is wrong with it
