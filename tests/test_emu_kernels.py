@@ -136,3 +136,21 @@ def test_emu_large_frame_is_searched_segment_by_segment(emu_engine, oracle, corp
         assert z.decompress(packed[1][0], len(raw))[0] == raw
     res = emu_engine.unpack([p[0] for p in packed], [len(small), len(raw), len(small)], [p[1] for p in packed])
     assert [r[2] for r in res] == [0, 0, 0] and res[1][0] == raw
+
+
+def test_emu_frame_pass_in_pieces(emu_engine, oracle, corpus, libzstd15):
+    """Frames of 4 MiB and more are cut into pieces wherever nothing in front of a block is read (engine.hip: pieces): libzstd's own
+    frames of text (every block reads the 2 MiB before it: one piece), of incompressible data (raw blocks: a piece every 8 blocks) and
+    the engine's (independent 2 MiB segments) must all come back bit-exact, together with small frames in the same batch."""
+    text = corpus.entry(5151, (4 << 20) + 700000, 0)
+    rnd = corpus.entry(5152, (4 << 20) + 300001, 3)
+    small = corpus.entry(5153, 90000, 1)
+    frames = [libzstd15.compress(text, 3, 1), libzstd15.compress(rnd, 3, 1), emu_engine.pack([text])[0][0], libzstd15.compress(small, 3, 1)]
+    raws = [text, rnd, text, small]
+    res = emu_engine.unpack(frames, [len(r) for r in raws], [oracle.blake3(r) for r in raws])
+    for raw, (out, dig, st) in zip(raws, res):
+        assert st == _lib.FRAME_OK and out == raw
+    # a corrupted large frame is reported, the others are not touched
+    bad = bytearray(frames[0]); bad[len(bad) // 2] ^= 0x55
+    res = emu_engine.unpack([bytes(bad), frames[1]], [len(text), len(rnd)], [oracle.blake3(text), oracle.blake3(rnd)])
+    assert res[0][2] != _lib.FRAME_OK and res[1][2] == _lib.FRAME_OK and res[1][0] == rnd

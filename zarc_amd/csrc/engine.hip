@@ -869,7 +869,10 @@ int unpack_device_once(zarc_gpu_t *h, size_t n, const void *d_frames_base, const
                         uint32_t nr[3];
                         for (int k = 0; k < 3; k++) {
                             const uint32_t e = zb[j].rep[k];
-                            if (e & ZDEC_REP_REF) { const uint32_t hv = r[e & 3], delta = (e & ~ZDEC_REP_REF) >> 2; if ((e & 3) > 2 || hv <= delta) { rep_ok = false; nr[k] = 1; } else nr[k] = hv - delta; }
+                            if (e & ZDEC_REP_REF) {
+                                const uint32_t slot = e & 3, delta = (e & ~ZDEC_REP_REF) >> 2, hv = slot < 3 ? r[slot] : 0u;
+                                if (hv <= delta) { rep_ok = false; nr[k] = 1; } else nr[k] = hv - delta; // (no cut behind a history the frame pass would reject)
+                            }
                             else nr[k] = e;
                         }
                         r[0] = nr[0]; r[1] = nr[1]; r[2] = nr[2];
