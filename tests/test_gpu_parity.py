@@ -238,3 +238,31 @@ def test_gpu_real_data_ratio_and_validity(engine, oracle, libzstds, libzstd15, r
             assert all(st == 0 and o == real_items[k] for k, (o, d, st) in zip(names, out))
     finally:
         e9.close()
+
+
+def test_gpu_large_frames_by_segment_and_piece(oracle, corpus, libzstds):
+    """Frames above 4 MiB: the match finder works through their 2 MiB segments with different workgroups (the model restarts its carried
+    state at the same places), the frame pass through pieces.  Levels 1 / 3 / 9, sizes around the thresholds, runs and far repeats:
+    GPU frames bit-identical to the model, valid for every libzstd, round trip on the GPU."""
+    from zarc_amd import Engine
+    sizes = [(4 << 20) + 1, (6 << 20) + 12345, (9 << 20) + 7, 4 << 20]
+    for level in (1, 3, 9):
+        eng = Engine(0)
+        eng.set_parameter(_lib.P_COMPRESSION_LEVEL, level)
+        eng.set_parameter(_lib.P_CHECKSUM_FLAG, 1)
+        raws = []
+        for i, size in enumerate(sizes):
+            raw = corpus.entry(8800 + 10 * level + i, size, (level + i) % 3)
+            if i == 1:   # a long run across a segment boundary and a repeat of the first MiB behind 4 MiB of other data
+                raw = raw[:(2 << 20) - 5000] + bytes([7]) * 10000 + raw[(2 << 20) + 5000:(5 << 20)] + raw[:size - (5 << 20)]
+            raws.append(raw)
+        packed = eng.pack(raws)
+        for raw, (frame, dig) in zip(raws, packed):
+            assert dig == oracle.blake3(raw)
+            assert frame == oracle.zge_encode(raw, oracle.params(level=level)), (level, len(raw))
+            for z in libzstds:
+                assert z.decompress(frame, len(raw))[0] == raw
+        res = eng.unpack([p[0] for p in packed], [len(r) for r in raws], [p[1] for p in packed])
+        for raw, (out, dig, st) in zip(raws, res):
+            assert st == _lib.FRAME_OK and out == raw
+        eng.close()
