@@ -557,6 +557,11 @@ int zarc_gpu_pack_batch_device(zarc_gpu_t *h, size_t n, const void *d_src_base, 
         if ((rc = upload_u32(h, h->d_units, units.data(), units.size()))) return rc;
         const size_t match_grid = std::min<size_t>(n_units, (size_t)h->num_cus * (deep ? 1 : 2)); // two 80 KiB workgroups fit a CU, one of 145 KiB
         ZHIP(h->d_far.reserve(match_grid * zge_far_words(P) * 4 + 16)); // one far-table slab per resident workgroup (cleared by the kernel per frame)
+        // The digest kernels (low-priority stream, queued behind the FIRST sub-batch's match launch) must be off the chip before another
+        // match launch: measured on the configs[4] shape, a second launch that found the last 4 ms of them still running took 326 ms
+        // instead of 209 (kernel trace in gpurun_out/trace_dpp.txt) -- the persistent workgroups keep whatever uneven placement the
+        // launch moment gave them.
+        if (digest_queued) ZHIP(hipStreamWaitEvent(h->stream, h->ev_join3, 0));
         auto match_kernel = deep ? zarc_zge_match_deep : zarc_zge_match;
 #ifdef ZARC_GPU_DIAG
         if (!deep && P.dbg) match_kernel = zarc_zge_match_diag;

@@ -145,6 +145,7 @@ __device__ __forceinline__ int ctz32(uint32_t v) { return __ffs((int)v) - 1; }  
 // inclusive prefix sum over the wave
 __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v)
 {
+#ifdef ZARC_HIPEMU
     int l = lane_id();
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -152,6 +153,18 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v)
         if (l >= d) v += t;
     }
     return v;
+#else
+    // Six data-parallel-primitive adds instead of six ds_bpermute round trips: shifts by 1, 2, 4, 8 inside the 16-lane rows (a lane
+    // without a source adds the 0 it is given), then lane 15 of rows 0 / 2 to rows 1 / 3 and lane 31 to rows 2 and 3.  Every caller
+    // runs it with the whole wave active.
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false); // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false); // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false); // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false); // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false); // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false); // row_bcast:31 -> rows 2, 3
+    return v;
+#endif
 }
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 {
