@@ -430,7 +430,7 @@ struct WavePacker {
     __device__ void put(uint64_t lo, uint32_t hi, uint32_t nbits, int lane)
     {
         const uint32_t incl = zd::wave_scan_incl(nbits);
-        const uint32_t total = zd::uniform(zd::shfl(incl, 63));
+        const uint32_t total = zd::readlane(incl, 63);
         const uint32_t at = carry + incl - nbits;
         if (nbits) {
             const uint32_t w = at >> 5, sh = at & 31;
@@ -688,7 +688,7 @@ __global__ void __launch_bounds__(64, 5) zarc_zge_entropy(uint32_t n_blocks, Zge
             uint32_t prev = zd::shfl_up(litpos, 1);
             if (lane == 0) prev = carry;
             const uint32_t ll = litpos - prev;
-            carry = zd::uniform(zd::shfl(litpos, (int)cnt - 1));
+            carry = zd::readlane(litpos, cnt - 1);
             const bool z = ll == 0;
             uint32_t a = zd::shfl_up(o, 1);            // r0 before this sequence
             if (lane == 0) a = r0;
@@ -711,9 +711,9 @@ __global__ void __launch_bounds__(64, 5) zarc_zge_entropy(uint32_t n_blocks, Zge
             if (!z) ofv = o == a ? 1u : (o == bb ? 2u : (o == c ? 3u : o + 3));
             else ofv = o == bb ? 1u : (o == c ? 2u : ((a > 1 && o == a - 1) ? 3u : o + 3));
             if (valid) seq[base + (uint32_t)lane] = zge_pack_seq(ll, ml, ofv);
-            r0 = zd::uniform(zd::shfl(o, (int)cnt - 1));
-            r1 = zd::uniform(zd::shfl(r1_after, (int)cnt - 1));
-            r2 = zd::uniform(zd::shfl(r2_after, (int)cnt - 1));
+            r0 = zd::readlane(o, cnt - 1);
+            r1 = zd::readlane(r1_after, cnt - 1);
+            r2 = zd::readlane(r2_after, cnt - 1);
         }
         zd::wave_sync_global(); // the coding passes below read seq[] with a different lane mapping
     }

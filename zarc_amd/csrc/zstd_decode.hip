@@ -943,7 +943,7 @@ __device__ __forceinline__ void decode_frame(Lds &L, const int lane, const uint3
                     const uint32_t ll = !have ? 0u : (PRE ? p_ll : L.seq[lane * 3]), ml = !have ? 0u : (PRE ? p_ml : L.seq[lane * 3 + 1]);
                     const uint32_t offset = !have ? 1u : (PRE ? p_off : L.seq[lane * 3 + 2]);
                     const uint32_t incl_ll = zd::wave_scan_incl(ll), incl_all = zd::wave_scan_incl(ll + ml);
-                    const uint32_t tot_ll = zd::uniform(zd::shfl(incl_ll, 63)), tot_all = zd::uniform(zd::shfl(incl_all, 63));
+                    const uint32_t tot_ll = zd::readlane(incl_ll, 63), tot_all = zd::readlane(incl_all, 63);
                     if (lp + tot_ll > lit_len) { err = ZARC_FRAME_CORRUPT; break; }
                     if (opos + tot_all > cap) { err = ZARC_FRAME_DSTSIZE; break; }
                     const uint32_t bpos = (uint32_t)opos;                      // output position where this batch starts
@@ -1005,14 +1005,14 @@ __device__ __forceinline__ void decode_frame(Lds &L, const int lane, const uint3
                                 const uint32_t probe = zd::shfl(o_mat, (int)((jb + step - 1) & 63));
                                 if (probe < s_end) jb += step;
                             }
-                            if (zd::shfl(o_mat, 63) < s_end) jb = 64;
+                            if (zd::readlane(o_mat, 63) < s_end) jb = 64;
                             uint32_t jl = 0;                                          // lanes whose match ends at or below my source's start
 #pragma unroll
                             for (uint32_t step = 32; step; step >>= 1) {
                                 const uint32_t probe = zd::shfl(o_end, (int)((jl + step - 1) & 63));
                                 if (probe <= (uint32_t)s_rel) jl += step;
                             }
-                            if (zd::shfl(o_end, 63) <= (uint32_t)s_rel) jl = 64;
+                            if (zd::readlane(o_end, 63) <= (uint32_t)s_rel) jl = 64;
                             // the lanes whose output overlaps my source: [jl, jb) -- fixed for the batch, so a round is a mask test
                             const uint64_t deps = (jb >= 64 ? ~0ull : ((1ull << jb) - 1)) & ~(jl >= 64 ? ~0ull : ((1ull << jl) - 1));
                             while (near) {
