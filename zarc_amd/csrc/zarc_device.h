@@ -166,6 +166,34 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v)
     return v;
 #endif
 }
+// value of the lane below (lane 0 keeps its own): a whole-wave shift by one as a data-parallel primitive, no LDS round trip
+__device__ __forceinline__ uint32_t shfl_up1(uint32_t v)
+{
+#ifdef ZARC_HIPEMU
+    return shfl_up(v, 1u);
+#else
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xF, 0xF, false); // wave_shr:1
+#endif
+}
+// inclusive prefix sum inside every 16-lane row (the first four steps of the scan above)
+__device__ __forceinline__ uint32_t row_scan_incl(uint32_t v)
+{
+#ifdef ZARC_HIPEMU
+    int l = lane_id() & 15;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+        uint32_t t = shfl_up(v, (unsigned)d);
+        if (l >= d) v += t;
+    }
+    return v;
+#else
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);
+    return v;
+#endif
+}
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 {
 #pragma unroll

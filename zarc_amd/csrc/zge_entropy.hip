@@ -650,7 +650,7 @@ __global__ void __launch_bounds__(64, 5) zarc_zge_entropy(uint32_t n_blocks, Zge
             const uint64_t s = valid ? s_next : 0;
             if (base + 64 + (uint32_t)lane < nseq) s_next = seq[base + 64 + (uint32_t)lane]; // (this round stores below base + 64 only)
             const uint32_t lp = zge_seq_ll(s), ml = valid ? zge_seq_ml(s) : 0u, o = zge_seq_ofv(s);
-            uint32_t plp = zd::shfl_up(lp, 1), po = zd::shfl_up(o, 1);
+            uint32_t plp = zd::shfl_up1(lp), po = zd::shfl_up1(o);
             if (lane == 0) { plp = c_lp; po = c_o; }
             const bool cont = valid && (base + (uint32_t)lane) > 0 && lp == plp && o == po;
             const uint64_t hm = zd::ballot(valid && !cont);
@@ -685,12 +685,12 @@ __global__ void __launch_bounds__(64, 5) zarc_zge_entropy(uint32_t n_blocks, Zge
             const uint64_t s = valid ? s_next : 0;
             if (base + 64 + (uint32_t)lane < nseq) s_next = seq[base + 64 + (uint32_t)lane];
             const uint32_t litpos = zge_seq_ll(s), ml = zge_seq_ml(s), o = zge_seq_ofv(s);
-            uint32_t prev = zd::shfl_up(litpos, 1);
+            uint32_t prev = zd::shfl_up1(litpos);
             if (lane == 0) prev = carry;
             const uint32_t ll = litpos - prev;
             carry = zd::readlane(litpos, cnt - 1);
             const bool z = ll == 0;
-            uint32_t a = zd::shfl_up(o, 1);            // r0 before this sequence
+            uint32_t a = zd::shfl_up1(o);            // r0 before this sequence
             if (lane == 0) a = r0;
             const uint64_t upto = lane == 63 ? ~0ull : ((2ull << lane) - 1); // lanes <= mine
             // r1 after each sequence
@@ -698,14 +698,14 @@ __global__ void __launch_bounds__(64, 5) zarc_zge_entropy(uint32_t n_blocks, Zge
             const uint64_t nk1 = zd::ballot(!keep1) & upto;
             const uint32_t src1 = zd::shfl(a, nk1 ? 63 - __clzll((long long)nk1) : 0);
             const uint32_t r1_after = nk1 ? src1 : r1;
-            uint32_t bb = zd::shfl_up(r1_after, 1);   // r1 before this sequence
+            uint32_t bb = zd::shfl_up1(r1_after);   // r1 before this sequence
             if (lane == 0) bb = r1;
             // r2 after each sequence
             const bool keep2 = !valid || (z ? o == bb : (o == a || o == bb));
             const uint64_t nk2 = zd::ballot(!keep2) & upto;
             const uint32_t src2 = zd::shfl(bb, nk2 ? 63 - __clzll((long long)nk2) : 0);
             const uint32_t r2_after = nk2 ? src2 : r2;
-            uint32_t c = zd::shfl_up(r2_after, 1);    // r2 before this sequence
+            uint32_t c = zd::shfl_up1(r2_after);    // r2 before this sequence
             if (lane == 0) c = r2;
             uint32_t ofv;
             if (!z) ofv = o == a ? 1u : (o == bb ? 2u : (o == c ? 3u : o + 3));

@@ -785,12 +785,8 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
             // counts of the chunks before mine: a 16-lane scan of the packed per-chunk counts (every wave repeats it)
             uint32_t sel_total, lit_total, sel_before[PER], lit_before[PER];
             {
-                uint32_t cv = lane < CHUNKS ? L.wcnt[lane] : 0u;
-#pragma unroll
-                for (int d = 1; d < CHUNKS; d <<= 1) {
-                    const uint32_t t = zd::shfl_up(cv, (unsigned)d);
-                    if (lane >= d) cv += t;
-                }
+                static_assert(CHUNKS == 16, "the chunk counts are scanned inside one 16-lane row");
+                const uint32_t cv = zd::row_scan_incl(lane < CHUNKS ? L.wcnt[lane] : 0u);
                 const uint32_t tot = zd::readlane(cv, CHUNKS - 1);
                 sel_total = tot >> 16;
                 lit_total = tot & 0xFFFFu;
