@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the content engine (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU under torch.distributed.run.  Started that way (WORLD_SIZE set) this process IS a rank; started plainly
+(`python bench.py --gpus 8`) it launches `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...
+bench.py <same arguments>` as a CHILD process before torch or HIP are touched, relays the ranks' output (rank 0 prints the JSON
+line) and exits with the child's code -- no exec from a process that has initialised the GPU.
 
 metric  : uncompressed GiB/s of `zarc pack` at zstd level 3 (BLAKE3 + frame encode + XXH64), inputs resident in
           HBM; the same line carries the unpack rate, the compression ratio and the ratio vs libzstd -3.
@@ -168,6 +173,25 @@ def host_path(eng, _lib, torch, d_src, off, lens, n_host, size):
     return out
 
 
+def launch_command(n, argv, port):
+    """The command a plain `python bench.py --gpus N ...` starts as a child: one rank per GPU of this node over RCCL."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def launch_ranks(n, argv):
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # this pool's driver only supports dmabuf IPC (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(launch_command(n, argv, port), env=env)   # stdout / stderr are inherited: rank 0's JSON line goes straight out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -188,9 +212,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # not under a launcher: start the ranks ourselves, as a child (this process has not imported torch nor touched HIP)
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     if args.gpus != world:
-        sys.exit("bench.py: --gpus %d but WORLD_SIZE is %d: for N > 1 launch with `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`"
-                 % (args.gpus, world))
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE is %d (launcher and flag disagree)" % (args.gpus, world))
     import torch
     dist = None
     if world > 1 or "RANK" in os.environ:  # under torchrun always go through RCCL, even with one rank

@@ -110,6 +110,9 @@ typedef struct {
 /* ---- context -------------------------------------------------------------------------------- */
 /* CCtx::try_create + init(0) / DCtx::try_create.  device = HIP device ordinal. */
 int zarc_gpu_create(zarc_gpu_t **out, int device);
+/* Number of usable HIP devices (0 when there is none or the runtime fails): what `--gpus N` is checked against.  Frames are
+ * independent, so a caller that wants G devices opens G handles and deals its batch itself. */
+int zarc_gpu_device_count(void);
 void zarc_gpu_destroy(zarc_gpu_t *h);
 /* Sticky across batches, like Encoder::set_zstd_parameter.  Unknown ids -> ZARC_GPU_E_PARAM; ids libzstd
  * knows but the engine ignores (LDM, NbWorkers, ...) -> ZARC_GPU_E_UNSUPPORTED. */

@@ -96,7 +96,9 @@ static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipPeekAtLastError() { return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
-static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+// HIPEMU_DEVICES=N makes the emulator report N devices (all the same host memory), so that the multi-device host paths
+// (`zarc pack|unpack --gpus N`, Encoder / FrameReader over several handles) open distinct ordinals in the CPU tests
+static inline hipError_t hipGetDeviceCount(int *n) { const char *e = getenv("HIPEMU_DEVICES"); *n = e && atoi(e) > 0 ? atoi(e) : 1; return hipSuccess; }
 static inline hipError_t hipMemGetInfo(size_t *f, size_t *t) { *f = (size_t)2 << 30; *t = (size_t)8 << 30; return hipSuccess; }
 static inline const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "hipemu error"; }
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int)

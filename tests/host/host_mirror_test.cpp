@@ -112,6 +112,39 @@ int main(int argc, char **argv)
         const auto rr = zarc::shard_assign(same.data(), same.size(), 3);
         CHECK(rr[0] == (std::vector<size_t>{0, 3, 6, 9}) && rr[1] == (std::vector<size_t>{1, 4, 7}) && rr[2] == (std::vector<size_t>{2, 5, 8}));
         (void)eq; (void)d3; (void)e3;
+        // ... and the way back: the frames of that archive dealt to two handles by uncompressed bytes decode to the same results, in
+        // the caller's order, a corrupt frame and a wrong expected digest included (unpack.rs:62-88: frames are independent).
+        // With two real devices (or HIPEMU_DEVICES=2) the second handle is device 1, otherwise the same device twice.
+        const int second = zarc_gpu_device_count() >= 2 ? 1 : 0;
+        std::printf("multi-device section: devices {0, %d} (%d visible)\n", second, zarc_gpu_device_count());
+        {
+            std::ostringstream f2;
+            zarc::Encoder e2(f2, {0, second});
+            e2.set_zstd_parameter(ZARC_GPU_P_CHECKSUM_FLAG, 1);
+            auto dg = e2.add_data_frames(p2.data(), l2.data(), p2.size());
+            CHECK(f2.str() == one && dg == d1);
+            std::string img = f2.str();
+            std::vector<zarc::Frame> want;
+            for (size_t i = 0; i < es.size(); i++) want.push_back(e2.frames().at(dg[i]));
+            zarc::Frame wrong = want[3];
+            wrong.digest.bytes[5] ^= 1;                       // reported, bytes delivered
+            want.push_back(wrong);
+            const zarc::Frame &victim = want[7];              // corrupt one byte in the middle of the largest frame
+            img[victim.offset + victim.length / 2] ^= 0x55;
+            zarc::FrameReader r1(std::vector<int>{0}), r2(std::vector<int>{0, second});
+            CHECK(r2.devices() == 2);
+            auto a1 = r1.read_content_frames((const uint8_t *)img.data(), img.size(), want);
+            auto a2 = r2.read_content_frames((const uint8_t *)img.data(), img.size(), want);
+            CHECK(a1.size() == want.size() && a2.size() == want.size());
+            for (size_t i = 0; i < want.size(); i++) {
+                CHECK(a1[i].status == a2[i].status && a1[i].data == a2[i].data && a1[i].digest == a2[i].digest && a1[i].verify == a2[i].verify);
+                if (i == 7) CHECK(a2[i].status != ZARC_GPU_FRAME_OK);
+                else if (i == want.size() - 1) CHECK(a2[i].status == ZARC_GPU_FRAME_DIGEST && a2[i].data == es[3]);
+                else CHECK(a2[i].status == ZARC_GPU_FRAME_OK && a2[i].verify.value_or(false) && a2[i].data == es[i]);
+            }
+            const auto us = zarc::shard_assign(l2.data(), l2.size(), 2);
+            CHECK(!us[0].empty() && !us[1].empty());
+        }
     }
     // --- parameter errors surface as exceptions carrying the libzstd-style name ---
     bool threw = false;

@@ -30,6 +30,8 @@ def make_tree(base, corpus):
         os.utime(p, ns=(1_600_000_000_123_456_000, 1_650_000_000_654_321_000))
     os.symlink("../a.txt", src / "sub" / "link")
     os.chmod(src / "sub", 0o750)
+    for d in (src / "sub" / "deep", src / "sub", src):       # deepest first: touching a directory's entries moves its own mtime
+        os.utime(d, ns=(1_610_000_000_000_000_000, 1_620_000_000_111_222_000))
     try:                                                   # extended attribute (metadata/encode.rs:343-372); not every file system takes user.*
         os.setxattr(src / "b.bin", "user.zarc.test", b"caf\xc3\xa9 \xff\x00bytes")
         os.setxattr(src / "a.txt", "user.note", b"plain text")
@@ -38,7 +40,7 @@ def make_tree(base, corpus):
     return files
 
 
-def run_cli(binary, tmp_path, corpus, oracle, libzstds, store=False):
+def run_cli(binary, tmp_path, corpus, oracle, libzstds, store=False, gpus=0, env=None):
     files = make_tree(tmp_path, corpus)
     arc = tmp_path / ("out-store.zarc" if store else "out.zarc")
     cmd = [binary, "pack", "--output", str(arc), "--level", "3", "--zstd", "ChecksumFlag=true"] + (["--store"] if store else []) + ["src"]
@@ -92,9 +94,9 @@ def run_cli(binary, tmp_path, corpus, oracle, libzstds, store=False):
     assert b" INFO zarc: logging initialised" in out.stderr and len(out.stdout.decode().splitlines()) == len(names)
     logdir = tmp_path / "logs"
     logdir.mkdir(exist_ok=True)
-    env = dict(os.environ); env.pop("RUST_LOG", None)
+    env_log = dict(os.environ); env_log.pop("RUST_LOG", None)
     out = subprocess.run([binary, "--log-file", str(logdir), "pack", "--output", str(tmp_path / "logged.zarc"), "src"], cwd=tmp_path, capture_output=True,
-                         timeout=900, check=True, env=env)
+                         timeout=900, check=True, env=env_log)
     logs = list(logdir.glob("zarc.*.log"))
     assert len(logs) >= 1 and re.fullmatch(r"zarc\.\d{4}-\d\d-\d\dT\d\d-\d\d-\d\dZ\.log", logs[0].name)
     import json
@@ -114,12 +116,33 @@ def run_cli(binary, tmp_path, corpus, oracle, libzstds, store=False):
         st = p.stat()
         assert st.st_mode & 0o7777 == 0o640 and st.st_mtime_ns == 1_650_000_000_654_321_000
     assert (dest / "src" / "sub").stat().st_mode & 0o7777 == 0o750
+    for d in ("src", "src/sub", "src/sub/deep"):            # directory metadata goes on last, deepest first: files created inside do not clobber it
+        assert (dest / d).stat().st_mtime_ns == 1_620_000_000_111_222_000, d
     assert not os.path.lexists(dest / "src" / "sub" / "link")                     # like the reference: links are listed, not recreated
     # --verify
     ok = subprocess.run([binary, "unpack", str(arc), "--verify", digest, "--filter", "b.bin"], cwd=dest, capture_output=True, timeout=600)
     assert ok.returncode == 0 and b"unpacked 1 files" in ok.stderr and b"digest:" not in ok.stderr
     bad = subprocess.run([binary, "unpack", str(arc), "--verify", "A" * 43 + "="], cwd=dest, capture_output=True, timeout=600)
     assert bad.returncode == 1 and b"integrity failure: zarc file digest is " + digest.encode() in bad.stderr
+    # --- several devices: the same archive body and the same tree, frames dealt to N engine handles both ways ---
+    if gpus > 1:
+        arc2 = tmp_path / "out-g.zarc"
+        cmd2 = [binary, "pack", "--output", str(arc2), "--level", "3", "--gpus", str(gpus)] + (["--store"] if store else []) + ["src"]
+        subprocess.run(cmd2, cwd=tmp_path, capture_output=True, timeout=900, check=True, env=env)
+        img2 = arc2.read_bytes()
+        assert img2[:a["dir_at"]] == img[:a["dir_at"]]                          # every content frame, byte for byte, at the same offsets
+        dest2 = tmp_path / "dest-g"
+        dest2.mkdir()
+        out = subprocess.run([binary, "unpack", str(arc2), "--gpus", str(gpus)], cwd=dest2, capture_output=True, timeout=900, check=True, env=env)
+        assert b"unpacked 5 files" in out.stderr
+        for name, data in files.items():
+            assert (dest2 / "src" / name).read_bytes() == data, name
+        many = subprocess.run([binary, "unpack", str(arc2), "--gpus", "63"], cwd=dest2, capture_output=True, timeout=600, env=env)
+        assert many.returncode == 1 and b"--gpus 63" in many.stderr             # more than the box has: a clean error, not a crash
+    # --- errors inside the pipeline end in "Error: ..." and exit code 1, never in an abort (reader / writer threads are joined) ---
+    if os.path.exists("/dev/full"):
+        full = subprocess.run([binary, "pack", "--output", "/dev/full", "src"], cwd=tmp_path, capture_output=True, timeout=900, env=env)
+        assert full.returncode == 1 and b"Error:" in full.stderr, (full.returncode, full.stderr[-500:])
     # a damaged archive is refused
     broken = bytearray(img); broken[-5] ^= 1
     (tmp_path / "broken.zarc").write_bytes(bytes(broken))
@@ -130,7 +153,8 @@ def run_cli(binary, tmp_path, corpus, oracle, libzstds, store=False):
 def test_cli_emulated(emu_lib_path, tmp_path, corpus, oracle, libzstds):
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu"), "host"])
     binary = os.path.join(ROOT, "tests", "emu", "_build", "zarc")
-    run_cli(binary, tmp_path, corpus, oracle, libzstds)
+    env2 = dict(os.environ, HIPEMU_DEVICES="2")             # the emulator then reports two devices: `--gpus 2` opens ordinals 0 and 1
+    run_cli(binary, tmp_path, corpus, oracle, libzstds, gpus=2, env=env2)
     (tmp_path / "s").mkdir()
     run_cli(binary, tmp_path / "s", corpus, oracle, libzstds, store=True)
 
@@ -139,6 +163,9 @@ def test_cli_emulated(emu_lib_path, tmp_path, corpus, oracle, libzstds):
 def test_cli_gpu(tmp_path, corpus, oracle, libzstds):
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "zarc_amd", "csrc"), "host"])
     binary = os.path.join(ROOT, "zarc_amd", "zarc")
-    run_cli(binary, tmp_path, corpus, oracle, libzstds)
+    from zarc_amd import _lib
+    ndev = _lib.load().zarc_gpu_device_count()
+    print("test_cli_gpu: %d device(s) visible%s" % (ndev, "" if ndev >= 2 else " -- `--gpus 2` section SKIPPED (needs two devices)"))
+    run_cli(binary, tmp_path, corpus, oracle, libzstds, gpus=2 if ndev >= 2 else 0)
     (tmp_path / "s").mkdir()
     run_cli(binary, tmp_path / "s", corpus, oracle, libzstds, store=True)

@@ -95,6 +95,64 @@ def test_sharded_pack_over_two_ranks_equals_single_handle(emu_lib_path, oracle):
     assert pos - 12 == len(body)
 
 
+def _unpack_worker(rank, world, port, emu_lib, frames, raw_lens, digests, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from zarc_amd import Engine, shard
+    shares = shard.assign_unpack(raw_lens, world)
+    eng = Engine(0, emu_lib)
+    mine = eng.unpack([frames[i] for i in shares[rank]], [raw_lens[i] for i in shares[rank]], [digests[i] for i in shares[rank]])
+    eng.close()
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)                       # results to the caller's rank; the data path itself has no collective
+    if rank == 0:
+        q.put(shard.gather(shares, gathered))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_unpack_over_two_ranks_equals_single_handle(emu_lib_path, oracle):
+    """The read side of section 8(e): the frames of an archive dealt to two ranks by uncompressed bytes, each rank decodes + verifies its
+    share; merged results (bytes, digests, statuses) equal the single-handle ones -- with a corrupt frame and a wrong expected digest
+    on rank 1's share (crates/zarc-cli/src/unpack.rs:62-88,118-120)."""
+    from zarc_amd import Engine, _lib, shard
+    ents = _entries()[:8]
+    eng = Engine(0, emu_lib_path)
+    eng.set_parameter(_lib.P_CHECKSUM_FLAG, 1)
+    packed = eng.pack(ents)
+    frames, digests, raw_lens = [p[0] for p in packed], [p[1] for p in packed], [len(e) for e in ents]
+    shares = shard.assign_unpack(raw_lens, 2)
+    assert sorted(shares[0] + shares[1]) == list(range(8)) and shares[0] and shares[1]
+    big = [i for i in shares[1] if raw_lens[i] > 50000]
+    corrupt, wrong = big[0], big[1]
+    f = bytearray(frames[corrupt])
+    f[len(f) // 2] ^= 0x40
+    frames[corrupt] = bytes(f)
+    digests[wrong] = bytes(32)
+    single = eng.unpack(frames, raw_lens, digests)
+    eng.close()
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_unpack_worker, args=(r, world, port, emu_lib_path, frames, raw_lens, digests, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    merged = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert [m[2] for m in merged] == [x[2] for x in single]                                   # statuses, in the caller's order
+    assert [m[:2] for i, m in enumerate(merged) if i != corrupt] == [x[:2] for i, x in enumerate(single) if i != corrupt]
+    for i, (out, dig, st) in enumerate(merged):
+        if i == corrupt:
+            assert st not in (_lib.FRAME_OK, _lib.FRAME_DIGEST)
+        elif i == wrong:
+            assert st == _lib.FRAME_DIGEST and out == ents[i] and dig == oracle.blake3(ents[i])
+        else:
+            assert st == _lib.FRAME_OK and out == ents[i] and dig == oracle.blake3(ents[i])
+
+
 def test_sharder_covers_every_entry_once_and_balances():
     from zarc_amd import shard
     import random
@@ -121,3 +179,24 @@ def test_bench_workload_gives_every_rank_the_same_mix():
             assert cidx == list(range(r * 1000, (r + 1) * 1000))       # contiguous corpus range: all four kinds in equal parts
             seen += cidx
         assert sorted(seen) == list(range(1000 * world))
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus N` without a launcher must start N ranks itself, as a child process (the driver's SCALE run may call
+    it either way).  The command is torch.distributed.run on 127.0.0.1; on this GPU-less box the ranks then fail loudly at
+    zarc_gpu_create (there is no CPU fallback) and the parent passes the failure on."""
+    import subprocess
+    import bench
+    cmd = bench.launch_command(4, ["--gpus", "4", "--steps", "2"], 29999)
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "2"]
+    assert cmd[cmd.index("--master-port") + 2] == os.path.join(ROOT, "bench.py")
+    if torch.cuda.device_count() > 0:
+        return                                                    # on a GPU box the real run is test_gpu_parity's business
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--entries", "4", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, timeout=600)
+    err = r.stderr.decode(errors="replace")
+    assert r.returncode != 0
+    assert "WORLD_SIZE" not in err.split("Traceback")[0] or "launcher" not in err       # it did not stop at the old WORLD_SIZE check
+    assert "no usable HIP device" in err or "nccl" in err.lower() or "cuda" in err.lower(), err[-2000:]

@@ -266,3 +266,54 @@ def test_gpu_large_frames_by_segment_and_piece(oracle, corpus, libzstds):
         for raw, (out, dig, st) in zip(raws, res):
             assert st == _lib.FRAME_OK and out == raw
         eng.close()
+
+
+def test_gpu_two_devices_pack_and_unpack(engine, oracle, corpus):
+    """SURVEY 8(e) on real hardware: entries dealt to device 0 and device 1 by the product's sharder, merged archive and merged unpack
+    results identical to one device's.  Needs two visible devices: a one-GPU box SKIPS (loudly) -- the C++ twin of this test
+    (tests/host/host_mirror_test.cpp, multi-device section) then runs its two handles on device 0."""
+    from zarc_amd import Engine, shard
+    ndev = engine.lib.zarc_gpu_device_count()
+    if ndev < 2:
+        pytest.skip("two-device test NOT RUN: this box has %d visible device(s)" % ndev)
+    ents = [corpus.entry(7000 + i, n, -1) for i, n in enumerate((1 << 20, 70000, 3 << 20, 65536, 0, 900001, 20000, 2 << 20, 5))]
+    ents += [ents[2], ents[1]]
+    single = engine.pack(ents)
+    shares = shard.assign([len(e) for e in ents], 2)
+    engs = [Engine(0), Engine(1)]
+    for e in engs:
+        e.set_parameter(_lib.P_CHECKSUM_FLAG, 1)
+    packed = [engs[d].pack([ents[i] for i in shares[d]]) for d in range(2)]
+    assert shard.merge(shares, packed) == shard.merge([list(range(len(ents)))], [single])
+    frames, digs, lens = [p[0] for p in single], [p[1] for p in single], [len(e) for e in ents]
+    us = shard.assign_unpack(lens, 2)
+    got = shard.gather(us, [engs[d].unpack([frames[i] for i in us[d]], [lens[i] for i in us[d]], [digs[i] for i in us[d]]) for d in range(2)])
+    assert got == engine.unpack(frames, lens, digs) and all(st == 0 and out == e for e, (out, dig, st) in zip(ents, got))
+    for e in engs:
+        e.close()
+
+
+def test_gpu_bench_runs_under_the_launcher_and_starts_its_own_ranks(tmp_path):
+    """bench.py as the driver starts it: (1) under torch.distributed.run with one rank (RCCL process group, barrier, max-over-ranks --
+    the code path of every N > 1 run), (2) `python bench.py --gpus 2` with no launcher, which must start its two ranks itself
+    (needs two devices; skipped loudly on a one-GPU box, where the CPU test covers the launching itself)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    small = ["--entries", "64", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-host-path"]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29631", os.path.join(root, "bench.py"), "--gpus", "1"] + small, env=env, capture_output=True, timeout=900)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
+    line = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["roundtrip_bit_exact"] and line["value"] > 0
+    from zarc_amd import _lib as L
+    ndev = L.load().zarc_gpu_device_count()
+    if ndev < 2:
+        pytest.skip("`bench.py --gpus 2` self-launch NOT RUN on hardware: %d visible device(s); the 1-rank launcher run above passed" % ndev)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"] + small, env=env, capture_output=True, timeout=900)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
+    line = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["roundtrip_bit_exact"] and line["config"]["entries_total"] == 128

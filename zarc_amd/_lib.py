@@ -27,7 +27,7 @@ PX_SCRATCH_MB, PX_STAGE_CHUNK, PX_STAGE_THREAD, PX_COPY_THREADS, PX_DEC_GROUPS =
 T_BLAKE3, T_XXH64, T_MATCH, T_ENTROPY, T_ASSEMBLE, T_DECODE, T_TOTAL, T_DEC_SEQS, T_DEC_LITS, T_DEC_FRAMES = range(10)
 
 EXPORTS = [
-    "zarc_gpu_abi_version", "zarc_gpu_create", "zarc_gpu_destroy", "zarc_gpu_set_parameter", "zarc_gpu_get_params",
+    "zarc_gpu_abi_version", "zarc_gpu_device_count", "zarc_gpu_create", "zarc_gpu_destroy", "zarc_gpu_set_parameter", "zarc_gpu_get_params",
     "zarc_gpu_enable_compression", "zarc_gpu_bound", "zarc_gpu_error_name", "zarc_gpu_frame_status_name", "zarc_gpu_last_error",
     "zarc_gpu_pack_batch", "zarc_gpu_pack_batch_device", "zarc_gpu_unpack_batch", "zarc_gpu_unpack_batch_device",
     "zarc_gpu_blake3_batch", "zarc_gpu_blake3_batch_device", "zarc_gpu_xxh64_batch_device", "zarc_gpu_last_kernel_ms",
@@ -57,6 +57,7 @@ def load(path=None):
     vp, sz, u64p, u8p, ip = c.c_void_p, c.c_size_t, c.POINTER(c.c_uint64), c.POINTER(c.c_uint8), c.POINTER(c.c_int)
     szp, vpp = c.POINTER(c.c_size_t), c.POINTER(c.c_void_p)
     lib.zarc_gpu_abi_version.restype = c.c_int
+    lib.zarc_gpu_device_count.restype = c.c_int
     lib.zarc_gpu_create.argtypes = [c.POINTER(vp), c.c_int]
     lib.zarc_gpu_destroy.argtypes = [vp]
     lib.zarc_gpu_destroy.restype = None

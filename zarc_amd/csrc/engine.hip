@@ -241,6 +241,12 @@ extern "C" {
 
 int zarc_gpu_abi_version(void) { return ZARC_GPU_ABI_VERSION; }
 
+int zarc_gpu_device_count(void)
+{
+    int count = 0;
+    return hipGetDeviceCount(&count) == hipSuccess && count > 0 ? count : 0;
+}
+
 int zarc_gpu_create(zarc_gpu_t **out, int device)
 {
     if (!out) return ZARC_GPU_E_PARAM;

@@ -181,7 +181,7 @@ int usage()
 {
     std::fprintf(stderr, "usage: zarc [-v...] [--log-file [PATH]] <pack|unpack|list-files> ...\n"
                          "       zarc pack --output PATH [--level N] [--zstd PARAM=VALUE]... [--store] [-L] [--gpus N] PATH...\n"
-                         "       zarc unpack INPUT [--filter REGEX]... [--verify DIGEST]\n"
+                         "       zarc unpack INPUT [--filter REGEX]... [--verify DIGEST] [--gpus N]\n"
                          "       zarc list-files INPUT [--only-files] [--decorate] [--filter REGEX]...\n");
     return 2;
 }
@@ -329,6 +329,7 @@ int cmd_pack(const std::vector<std::string> &a)
         else paths.push_back(a[i]);
     }
     if (output.empty() || gpus < 1 || gpus > 64) return usage();
+    if (gpus > zarc_gpu_device_count()) { std::fprintf(stderr, "Error: --gpus %d but %d device(s) are usable\n", gpus, zarc_gpu_device_count()); return 1; }
     std::ofstream file(output, std::ios::binary | std::ios::trunc);
     if (!file) { std::fprintf(stderr, "Error: %s: %s\n", output.c_str(), std::strerror(errno)); return 1; }
     std::vector<int> devices;
@@ -349,10 +350,11 @@ int cmd_pack(const std::vector<std::string> &a)
     std::deque<Batch> ready;
     std::mutex mu;
     std::condition_variable cv;
-    bool reader_done = false;
+    bool reader_done = false, abandon = false;
     std::thread reader([&] {
         size_t first = 0;
         while (first < entries.size()) {
+            { std::lock_guard<std::mutex> lk(mu); if (abandon) break; }
             Batch b;
             b.first = first;
             size_t last = first, bytes = 0;
@@ -371,7 +373,8 @@ int cmd_pack(const std::vector<std::string> &a)
             const bool failed = !b.error.empty();
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return ready.size() < 2; }); // at most two batches of file contents in memory
+                cv.wait(lk, [&] { return ready.size() < 2 || abandon; }); // at most two batches of file contents in memory
+                if (abandon) break;
                 ready.push_back(std::move(b));
             }
             cv.notify_all();
@@ -381,6 +384,13 @@ int cmd_pack(const std::vector<std::string> &a)
         { std::lock_guard<std::mutex> lk(mu); reader_done = true; }
         cv.notify_all();
     });
+    // Whatever ends the loop below -- a read error, or an exception out of the engine / the archive writer (zarc::Error: engine
+    // failure, an entry of 4 GiB or more, a failed write) -- the reader thread is told to stop and joined before this frame unwinds:
+    // a joinable std::thread must never be destroyed (std::terminate), the error goes to main()'s handler ("Error: ...", exit 1).
+    struct Joiner {
+        std::thread &t; std::mutex &mu; std::condition_variable &cv; bool &stop;
+        ~Joiner() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); if (t.joinable()) t.join(); }
+    } joiner{reader, mu, cv, abandon};
     std::string failure;
     for (;;) {
         Batch b;
@@ -405,11 +415,6 @@ int cmd_pack(const std::vector<std::string> &a)
             enc.add_file_entry(f);
         }
     }
-    if (!failure.empty()) { // let the reader finish before leaving
-        { std::unique_lock<std::mutex> lk(mu); ready.clear(); }
-        cv.notify_all();
-    }
-    reader.join();
     if (!failure.empty()) { std::fprintf(stderr, "Error: %s\n", failure.c_str()); return 1; }
     timespec now;
     clock_gettime(CLOCK_REALTIME, &now);
@@ -465,15 +470,20 @@ int cmd_unpack(const std::vector<std::string> &a)
 {
     std::string input, verify;
     std::vector<std::regex> filters;
+    int gpus = 1;
     for (size_t i = 0; i < a.size(); i++) {
         if (a[i] == "--filter" && i + 1 < a.size()) filters.emplace_back(a[++i]);
         else if (a[i] == "--verify" && i + 1 < a.size()) verify = a[++i];
+        else if (a[i] == "--gpus" && i + 1 < a.size()) gpus = std::atoi(a[++i].c_str());
         else if (!a[i].empty() && a[i][0] == '-') return usage();
         else input = a[i];
     }
-    if (input.empty()) return usage();
+    if (input.empty() || gpus < 1 || gpus > 64) return usage();
+    if (gpus > zarc_gpu_device_count()) { std::fprintf(stderr, "Error: --gpus %d but %d device(s) are usable\n", gpus, zarc_gpu_device_count()); return 1; }
     Mapped m(input);
-    zarc::ArchiveReader rd(m.p, m.n);
+    std::vector<int> devices;
+    for (int d = 0; d < gpus; d++) devices.push_back(d);
+    zarc::ArchiveReader rd(m.p, m.n, devices); // frames of a batch are dealt to the devices by uncompressed bytes (zarc_host.hpp)
     const std::string digest = base64(rd.trailer().digest.bytes.data(), 32);
     if (!verify.empty()) {
         if (verify != digest) { std::fprintf(stderr, "Error: integrity failure: zarc file digest is %s\n", digest.c_str()); return 1; }
@@ -541,19 +551,25 @@ int cmd_unpack(const std::vector<std::string> &a)
         batch.clear();
         batch_bytes = 0;
     };
-    auto drain = [&]() { // directories are made by this thread: every file queued before must be on disk first
-        std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return todo.empty(); });
-    };
+    // As in cmd_pack: the writer thread is stopped and joined on every way out of this function, exceptions included (a corrupt
+    // frame record makes read_files throw in the middle of the loop).
+    struct Joiner {
+        std::thread &t; std::mutex &mu; std::condition_variable &cv; bool &stop;
+        ~Joiner() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); if (t.joinable()) t.join(); }
+    } joiner{writer, mu, cv, no_more};
+    // Directories are MADE when their entry comes up (the files below them follow in the archive), but their metadata is applied
+    // last, deepest first, once the writer thread has put every file on disk: creating a file inside a directory moves the
+    // directory's mtime, and a read-only mode would refuse the files.  (The reference applies it at once, unpack.rs:62-88, and so
+    // restores directory mtimes only for empty directories.)
+    std::vector<size_t> dirs;
     for (size_t i = 0; i < rd.files().size(); i++) {
         const zarc::File &f = rd.files()[i];
         const std::string name = to_path(f.name);
         if (!passes(filters, name)) continue;
         if (!safe_name(f.name)) { std::fprintf(stderr, "WARN unsafe pathname skipped: %s\n", name.c_str()); continue; }
         if (f.is_dir()) {
-            mkdirs(name, f.mode ? (mode_t)(*f.mode & 07777) : 0777);
-            const int fd = open(name.c_str(), O_RDONLY | O_DIRECTORY);
-            if (fd >= 0) { set_metadata(f, fd); close(fd); }
+            mkdirs(name, 0777);
+            dirs.push_back(i);
         } else if (f.is_normal()) {
             auto it = rd.frames().find(*f.digest);
             if (it == rd.frames().end()) { std::fprintf(stderr, "WARN frame not found\n"); continue; } // unpack.rs:107-110
@@ -562,12 +578,17 @@ int cmd_unpack(const std::vector<std::string> &a)
             if (batch_bytes >= BATCH) flush();
         }
     }
-    try { flush(); } catch (...) { { std::lock_guard<std::mutex> lk(mu); no_more = true; } cv.notify_all(); writer.join(); throw; }
-    (void)drain;
+    flush();
     { std::lock_guard<std::mutex> lk(mu); no_more = true; }
     cv.notify_all();
     writer.join();
     if (!failure.empty()) throw zarc::Error(ZARC_GPU_E_PARAM, failure);
+    std::stable_sort(dirs.begin(), dirs.end(), [&](size_t x, size_t y) { return rd.files()[x].name.size() > rd.files()[y].name.size(); }); // more components first
+    for (size_t i : dirs) {
+        const zarc::File &f = rd.files()[i];
+        const int fd = open(to_path(f.name).c_str(), O_RDONLY | O_DIRECTORY);
+        if (fd >= 0) { set_metadata(f, fd); close(fd); }
+    }
     std::fprintf(stderr, "unpacked %llu files\n", unpacked);
     return 0;
 }

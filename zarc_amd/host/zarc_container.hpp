@@ -347,7 +347,9 @@ class ArchiveWriter : public Encoder {
 class ArchiveReader {
   public:
     // Decoder::open + read_directory over an archive image in memory
-    ArchiveReader(const uint8_t *data, size_t len, int device = 0) : data_(data), len_(len), reader_(device)
+    ArchiveReader(const uint8_t *data, size_t len, int device = 0) : ArchiveReader(data, len, std::vector<int>{device}) {}
+    // ... on several devices (`zarc unpack --gpus N`): read_files deals the frames of a batch to one engine handle per device
+    ArchiveReader(const uint8_t *data, size_t len, const std::vector<int> &devices) : data_(data), len_(len), reader_(devices)
     {
         if (len < 12 + SKIPPABLE_FRAME_OVERHEAD + TRAILER_LENGTH) throw Error(ZARC_GPU_E_PARAM, "not a zarc archive: too short");
         if (std::memcmp(data, FILE_MAGIC, 11) != 0) throw Error(ZARC_GPU_E_PARAM, "not a zarc archive: bad header");   // open.rs:48-67

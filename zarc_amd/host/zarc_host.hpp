@@ -214,6 +214,11 @@ class Encoder {
 };
 
 // Decoder::read_content_frame + FrameIterator for a batch of frames of one archive image held in memory.
+// The reference's read side is a serial loop over frames that each get a fresh reader and DCtx (zarc-cli/src/unpack.rs:62-88,
+// decode/zstd_iterator.rs:28-29): frames are as independent on the way out as on the way in.  A FrameReader constructed with G
+// devices deals the wanted frames with the same `shard_assign` as the Encoder -- by UNCOMPRESSED bytes, what the decoder's work
+// is proportional to -- decodes the shares concurrently (one host thread per handle, no collective) and returns the results in the
+// caller's order; statuses, digests and bytes are identical to the single-device ones.
 class FrameReader {
   public:
     struct Result {
@@ -222,18 +227,20 @@ class FrameReader {
         std::optional<bool> verify;      // FrameIterator::verify(): None if the frame did not decode
         int status = ZARC_GPU_FRAME_OK;  // Error::Zstd analogue (decode/error.rs:35-38) via zarc_gpu_frame_status_name
     };
-    explicit FrameReader(int device = 0) : engine_(device) {}
+    explicit FrameReader(int device = 0) : FrameReader(std::vector<int>{device}) {}
+    explicit FrameReader(const std::vector<int> &devices)
+    {
+        if (devices.empty()) throw Error(ZARC_GPU_E_PARAM, "no device");
+        for (int d : devices) engines_.emplace_back(new Engine(d));
+    }
+    size_t devices() const { return engines_.size(); }
 
     // `archive` is the whole file; `wanted` are directory records (offset/length/uncompressed/digest).
     std::vector<Result> read_content_frames(const uint8_t *archive, size_t archive_len, const std::vector<Frame> &wanted)
     {
         const size_t n = wanted.size();
         std::vector<Result> out(n);
-        std::vector<const void *> fp(n);
-        std::vector<void *> dp(n);
-        std::vector<size_t> fl(n), rl(n);
-        std::vector<Digest> expect(n), got(n);
-        std::vector<int> status(n);
+        std::vector<size_t> rl(n);
         for (size_t i = 0; i < n; i++) {
             // untrusted directory records: no u64 wrap-around, no frame beyond the file, no allocation the engine would refuse anyway
             if (wanted[i].length > archive_len || wanted[i].offset > archive_len - wanted[i].length) throw Error(ZARC_GPU_E_PARAM, "frame outside the archive");
@@ -241,27 +248,49 @@ class FrameReader {
             // Zstandard cannot expand a frame by more than a factor of ~(128 KiB block from a 4-byte RLE block): a larger claim is corrupt
             if (wanted[i].uncompressed > (wanted[i].length + 16) * (uint64_t)65536) throw Error(ZARC_GPU_E_PARAM, "frame claims an impossible uncompressed size");
             out[i].data.resize(wanted[i].uncompressed);
-            fp[i] = archive + wanted[i].offset;
-            fl[i] = wanted[i].length;
             rl[i] = wanted[i].uncompressed;
-            dp[i] = out[i].data.data();
-            expect[i] = wanted[i].digest;
         }
         if (n == 0) return out;
-        engine_.check(zarc_gpu_unpack_batch(engine_.get(), n, fp.data(), fl.data(), rl.data(), dp.data(), (const uint8_t(*)[32])expect.data(),
-                                            (uint8_t(*)[32])got.data(), status.data()));
-        for (size_t i = 0; i < n; i++) {
-            out[i].status = status[i];
-            out[i].digest = got[i];
-            const bool decoded = status[i] == ZARC_GPU_FRAME_OK || status[i] == ZARC_GPU_FRAME_DIGEST;
-            if (decoded) out[i].verify = got[i] == expect[i]; // a mismatch is reported, not fatal (zarc-cli/src/unpack.rs:118-120)
-            else out[i].data.clear();
+        const size_t g = engines_.size();
+        const auto share = shard_assign(rl.data(), n, g);
+        std::vector<int> rc(g, ZARC_GPU_OK);
+        auto unpack_share = [&](size_t d) {
+            const std::vector<size_t> &idx = share[d];
+            const size_t m = idx.size();
+            if (m == 0) return;
+            std::vector<const void *> fp(m);
+            std::vector<void *> dp(m);
+            std::vector<size_t> fl(m), ul(m);
+            std::vector<Digest> expect(m), got(m);
+            std::vector<int> status(m);
+            for (size_t j = 0; j < m; j++) {
+                const Frame &f = wanted[idx[j]];
+                fp[j] = archive + f.offset; fl[j] = f.length; ul[j] = f.uncompressed; dp[j] = out[idx[j]].data.data(); expect[j] = f.digest;
+            }
+            rc[d] = zarc_gpu_unpack_batch(engines_[d]->get(), m, fp.data(), fl.data(), ul.data(), dp.data(), (const uint8_t(*)[32])expect.data(),
+                                          (uint8_t(*)[32])got.data(), status.data());
+            if (rc[d] != ZARC_GPU_OK) return;
+            for (size_t j = 0; j < m; j++) {
+                Result &r = out[idx[j]];
+                r.status = status[j];
+                r.digest = got[j];
+                const bool decoded = status[j] == ZARC_GPU_FRAME_OK || status[j] == ZARC_GPU_FRAME_DIGEST;
+                if (decoded) r.verify = got[j] == expect[j]; // a mismatch is reported, not fatal (zarc-cli/src/unpack.rs:118-120)
+                else r.data.clear();
+            }
+        };
+        if (g == 1) unpack_share(0);
+        else {
+            std::vector<std::thread> th;
+            for (size_t d = 0; d < g; d++) th.emplace_back(unpack_share, d);
+            for (auto &t : th) t.join();
         }
+        for (size_t d = 0; d < g; d++) engines_[d]->check(rc[d]);
         return out;
     }
 
   private:
-    Engine engine_;
+    std::vector<std::unique_ptr<Engine>> engines_; // one per device
 };
 
 } // namespace zarc
