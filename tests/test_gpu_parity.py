@@ -293,10 +293,7 @@ def test_gpu_two_devices_pack_and_unpack(engine, oracle, corpus):
         e.close()
 
 
-def test_gpu_bench_runs_under_the_launcher_and_starts_its_own_ranks(tmp_path):
-    """bench.py as the driver starts it: (1) under torch.distributed.run with one rank (RCCL process group, barrier, max-over-ranks --
-    the code path of every N > 1 run), (2) `python bench.py --gpus 2` with no launcher, which must start its two ranks itself
-    (needs two devices; skipped loudly on a one-GPU box, where the CPU test covers the launching itself)."""
+def _bench(args, launcher):
     import json
     import os
     import subprocess
@@ -304,16 +301,24 @@ def test_gpu_bench_runs_under_the_launcher_and_starts_its_own_ranks(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     small = ["--entries", "64", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-host-path"]
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-                        "--master-port", "29631", os.path.join(root, "bench.py"), "--gpus", "1"] + small, env=env, capture_output=True, timeout=900)
+    pre = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29631"] if launcher else [sys.executable]
+    r = subprocess.run(pre + [os.path.join(root, "bench.py")] + args + small, env=env, capture_output=True, timeout=900)
     assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
-    line = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
+    return json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
+
+
+def test_gpu_bench_under_the_launcher():
+    """bench.py as the driver starts it for N > 1: under torch.distributed.run (here with one rank: RCCL process group, barrier,
+    max-over-ranks -- the code path of every multi-GPU run)."""
+    line = _bench(["--gpus", "1"], launcher=True)
     assert line["n_gpus"] == 1 and line["roundtrip_bit_exact"] and line["value"] > 0
-    from zarc_amd import _lib as L
-    ndev = L.load().zarc_gpu_device_count()
+
+
+def test_gpu_bench_starts_its_own_ranks(engine):
+    """`python bench.py --gpus 2` with no launcher must start its two ranks itself.  Needs two devices; a one-GPU box SKIPS loudly
+    (tests/test_dist.py covers the launching itself on CPU)."""
+    ndev = engine.lib.zarc_gpu_device_count()
     if ndev < 2:
-        pytest.skip("`bench.py --gpus 2` self-launch NOT RUN on hardware: %d visible device(s); the 1-rank launcher run above passed" % ndev)
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"] + small, env=env, capture_output=True, timeout=900)
-    assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
-    line = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
+        pytest.skip("`bench.py --gpus 2` self-launch NOT RUN on hardware: %d visible device(s)" % ndev)
+    line = _bench(["--gpus", "2"], launcher=False)
     assert line["n_gpus"] == 2 and line["roundtrip_bit_exact"] and line["config"]["entries_total"] == 128
