@@ -37,7 +37,15 @@ typedef struct {
     int far_short;    /* 1 = a second far table keyed by the short hash */
     int far_skip;     /* a far candidate is not compared once a candidate of this many bytes is in hand (0 = always compared)        */
     int far_back;     /* backward-extension cap of far candidates (they are found up to 2^far_step_log + 2^far_res_log - 2
-                         positions into a repeat) */
+                         positions into a repeat; with content-defined sampling 2^far_cdc_log positions on average) */
+    /* Round 3, the level-3 finder: */
+    int near16;       /* 1 = ONE near table of 2^short_log 16-bit entries keyed by the short hash (no long table, no check bits): an
+                         entry is the low 16 bits of the position, so a candidate lies 1 .. 65536 bytes back (a stale entry is just a
+                         candidate that fails its compare); the far table covers everything beyond                                     */
+    int far_cdc_log;  /* > 0: content-defined sampling of the far table: a position is inserted AND looked up iff the far_cdc_log
+                         bits of its 12-byte hash just below the bucket and check bits are zero (far_step_log / far_res_log unused) and its three
+                         4-byte words are not all equal (no runs / periods 1, 2, 4: those are the near table's business): both
+                         occurrences of a repeat sample the same relative positions, so a repeat is found if it contains one sample */
 } zge_params;
 
 typedef struct { uint32_t ll, ml, off, ofv; } zge_seq;

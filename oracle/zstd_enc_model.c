@@ -617,6 +617,7 @@ typedef struct {
     const uint8_t *src;
     size_t n;
     uint32_t *tl, *ts;       /* long / short tables: value = position+1, 0 = empty */
+    uint16_t *t16;           /* near16: the one near table, value = low 16 bits of the position */
     size_t window;
     cand *M, *M2;            /* per-tile candidates: own best, then after backward propagation */
     uint32_t *next;          /* per-tile successor of each position on the parse path */
@@ -674,13 +675,29 @@ static void resolve_repcodes(zge_seq *seq, uint32_t nseq, zge_stats *st)
     }
 }
 
+/* Is position p (12 readable bytes) a far-table position?  Positional scheme: p mod 2^far_step_log < 2^far_res_log is inserted,
+ * p mod 2^far_res_log == 0 is looked up.  Content-defined scheme (far_cdc_log > 0): inserted and looked up iff the far_cdc_log bits
+ * of the hash below the bucket and check bits are zero. */
+static int far_sampled(const zge_params *P, const uint8_t *src, size_t p, int insert)
+{
+    if (P->far_cdc_log > 0) {
+        /* windows of period 1, 2 or 4 (three equal 4-byte words: runs, zero padding) are no far positions: every position of such a
+         * stretch has the same hash -- hundreds of same-bucket inserts per tile -- and the near table and the recent offsets find them */
+        const uint64_t v = rd64(src + p);
+        if ((uint32_t)v == (uint32_t)(v >> 32) && (uint32_t)v == rd32(src + p + 8)) return 0;
+        return (hash_far(v, rd32(src + p + 8), P->far_log + P->tag_bits + P->far_cdc_log) & ((1u << P->far_cdc_log) - 1)) == 0;
+    }
+    if (insert) return ((uint32_t)p & ((1u << P->far_step_log) - 1)) < (1u << P->far_res_log);
+    return ((uint32_t)p & ((1u << P->far_res_log) - 1)) == 0;
+}
+
 /* Far inserts of the searched tile starting at `tile`: every 2^far_step_log-th position, into the way of this tile; the highest
  * position wins (atomic max in the kernel). */
 static void far_insert_tile(mf_ctx *c, size_t tile)
 {
     const zge_params *P = c->P;
     const uint8_t *src = c->src;
-    const uint32_t tmask = (1u << P->tag_bits) - 1, smask = (1u << P->far_step_log) - 1;
+    const uint32_t tmask = (1u << P->tag_bits) - 1;
     const size_t segbase = tile & ~(((size_t)1 << P->seg_log) - 1);
     const size_t way = (tile / (size_t)P->tile) % (size_t)P->far_ways;
     const size_t far_end = c->n >= 12 ? c->n - 11 : 0;
@@ -691,7 +708,7 @@ static void far_insert_tile(mf_ctx *c, size_t tile)
     for (p = tile; p < tend && p < far_end; p++) {
         uint64_t v;
         uint32_t hf, code = (uint32_t)(p - segbase) + 1, *e;
-        if (((uint32_t)p & smask) >= (1u << P->far_res_log)) continue;
+        if (!far_sampled(P, src, p, 1)) continue;
         v = rd64(src + p);
         hf = hash_far(v, rd32(src + p + 8), P->far_log + P->tag_bits);
         e = &c->fl[(size_t)(hf >> P->tag_bits) * (size_t)P->far_ways + way];
@@ -734,6 +751,22 @@ static uint32_t matchfind_block(mf_ctx *c, size_t bs, size_t be, zge_seq *seq, u
             size_t send = sub + (size_t)P->sub < tend ? sub + (size_t)P->sub : tend;
             const uint32_t tmask = (1u << P->tag_bits) - 1;
             const size_t segbase = tile & ~(((size_t)1 << P->seg_log) - 1);
+            if (P->near16) {
+                /* one table of 16-bit entries: the candidate lies d = 1 .. 65536 bytes back, d = (p - entry) mod 2^16 (0 -> 65536);
+                 * whatever the entry holds (a stale position, the zeros of a fresh table) is a candidate like any other: S3 compares */
+                for (p = sub; p < send; p++) {
+                    cand *m = &c->M[p - tile];
+                    m->len = 0; m->off = 0; m->back = 0; m->is_rep = 0;
+                    if (p < hash_end) {
+                        uint32_t hs = hash_short(rd64(src + p), P->short_log, P->short_bytes);
+                        uint32_t d = (((uint32_t)p - c->t16[hs] - 1u) & 0xFFFFu) + 1u;
+                        m->len = d <= p ? (uint32_t)p - d + 1 : 0; /* candidate position + 1 */
+                    }
+                }
+                for (p = sub; p < send && p < hash_end; p++)
+                    c->t16[hash_short(rd64(src + p), P->short_log, P->short_bytes)] = (uint16_t)p; /* ascending: the highest position stays */
+                continue;
+            }
             for (p = sub; p < send; p++) {
                 cand *m = &c->M[p - tile];
                 m->len = 0; m->off = 0; m->back = 0; m->is_rep = 0;
@@ -766,7 +799,7 @@ static uint32_t matchfind_block(mf_ctx *c, size_t bs, size_t be, zge_seq *seq, u
             for (p = tile; p < tend && p < far_end; p++) {
                 uint64_t v = rd64(src + p);
                 uint32_t hf = hash_far(v, rd32(src + p + 8), P->far_log + P->tag_bits), *fc = c->farc + (p - tile) * ZGE_FAR_MAX;
-                if ((uint32_t)p & ((1u << P->far_res_log) - 1)) continue;
+                if (!far_sampled(P, src, p, 0)) continue;
                 for (w = 0; w < P->far_ways; w++) {
                     uint32_t e = c->fl[(size_t)(hf >> P->tag_bits) * (size_t)P->far_ways + (size_t)w];
                     if (e && (e & tmask) == (hf & tmask)) fc[w] = (uint32_t)segbase + (e >> P->tag_bits);
@@ -780,11 +813,15 @@ static uint32_t matchfind_block(mf_ctx *c, size_t bs, size_t be, zge_seq *seq, u
                 }
             }
         }
-        /* S3: every position scores its own candidates {near (long, else short), far ..., guess0, guess1}; ties keep the earlier candidate */
+        /* S3: every position scores its own candidates {near (long, else short), far ..., guess0, guess1}; ties keep the earlier candidate.
+         * near16, runs: inside a repeat every position's hash leads to the same distance; a position whose validated near distance
+         * equals its left neighbour's (same 64-position chunk) is a FOLLOWER: its near length is its neighbour's minus one, nothing is
+         * compared (the kernel requests no source for it), and a follower's near match gets no backward extension. */
+        uint32_t prev_on = 0, prev_near = 0;
         for (p = tile; p < tend; p++) {
             cand *m = &c->M[p - tile];
             uint32_t limit = (uint32_t)(be - p), cap = limit < (uint32_t)P->cap ? limit : (uint32_t)P->cap;
-            uint32_t best_len = 0, best_off = 0; int best_rep = 0, best_far = 0; int32_t best_score = -1000000;
+            uint32_t best_len = 0, best_off = 0; int best_rep = 0, best_far = 0, best_fol = 0, fol = 0; int32_t best_score = -1000000;
             uint32_t k, offs[4 + ZGE_FAR_MAX];
             const uint32_t nfar = P->far_log ? (uint32_t)(P->far_ways * (1 + (P->far_short ? 1 : 0))) : 0, ntab = 1 + nfar;
             /* one near candidate: the long table's when it has a hit, the short table's only otherwise (measured: with a long-hash hit
@@ -801,6 +838,12 @@ static uint32_t matchfind_block(mf_ctx *c, size_t bs, size_t be, zge_seq *seq, u
             /* table candidates need 8 bytes in front of their source: the kernel fetches source[-8 .. 8) in one load (the
              * first half feeds the backward extension); sources in the first 8 bytes of a frame are skipped */
             for (k = 0; k < ntab; k++) if (offs[k] + 8 > p) offs[k] = 0;
+            if (offs[0] > p || offs[0] > c->window) offs[0] = 0; /* the validated near distance */
+            if (P->near16) {
+                fol = ((p - tile) & 63) != 0 && offs[0] != 0 && offs[0] == prev_on;
+                prev_near = fol ? (prev_near > 0 ? prev_near - 1 : 0) : (offs[0] ? match_len(src, p, p - offs[0], cap) : 0);
+                prev_on = offs[0];
+            }
             m->len = 0; m->off = 0;
             for (k = 0; k < ntab + 2; k++) {
                 uint32_t off = offs[k], len; int is_rep; int32_t sc;
@@ -808,16 +851,16 @@ static uint32_t matchfind_block(mf_ctx *c, size_t bs, size_t be, zge_seq *seq, u
                 is_rep = off == erep0 || off == erep1;
                 /* with 64 bytes in hand already, a far candidate is not looked at: comparing it would be the longest compare of the tile */
                 if (k >= 1 && k < ntab && P->far_skip && best_len >= (uint32_t)P->far_skip) continue;
-                len = match_len(src, p, p - off, cap);
+                len = (P->near16 && k == 0) ? prev_near : match_len(src, p, p - off, cap);
                 if (len < (uint32_t)(is_rep ? P->min_rep : P->min_match)) continue;
                 sc = score_of(P, len, off, is_rep);
-                if (sc > best_score) { best_score = sc; best_len = len; best_off = off; best_rep = is_rep; best_far = k >= 1 && k < ntab; }
+                if (sc > best_score) { best_score = sc; best_len = len; best_off = off; best_rep = is_rep; best_far = k >= 1 && k < ntab; best_fol = k == 0 && fol; }
             }
             if (best_len && best_score > 0) {
                 uint32_t back = 0, back_cap = best_far ? (uint32_t)P->far_back : (uint32_t)P->back_cap;
                 m->len = best_len; m->off = best_off; m->is_rep = (uint8_t)best_rep;
                 /* backward extension potential: equal bytes just before the match and its source */
-                if (p - best_off >= back_cap) /* same rule for recent-offset guesses: no extension next to the frame start */
+                if (p - best_off >= back_cap && !best_fol) /* same rule for recent-offset guesses: no extension next to the frame start */
                     while (back < back_cap && p - back > bs && p - back > best_off &&
                            src[p - back - 1] == src[p - back - 1 - best_off]) back++;
                 m->back = (uint8_t)back;
@@ -914,8 +957,10 @@ void zge_default_params(zge_params *P, int level)
     P->back_cap = 8; P->lazy = level >= 2 || level == 0 ? 1 : 0; P->lazy_delta = 5; /* engine.hip: derive_params */
     P->lit_cost = 5; P->match_cost = 12; P->rep_cost = 9;
     P->window_log = 21; P->short_window_log = 30;
-    P->far_log = 16; P->far_ways = 1; P->far_step_log = 5; P->far_res_log = 2; P->far_short = 0; P->far_skip = 64; P->far_back = 24;
+    P->far_log = 16; P->far_ways = 1; P->far_step_log = 5; P->far_res_log = 2; P->far_short = 0; P->far_skip = 64; P->far_back = 32;
+    P->near16 = 1; P->short_log = 15; P->far_cdc_log = 4; /* round 3: one 16-bit near table of 2^15 entries, content-defined far sampling */
     if (level >= 9) { /* the engine's deep finder (engine.hip: derive_params) */
+        P->near16 = 0; P->far_cdc_log = 0; P->far_back = 8;
         P->long_log = 14; P->short_log = 14; P->short_bytes = 4; P->min_match = 4; P->match_cost = 10; P->window_log = 22;
         P->far_log = 16; P->far_ways = 2; P->far_step_log = 1; P->far_res_log = 0; P->far_short = 1; P->far_skip = 0; P->far_back = 8;
     }
@@ -955,6 +1000,7 @@ int zge_encode_frame(const zge_params *P, const void *src_, size_t n, void *dst_
         c.fs = (uint32_t *)calloc(fw, 4);
         c.farc = (uint32_t *)calloc((size_t)P->tile * ZGE_FAR_MAX, 4);
     }
+    c.t16 = (uint16_t *)calloc((size_t)1 << P->short_log, 2);
     c.tl = (uint32_t *)calloc((size_t)1 << P->long_log, 4);
     c.ts = (uint32_t *)calloc((size_t)1 << P->short_log, 4);
     c.M = (cand *)calloc((size_t)P->tile, sizeof(cand));
@@ -980,6 +1026,7 @@ int zge_encode_frame(const zge_params *P, const void *src_, size_t n, void *dst_
             }
             memset(c.tl, 0, sizeof(uint32_t) << P->long_log);
             memset(c.ts, 0, sizeof(uint32_t) << P->short_log);
+            memset(c.t16, 0, sizeof(uint16_t) << P->short_log);
             /* in a frame larger than ZGE_SPLIT_MIN a segment is a unit of work of its own in the engine (zge_match.hip: one workgroup
              * per segment, so that the segments of a large frame are searched side by side): what the finder carries from tile to
              * tile starts afresh as well */
@@ -1022,7 +1069,7 @@ int zge_encode_frame(const zge_params *P, const void *src_, size_t n, void *dst_
         uint32_t x = (uint32_t)oracle_xxh64(src, n, 0);
         dst[pos++] = (uint8_t)x; dst[pos++] = (uint8_t)(x >> 8); dst[pos++] = (uint8_t)(x >> 16); dst[pos++] = (uint8_t)(x >> 24);
     }
-    free(c.fl); free(c.fs); free(c.farc); free(c.tl); free(c.ts); free(c.M); free(c.M2); free(c.next); free(c.take); free(c.mark); free(seq); free(lit); free(blk);
+    free(c.t16); free(c.fl); free(c.fs); free(c.farc); free(c.tl); free(c.ts); free(c.M); free(c.M2); free(c.next); free(c.take); free(c.mark); free(seq); free(lit); free(blk);
     *out_len = pos;
     return 0;
 }

@@ -47,7 +47,7 @@ def real_items():
     missing = [k for k, v in items.items() if v is None]
     if missing:
         print("realdata: sources missing on this box, items skipped: %s" % missing)
-    assert sum(v is not None for v in items.values()) >= 3, "hardly any real-data source on this box: %s" % missing
+    assert sum(v is not None for v in items.values()) >= 5, "hardly any real-data source on this box: %s" % missing
     return {k: v for k, v in items.items() if v is not None}
 
 

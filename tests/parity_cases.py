@@ -61,7 +61,13 @@ def encode_cases(corpus, big):
          "periodic": bytes(range(200)) * 1500,
          # a repeat 120 KB back: long forgotten by the LDS tables, found through the far table in HBM; joined pieces across tiles
          "far_repeat": corpus.entry(27, 60000, 0) + corpus.entry(28, 60000, 1) + corpus.entry(27, 60000, 0) + corpus.entry(28, 30000, 1),
-         "far_text": corpus.entry(29, 150000, 0) + corpus.entry(29, 150000, 0)[777:90000]}
+         "far_text": corpus.entry(29, 150000, 0) + corpus.entry(29, 150000, 0)[777:90000],
+         # the 16-bit near table (round 3): several lanes of one 64-position group with the SAME bucket (short periods: the store is
+         # contested and settled by the read-back), candidates exactly 65536 and 65537 bytes back (the 16-bit distance wraps), stale entries
+         "per3": b"abc" * 4000, "per2": b"xy" * 3000 + b"q" + b"xy" * 3000,
+         "per7n": bytes((i % 7) * 31 + (rnd.randrange(256) if rnd.randrange(40) == 0 else 0) & 255 for i in range(30000)),
+         "wrap64k": corpus.entry(31, 100, 0) + corpus.entry(32, 1500, 1) + corpus.entry(33, 65536 - 1500, 0) + corpus.entry(32, 1500, 1)
+                    + corpus.entry(34, 1, 0) + corpus.entry(33, 65536 - 1500, 0)[:30000] + corpus.entry(35, 65537 - 30000 - 1, 2) + corpus.entry(33, 65536 - 1500, 0)[:2000]}
     if big:
         for k in range(4):
             c["k%d_1m" % k] = corpus.entry(40 + k, 1 << 20, k)

@@ -58,21 +58,91 @@ def items():
     out["pyc_2m"] = _tarlike(pyc, 2 << 20) if len(pyc) > 50 else None
     co = sorted(glob.glob("/opt/rocm/lib/**/*.hsaco", recursive=True)) + sorted(glob.glob("/opt/rocm/lib/rocblas/library/*.co"))
     out["hsaco_2m"] = _tarlike(co, 2 << 20) if co else None
+    # generated, no file of the box involved: the behaviour on log-like text and on relocation-table-like binaries is gated wherever
+    # the tests run
+    out["loglike_2m"] = loglike(2 << 20)
+    out["reloc_2m"] = reloc_like(2 << 20)
     return out
 
 
-# Ratio bound per item and level, ours / libzstd at the same level.  The contract (BASELINE.json north_star) is 1.05; the items
-# above it are argued in DESIGN.md section 4.1 (level 9 on machine code and on hundreds of tiny JSON files: libzstd's lazy2 parser
-# walks a 16-deep hash chain and tries the live repeat offset at every position, the tile-parallel finder sees four table ways and
-# the repeat offsets of the previous tile).  The numbers are measured values plus a little slack, so that a regression shows.
-# Machine code and byte code are outside the contract at BOTH levels (5 - 8 %): their repeats are short (5 - 8 bytes) and tens of KiB
-# apart, and the finder's short-hash table remembers 2^13 positions where libzstd -3 keeps 2^16 (chainLog 16); the model says 2^15
-# entries would bring all three within 4 %, 64 KiB of LDS per workgroup do not hold them.  GPU code objects (thousands
-# of near-identical kernels, 70x compressible) lose more: their repeats of 10 - 40 bytes at MiB distances are what libzstd's 2^17-entry
-# long table finds and the sampled far table (repeats of 44 bytes and more) does not.
-BOUND = {3: {"guides_md": 1.06, "libc_2m": 1.06, "python_bin_2m": 1.075, "pyc_2m": 1.08, "hsaco_2m": 1.35},
-         9: {"elf_head_4m": 1.09, "elf_mid_4m": 1.18, "json_node_2m": 1.10, "libc_2m": 1.065, "python_bin_2m": 1.07, "pyc_2m": 1.085, "hsaco_2m": 1.56}}
+FILE_ITEMS = ("py_stdlib_4m", "rocm_headers_4m", "json_2m", "json_node_2m", "elf_head_4m", "elf_mid_4m", "guides_md", "libc_2m",
+              "python_bin_2m", "pyc_2m", "hsaco_2m")   # built from files of the image; the other items are generated
+
+
+def loglike(n, seed=20261004):
+    """Service-log-like text: timestamps that creep forward, a few levels / components / paths, ids and durations that vary."""
+    import random
+    rnd = random.Random(seed)
+    r = lambda k: int(rnd.random() * k)
+    levels = ["INFO"] * 12 + ["DEBUG"] * 5 + ["WARN"] * 2 + ["ERROR"]
+    comps = ["http.server", "db.pool", "auth.session", "cache.l2", "queue.worker", "scheduler", "storage.blob", "rpc.client"]
+    paths = ["/api/v1/users/%d", "/api/v1/orders/%d/items", "/static/js/app.%x.js", "/healthz", "/api/v2/search?q=%x&page=%d", "/metrics"]
+    msgs = ["request completed", "connection acquired", "cache miss, fetching from origin", "retrying after transient failure",
+            "session refreshed", "job scheduled", "blob uploaded", "upstream responded", "slow query detected", "rate limit applied"]
+    t, out, size = 1759564800000, [], 0
+    while size < n:
+        t += 1 + r(40)
+        ms = t % 1000
+        sec = t // 1000
+        path = paths[r(len(paths))]
+        path = path % tuple(r(100000) for _ in range(path.count("%")))
+        line = "2026-10-%02dT%02d:%02d:%02d.%03dZ %-5s [%s] %s id=%08x user=%d path=%s status=%d dur=%dms bytes=%d\n" % (
+            4 + (sec // 86400) % 20, (sec // 3600) % 24, (sec // 60) % 60, sec % 60, ms, levels[r(len(levels))], comps[r(len(comps))],
+            msgs[r(len(msgs))], r(1 << 32), 1000 + r(5000), path, (200, 200, 200, 201, 204, 304, 404, 500)[r(8)], r(2000), r(1 << 20))
+        out.append(line)
+        size += len(line)
+    return "".join(out).encode()[:n]
+
+
+def reloc_like(n, seed=3):
+    """Relocation-table-like binary (what the head of an ELF shared object is made of): 16-byte records
+    {u32 small delta, u32 type out of a handful, u64 slowly rising address}."""
+    import random
+    import struct
+    rnd = random.Random(seed)
+    r = lambda k: int(rnd.random() * k)
+    types = (8, 8, 8, 8, 8, 8, 7, 6, 1, 37, 8, 8)
+    addr, out = 0x1C0000, bytearray()
+    while len(out) < n:
+        addr += (8, 8, 8, 8, 16, 24, 8, 8, 32, 8, 8, 4096)[r(12)]
+        out += struct.pack("<IIQ", r(4) * 8 + (r(64) if r(8) == 0 else 0), types[r(len(types))], addr)
+    return bytes(out[:n])
+
+
+# The ratio contract (BASELINE.json north_star): ours / libzstd at the same level <= 1.05.  EXCEPTIONS is the ONE table of items that
+# are outside it: (level, item) -> (bound the tests still enforce = measured value + slack so that a regression shows, why).  The gate
+# prints every item with its ratio, so the table below is always next to the numbers it excuses (see DESIGN.md section 4.1).
+CONTRACT = 1.05
+EXCEPTIONS = {
+    (3, "hsaco_2m"): (1.38, "GPU code objects (thousands of near-identical kernels, 70x compressible): repeats of 10 - 40 bytes at MiB "
+                            "distances; libzstd's 2^17-entry long table holds every position, the sampled far table one in 16"),
+    (9, "elf_head_4m"): (1.09, "level 9: libzstd's lazy2 parser tries the live repeat offset at every position; the tile-parallel finder "
+                               "knows the previous tile's"),
+    (9, "elf_mid_4m"): (1.18, "as above"),
+    (9, "json_node_2m"): (1.10, "as above (hundreds of tiny files)"),
+    (9, "libc_2m"): (1.065, "as above"),
+    (9, "python_bin_2m"): (1.07, "as above"),
+    (9, "pyc_2m"): (1.085, "as above"),
+    (9, "loglike_2m"): (1.065, "as above (fields that repeat at the previous line's offset)"),
+    (9, "hsaco_2m"): (1.56, "as level 3, and the level-9 far tables hold every 2nd position of the last two tiles' ways"),
+}
 
 
 def bound(name, level):
-    return BOUND.get(level, {}).get(name, 1.05)
+    return EXCEPTIONS.get((level, name), (CONTRACT, ""))[0]
+
+
+def gate(ratios, where):
+    """ratios: {(item, level): ours / libzstd}.  Prints the whole table (pytest -s, or the captured output of a failing test), returns the
+    list of violations: items above the contract that are not in EXCEPTIONS, or above their recorded bound."""
+    bad = []
+    print("ratio gate (%s): ours / libzstd at the same level, contract %.2f" % (where, CONTRACT))
+    for (name, level), r in sorted(ratios.items(), key=lambda kv: (kv[0][1], kv[0][0])):
+        b = bound(name, level)
+        tag = "ok" if r <= CONTRACT else ("EXCEPTION (bound %.3f)" % b if r <= b else "VIOLATION (bound %.3f)" % b)
+        print("  L%d %-18s %.4f  %s" % (level, name, r, tag))
+        if r > b:
+            bad.append((name, level, r, b))
+    return bad
+
+

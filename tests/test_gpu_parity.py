@@ -215,12 +215,20 @@ def test_gpu_environment_cannot_change_the_frames(engine, oracle, corpus, libzst
 
 
 def test_gpu_real_data_ratio_and_validity(engine, oracle, libzstds, libzstd15, real_items):
-    """Off the synthetic corpus (tests/support/realdata.py): GPU frames of source text, headers, JSON, machine code and a periodic
-    buffer are bit-identical to the model, decode under every libzstd, and stay within the ratio bounds at level 3 and level 9."""
+    """Off the synthetic corpus (tests/support/realdata.py): GPU frames of source text, headers, JSON, machine code, byte code, logs,
+    relocation-like records and a periodic buffer are bit-identical to the model, decode under every libzstd, and pass the ratio gate
+    (contract 1.05; realdata.EXCEPTIONS is the one table of items outside it) at level 3 and level 9.  Which items ran, and their
+    ratios, go to gpurun_out/realdata_gpu.json (kept as profiles/r03_realdata_gpu.json); at least 10 of the 11 file-built items must
+    exist on the box."""
+    import json
+    import os
     import realdata
     from zarc_amd import Engine
     names = list(real_items)
+    ran_files = [k for k in names if k in realdata.FILE_ITEMS]
+    assert len(ran_files) >= 10, "only %d of %d file-built items exist on this box: %s" % (len(ran_files), len(realdata.FILE_ITEMS), ran_files)
     e9 = Engine(0)
+    ratios = {}
     try:
         e9.set_parameter(_lib.P_CHECKSUM_FLAG, 1)
         e9.set_parameter(_lib.P_COMPRESSION_LEVEL, 9)
@@ -232,12 +240,23 @@ def test_gpu_real_data_ratio_and_validity(engine, oracle, libzstds, libzstd15, r
                 assert dig == oracle.blake3(raw)
                 for z in libzstds:
                     assert z.decompress(frame, len(raw))[0] == raw, (k, level, z.version)
-                ref = len(libzstd15.compress(raw, level, 1))
-                assert len(frame) <= ref * realdata.bound(k, level), (k, level, len(frame) / ref)
+                ratios[(k, level)] = len(frame) / len(libzstd15.compress(raw, level, 1))
             out = eng.unpack([f for f, _ in res], [len(real_items[k]) for k in names], [d for _, d in res])
             assert all(st == 0 and o == real_items[k] for k, (o, d, st) in zip(names, out))
     finally:
         e9.close()
+    bad = realdata.gate(ratios, "GPU frames")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(root, "gpurun_out", "realdata_gpu.json"), "w") as f:
+            json.dump({"libzstd": libzstd15.version, "contract": realdata.CONTRACT, "file_items_on_this_box": ran_files,
+                       "ratios": {"L%d %s" % (lv, k): round(r, 4) for (k, lv), r in sorted(ratios.items())},
+                       "exceptions": {"L%d %s" % (lv, k): b for (lv, k), (b, _) in realdata.EXCEPTIONS.items()},
+                       "violations": bad}, f, indent=1)
+    except OSError:
+        pass
+    assert not bad, bad
 
 
 def test_gpu_large_frames_by_segment_and_piece(oracle, corpus, libzstds):
@@ -322,3 +341,22 @@ def test_gpu_bench_starts_its_own_ranks(engine):
         pytest.skip("`bench.py --gpus 2` self-launch NOT RUN on hardware: %d visible device(s)" % ndev)
     line = _bench(["--gpus", "2"], launcher=False)
     assert line["n_gpus"] == 2 and line["roundtrip_bit_exact"] and line["config"]["entries_total"] == 128
+
+
+def test_gpu_lds_same_address_stores_keep_the_highest_lane(tmp_path):
+    """The level-3 match finder's 16-bit near table is updated with plain ds_write_b16 (there is no 16-bit LDS atomic): when several
+    lanes of one instruction store to the same address, the HIGHEST lane's value must stay -- that is what makes the table hold the
+    highest position per bucket, as the model's ascending loop does (zge_match.hip S2).  Measured property of gfx950's LDS; this test
+    pins it on whatever box the suite runs on (tools/micro/lds_write_order.hip: random, periodic, all-equal and same-dword patterns)."""
+    import os
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "lds_write_order")
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-w", "-o", exe, os.path.join(root, "tools", "micro", "lds_write_order.hip")],
+                   check=True, capture_output=True, timeout=600)
+    out = subprocess.run([exe], check=True, capture_output=True, timeout=120).stdout.decode()
+    m = re.search(r"contested slots (\d+) \| b16: highest lane wins (\d+), lowest (\d+), other (\d+) \| b32: highest (\d+), lowest (\d+), other (\d+)", out)
+    assert m, out
+    n, hi16, lo16, ot16, hi32, lo32, ot32 = map(int, m.groups())
+    assert n > 100000 and hi16 == n and hi32 == n and lo16 == ot16 == lo32 == ot32 == 0, out

@@ -74,10 +74,12 @@ def test_model_cold_stretches_keep_the_ratio_on_mixed_content(oracle, corpus, li
 
 
 def test_model_ratio_on_real_data(oracle, libzstd15, libzstds, real_items):
-    """The ratio contract off the synthetic corpus: source text, C headers, JSON, machine code, a periodic buffer -- built from
-    files of the image (tests/support/realdata.py).  Level 3 within 5 % of libzstd -3 on every item; level 9 within the bounds
-    realdata.BOUND documents.  Every frame decodes under the oracle decoder and every libzstd on the box."""
+    """The ratio contract off the synthetic corpus: source text, C headers, JSON, machine code, byte code, a periodic buffer, log-like
+    text, a relocation-table-like binary (tests/support/realdata.py).  Every item within 5 % of libzstd at the same level, except the
+    ones realdata.EXCEPTIONS lists with their measured bound -- the gate prints the whole table.  Every frame decodes under the
+    oracle decoder and every libzstd on the box."""
     import realdata
+    ratios = {}
     for name, raw in real_items.items():
         for level in (3, 9):
             frame = oracle.zge_encode(raw, oracle.params(level=level))
@@ -85,8 +87,9 @@ def test_model_ratio_on_real_data(oracle, libzstd15, libzstds, real_items):
             assert rc == 0 and out == raw and used == len(frame), (name, level)
             for z in libzstds:
                 assert z.decompress(frame, len(raw))[0] == raw, (name, level, z.version)
-            ref = len(libzstd15.compress(raw, level, 1))
-            assert len(frame) <= ref * realdata.bound(name, level), (name, level, len(frame), ref, len(frame) / ref)
+            ratios[(name, level)] = len(frame) / len(libzstd15.compress(raw, level, 1))
+    bad = realdata.gate(ratios, "model, CPU")
+    assert not bad, bad
 
 
 def test_model_joins_the_pieces_of_long_matches(oracle):

@@ -126,17 +126,21 @@ ZgeParams derive_params(const zarc_gpu_params &p)
     // level >= 9 selects the deep finder (zarc_zge_match_deep): tables of 2^14 entries, a 4-byte short hash, 4-byte matches and a
     // lower match cost -- within 5 % of libzstd -9 on the corpus, at about half the speed of the level-3 finder
     const bool deep = level >= 9;
-    z.long_log = deep ? 14 : 13; z.short_log = z.long_log; z.short_bytes = deep ? 4 : 5; z.tag_bits = 10; z.seg_log = 21; z.rep_back = 256;
+    // levels below 9 (round 3): ONE near table of 2^15 16-bit entries on the 5-byte hash (candidates 1 .. 65536 bytes back), no long table
+    z.near16 = deep ? 0 : 1;
+    z.long_log = deep ? 14 : 13; z.short_log = deep ? 14 : 15; z.short_bytes = deep ? 4 : 5; z.tag_bits = 10; z.seg_log = 21; z.rep_back = 256;
     z.tile = 1024; z.sub = 64; z.cap = diag_env("ZARC_GPU_CAP", 256);
     z.min_match = p.min_match >= 4 && p.min_match <= 7 ? p.min_match : (deep ? 4 : 5);
     z.min_rep = 3; z.rep_search = 2; z.back_cap = 8;
     z.lazy = level >= 2 ? 1 : 0; z.lazy_delta = 5;
     z.lit_cost = 5; z.match_cost = deep ? 10 : 12; z.rep_cost = 9;
     z.short_window_log = 30;
-    // far tables in HBM (zge_match.hip).  Level 3: 2^16 buckets, one way on the 12-byte hash, 4 of 32 positions inserted, every 4th
-    // looked up; level >= 9: 2^16 buckets, two ways on both hashes, every 2nd position inserted, all looked up
+    // far tables in HBM (zge_match.hip).  Level 3: 2^16 buckets, one way on the 12-byte hash, content-defined sampling: the positions
+    // whose hash has four given bits zero (one in 16) are inserted and looked up; level >= 9: 2^16 buckets, two ways on both hashes,
+    // every 2nd position inserted, all looked up
     z.far_log = 16; z.far_ways = deep ? 2 : 1; z.far_step_log = deep ? 1 : 5; z.far_res_log = deep ? 0 : 2; z.far_short = deep ? 1 : 0;
-    z.far_back = deep ? 8 : 24; z.far_skip = deep ? 0 : 64;
+    z.far_cdc_log = deep ? 0 : 4;
+    z.far_back = deep ? 8 : 32; z.far_skip = deep ? 0 : 64;
     z.dbg = diag_env("ZARC_GPU_DBG", 0); // timing-only ablations (outputs invalid when set): diagnostic build only
     return z;
 }
@@ -443,7 +447,8 @@ int zarc_gpu_pack_batch_device(zarc_gpu_t *h, size_t n, const void *d_src_base, 
     if (P.rep_back != 256 || P.back_cap != 8 || P.lazy_delta != 5 || P.min_rep != 3 || P.rep_search != 2 || P.seg_log != 21 || P.short_window_log < 30 ||
         P.lit_cost != 5 || P.rep_cost != 9 || P.tag_bits != 10 || P.far_log != 16 || P.match_cost != (P.long_log == 14 ? 10 : 12) || P.far_ways != (P.long_log == 14 ? 2 : 1) ||
         P.far_step_log != (P.long_log == 14 ? 1 : 5) || P.far_res_log != (P.long_log == 14 ? 0 : 2) || (P.far_short != 0) != (P.long_log == 14) ||
-        P.far_back != (P.long_log == 14 ? 8 : 24) || P.far_skip != (P.long_log == 14 ? 0 : 64)) { set_error(h, "internal: encoder parameters differ from the compiled-in ones"); return ZARC_GPU_E_PARAM; }
+        P.near16 != (P.long_log == 14 ? 0 : 1) || P.short_log != (P.long_log == 14 ? 14 : 15) || P.far_cdc_log != (P.long_log == 14 ? 0 : 4) ||
+        P.far_back != (P.long_log == 14 ? 8 : 32) || P.far_skip != (P.long_log == 14 ? 0 : 64)) { set_error(h, "internal: encoder parameters differ from the compiled-in ones"); return ZARC_GPU_E_PARAM; }
     uint64_t need = 0;
     for (size_t i = 0; i < n; i++) {
         if (src_off[i] % ZARC_GPU_ALIGN) { set_error(h, "entry offset not 16-byte aligned"); return ZARC_GPU_E_PARAM; }

@@ -16,7 +16,7 @@ constexpr uint32_t ZARC_MAX_SEQ = ZARC_BLOCK / 3 + 8; // sequences per block (ev
 struct ZgeParams {
     int level, checksum, window_log, long_log, short_log, short_bytes, tile, sub, cap, min_match, min_rep, rep_search,
         back_cap, lazy, lazy_delta, lit_cost, match_cost, rep_cost, short_window_log, rep_back, tag_bits, seg_log,
-        far_log, far_ways, far_step_log, far_res_log, far_short, far_skip, far_back, dbg;
+        far_log, far_ways, far_step_log, far_res_log, far_short, far_skip, far_back, near16, far_cdc_log, dbg;
 };
 // words of far-table scratch one match-finder workgroup needs (HBM): 2^far_log buckets x ways, once or twice
 __host__ __device__ inline size_t zge_far_words(const ZgeParams &P) { return P.far_log ? (((size_t)P.far_ways << P.far_log) * (P.far_short ? 2 : 1)) : 0; }

@@ -45,6 +45,9 @@ namespace {
 // going through LDS, and the chain over chunk entries hops pair by pair)
 #define ZGE_IDX(u) ((uint32_t)((wave * PER + (u)) * 64 + lane))
 // stage timing (diagnostics): ticks since the previous mark, accumulated per stage; each mark sits after a barrier
+#ifndef ZGE_S2_DUPMASK
+#define ZGE_S2_DUPMASK 0 // A/B switch: 1 = a lane whose right neighbour has the same hash does not store (what the 32-bit tables' atomics need)
+#endif
 #define ZGE_PROF(i) do { if ((dbg & 1024) && tid == 0) { const unsigned long long now_ = ZGE_CLOCK(); L.prof[i] += now_ - tprev; tprev = now_; } } while (0)
 
 constexpr int TILE = 1024;
@@ -59,9 +62,12 @@ constexpr int CAP_MAX = 256;
 constexpr int REP_BACK_MAX = 256;
 constexpr int TB_BYTES = 12 + REP_BACK_MAX + TILE + CAP_MAX + 24; // rep window + 8 bytes before the tile, compare overrun after it
 
-template <int TAB_LOG> struct MatchLds {
-    uint32_t tl[1 << TAB_LOG];
-    uint32_t ts[1 << TAB_LOG];
+// NEAR16 (the level-3 finder since round 3): ONE near table of 2^TAB_LOG 16-bit entries keyed by the short hash -- an entry is the
+// low 16 bits of a position, a candidate lies 1 .. 65536 bytes back, there are no check bits and no long table (2^15 entries in the
+// 64 KiB the two 2^13-entry tables took).  Otherwise: long table, then short table, 2^TAB_LOG 32-bit entries each.
+template <int TAB_LOG, bool NEAR16> struct MatchLds {
+    static constexpr int TAB_WORDS = NEAR16 ? (1 << TAB_LOG) / 2 : 2 << TAB_LOG;
+    uint32_t tab[TAB_WORDS + (NEAR16 ? 1 : 0)]; // NEAR16: one more word = slot 2^TAB_LOG, where positions without a hash look up and store (no branch in the chain)
     uint32_t a0[TILE], a1[TILE]; // S1: hashes -> S2: candidates (pos+1) -> S3: a0 = own match (match_pack) -> S4: a1 = final match
     uint32_t ex[TILE];            // S4: best backward offer per position; S6: first position outside its chunk reached from each position
     uint32_t tb[2][(TB_BYTES + 3) / 4]; // the window of a tile lives in buffer (tile / TILE) & 1: the current tile's and the next one's
@@ -149,8 +155,13 @@ __device__ __forceinline__ uint32_t tile_end(uint32_t tile, uint32_t n)
 // P carries the same values.  Positions p with p mod 2^FAR_STEP_LOG < 2^FAR_RES_LOG are inserted, positions with
 // p mod 2^FAR_RES_LOG == 0 are looked up: of 2^FAR_RES_LOG inserted neighbours exactly one lands on a looked-up position whatever the
 // offset of the repeat -- the memory requests per tile (what the far tables cost) go down by that factor.
-template <int TAB_LOG, int SHORT_BYTES, int MATCH_COST, int F_FAR_LOG, int FAR_WAYS, bool FAR_SHORT, int FAR_STEP_LOG, int FAR_RES_LOG, int FAR_SKIP, int FAR_BACK, bool DIAG>
-__device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgeParams &P, const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off,
+// FAR_CDC > 0: content-defined sampling of the far table (FAR_STEP_LOG / FAR_RES_LOG unused): a position is inserted AND looked up iff
+// the FAR_CDC bits of its 12-byte hash just below the bucket and check bits are zero.  Both occurrences of a repeat sample the same
+// relative positions, so a repeat is found when it contains one sample: 64 lookups + 64 inserts per 1024-position tile at FAR_CDC 4
+// instead of 256 + 128, and every thread asks for its OWN positions (no hand-over between lanes).
+template <int TAB_LOG, int SHORT_BYTES, int MATCH_COST, int F_FAR_LOG, int FAR_WAYS, bool FAR_SHORT, int FAR_STEP_LOG, int FAR_RES_LOG, int FAR_SKIP, int FAR_BACK, bool DIAG,
+          bool NEAR16, int FAR_CDC>
+__device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG, NEAR16> &L, const ZgeParams &P, const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off,
                                                const uint64_t *__restrict__ src_len, const uint32_t *__restrict__ order, const uint32_t *__restrict__ units, uint32_t n_units,
                                                const uint64_t *__restrict__ block_prefix, ZgeBlock *__restrict__ blocks,
                                                uint64_t *__restrict__ seq_scratch, uint8_t *__restrict__ lit_scratch, uint32_t *__restrict__ queue,
@@ -163,7 +174,12 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
     uint32_t *const far_l = far_scratch + (size_t)blockIdx.x * far_words;  // this workgroup's slab: long-hash table, then short-hash table
     uint32_t *const far_s = far_l + ((size_t)FAR_WAYS << F_FAR_LOG);
     constexpr uint32_t far_smask = (1u << FAR_STEP_LOG) - 1, far_rmask = (1u << FAR_RES_LOG) - 1;
-    static_assert(FAR_BACK == 8 || FAR_BACK == 16 || FAR_BACK == 24 || FAR_BACK == 32, "backward extension of far candidates");
+    static_assert(FAR_BACK % 8 == 0 && FAR_BACK >= 8 && FAR_BACK <= 48, "backward extension of far candidates");
+    static_assert(!FAR_CDC || (FAR_WAYS == 1 && !FAR_SHORT && far_shift >= FAR_CDC), "content-defined sampling: one way on the 12-byte hash");
+    constexpr uint32_t cdc_mask = (1u << FAR_CDC) - 1;
+    uint32_t *const Ltl = L.tab, *const Lts = L.tab + (NEAR16 ? 0 : (1 << TAB_LOG)); // long / short table (not NEAR16)
+    typedef uint16_t __attribute__((may_alias)) u16a;
+    u16a *const Lt16 = (u16a *)L.tab;                                                  // the 16-bit near table (NEAR16)
     const int tid = (int)threadIdx.x, lane = zd::lane_id();
     const uint32_t dbg = DIAG ? (uint32_t)P.dbg : 0u;
     const int wave = (int)zd::uniform((uint32_t)zd::wave_id()); // scalar: chunk bounds and the parse walk stay on the SALU
@@ -196,7 +212,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
     const uint64_t first_block = block_prefix[slot];
     const uint32_t nblocks = (uint32_t)(block_prefix[slot + 1] - first_block);
 
-    for (int i = tid; i < (1 << TAB_LOG); i += THREADS) { L.tl[i] = 0; L.ts[i] = 0; }
+    for (int i = tid; i < MatchLds<TAB_LOG, NEAR16>::TAB_WORDS; i += THREADS) L.tab[i] = 0;
     if (NFAR) { // the slab still holds the previous frame (whose last inserts were waited for in its last tile)
         uint4 *f4 = (uint4 *)far_l;
         for (uint32_t i = (uint32_t)tid; i < far_words / 4; i += THREADS) f4[i] = make_uint4(0, 0, 0, 0);
@@ -215,10 +231,11 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
     // With FAR_RES_LOG > 0 only every 2^FAR_RES_LOG-th position is looked up: the wave's 128 >> FAR_RES_LOG lookups are made by its
     // first lanes (lane l asks for position wave * 128 + (l << FAR_RES_LOG), one pass instead of two mostly idle ones) and handed to
     // the lanes that own those positions by a shuffle at the top of the next tile.
-    constexpr bool FAR_COMPACT = FAR_RES_LOG > 0;
+    constexpr bool FAR_COMPACT = FAR_RES_LOG > 0 && !FAR_CDC;
     constexpr int FNEXT_ROWS = FAR_COMPACT ? 1 : PER;
     uint32_t fnext[FNEXT_ROWS][NFAR ? NFAR : 1];
     uint32_t pf_far_tile = 0xFFFFFFFFu; // the tile fnext[] belongs to
+    uint32_t hfn[PER] = {0xFFFFFFFFu, 0xFFFFFFFFu}; // FAR_CDC: bucket | check bits of this thread's positions of that tile (0xFFFFFFFF: not a far position)
     // Tile windows are staged two tiles ahead: at the top of tile T the window of T+1 goes to the other LDS buffer (it was requested
     // during T-1 and sits in a register) and the window of T+2 is requested.  S1 hashes the next tile's positions out of that buffer.
     uint32_t pf_word = 0, pf_tile = 0xFFFFFFFFu;            // this thread's dword of the window of tile `pf_tile`
@@ -240,7 +257,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
         uint8_t *lit_out = lit_scratch + (first_block + b) * (uint64_t)(ZARC_BLOCK + 64);
 
         if (b > ub0 && (bs & seg_mask) == 0) { // a frame that is one unit: new 2^seg_log segment (a multiple of the block size), table positions restart
-            for (int i = tid; i < (1 << TAB_LOG); i += THREADS) { L.tl[i] = 0; L.ts[i] = 0; }
+            for (int i = tid; i < MatchLds<TAB_LOG, NEAR16>::TAB_WORDS; i += THREADS) L.tab[i] = 0;
             if (NFAR) {
                 uint4 *f4 = (uint4 *)far_l;
                 for (uint32_t i = (uint32_t)tid; i < far_words / 4; i += THREADS) f4[i] = make_uint4(0, 0, 0, 0);
@@ -347,6 +364,8 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
             // far-table entries (requested during the previous tile; only a tile that follows unsearched ones asks here and waits in
             // S3), the check bits they must carry, and -- entries at hand -- the far candidates' sources, requested now: ahead of S2
             uint32_t fe[PER][NFAR ? NFAR : 1], ftag[PER][FAR_SHORT ? 2 : 1];
+            // FAR_CDC: bucket | check bits of a position that IS a far position (else 0xFFFFFFFF) wait in a1[] -- free until S4 with one near
+            // table -- for S3 (a tile that asked for its entries late) and for the inserts after S3: two registers less across S3
             uint32_t foffs[PER][NFAR ? NFAR : 1];
             uint64_t qf[PER][NFAR ? NFAR : 1]; // far candidates: source[0 .. 8) only (registers); a far winner fetches the 8 bytes in front later
             const bool far_ahead = NFAR && pf_far_tile == tile; // uniform
@@ -361,17 +380,41 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
                     if (FAR_COMPACT) { // from the lane that asked for this position (only looked-up positions read a meaningful value)
                         const uint32_t got = zd::shfl(fnext[0][k], (int)(((uint32_t)u * 64u + (uint32_t)lane) >> FAR_RES_LOG));
                         fe[u][k] = (far_ahead && !(idx & far_rmask)) ? got : 0u;
-                    } else fe[u][k] = far_ahead ? fnext[FAR_COMPACT ? 0 : u][k] : 0u;
+                    } else fe[u][k] = far_ahead ? fnext[FAR_COMPACT ? 0 : u][k] : 0u; // (FAR_CDC: a position that is no far position got 0)
                     foffs[u][k] = 0; qf[u][k] = 0;
                 }
                 ftag[u][0] = 0xFFFFFFFFu; // matches no entry
                 if (FAR_SHORT) ftag[u][1] = 0xFFFFFFFFu;
+                uint32_t hfc = 0xFFFFFFFFu;
                 if (idx < tcount) {
                     p8[u] = zd::load_u64(tbb + (uint32_t)(p + wofs));
                     if (p < hash_end && !(dbg & 64)) {
-                        const uint32_t h32l = hash_long32(p8[u]), h32s = hash_short32(p8[u], SHORT_BYTES);
-                        hl = h32l >> (32 - (TAB_LOG + TAG_BITS));
-                        hs = h32s >> (32 - (TAB_LOG + TAG_BITS));
+                        const uint32_t h32s = hash_short32(p8[u], SHORT_BYTES);
+                        const uint32_t h32l = NEAR16 ? 0u : hash_long32(p8[u]);
+                        hl = NEAR16 ? 0xFFFFFFFFu : h32l >> (32 - (TAB_LOG + TAG_BITS));
+                        hs = NEAR16 ? h32s >> (32 - TAB_LOG) : h32s >> (32 - (TAB_LOG + TAG_BITS));
+                        if (FAR_CDC) {
+                            // Is this a far position?  Known since the previous tile's S3 (hfn) when the entries were requested there;
+                            // a tile that follows unsearched ones hashes its 12 bytes here and asks now (the entries are waited for in S3).
+                            if (p < far_end && !(dbg & 2048)) {
+                                if (far_ahead) hfc = hfn[u];
+                                else {
+                                    const uint32_t w8 = zd::load_u32(tbb + (uint32_t)(p + 8 + wofs));
+                                    const uint32_t h32f = hash_far32(p8[u], w8);
+                                    if (((h32f >> (far_shift - FAR_CDC)) & cdc_mask) == 0 && !((uint32_t)p8[u] == (uint32_t)(p8[u] >> 32) && (uint32_t)p8[u] == w8)) hfc = h32f >> far_shift;
+                                }
+                            }
+                            if (hfc != 0xFFFFFFFFu) {
+                                if (!far_ahead) fe[u][0] = zd::load_l2_u32(far_l + (size_t)(hfc >> TAG_BITS));
+                                else {
+                                    const uint32_t e = fe[u][0];
+                                    uint32_t o = (e && (e & TAG_MASK) == (hfc & TAG_MASK) && !(dbg & 4096)) ? p - (segbase + (e >> TAG_BITS) - 1) : 0u;
+                                    if (o + 8 > p || o > window || (dbg & 1)) o = 0;
+                                    foffs[u][0] = o;
+                                    if (o) qf[u][0] = zd::load_u64(src + (p - o));
+                                }
+                            }
+                        } else
                         if (NFAR && p < far_end && !(p & far_rmask) && !(dbg & 2048)) {
                             const uint32_t hf = (h32l + zd::load_u32(tbb + (uint32_t)(p + 8 + wofs)) * 0xC2B2AE3Du) >> far_shift, hg = h32s >> far_shift;
                             ftag[u][0] = hf & TAG_MASK;
@@ -397,17 +440,56 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
                         }
                     }
                 }
-                L.a0[idx] = hl;
-                L.a1[idx] = hs;
+                L.a0[idx] = NEAR16 ? (hs == 0xFFFFFFFFu ? (1u << TAB_LOG) : hs) : hl; // NEAR16: the one table's hash goes through a0 (no hash: the spare slot), a1 is free until S4
+                if (!NEAR16) L.a1[idx] = hs;
+                else if (FAR_CDC) L.a1[idx] = hfc;
                 L.ex[idx] = 0; // S4 offers start empty (the previous tile's walk is over)
             }
             zd::lds_barrier();
             ZGE_PROF(2);
             // ---- S2: ordered lookup + insert (wave 0); no waits between the steps on hardware ----
             // The two tables are independent: wave 0 owns the long table, wave 1 the short one.
+            if (NEAR16) {
+              if (wave == 0 && !(dbg & 4)) {
+                // One table of 16-bit entries (the low 16 bits of the position), one wave, and -- as with the 32-bit tables -- not a
+                // single wait inside the chain: 16 x (lookup, store) go to the LDS back to back, which executes them in order.  There is
+                // no 16-bit LDS atomic; the stores are plain ds_write_b16, and when several lanes of a group have the same bucket the
+                // value of the HIGHEST lane stays.  That is how gfx950's LDS resolves same-address stores of one instruction (measured:
+                // tools/micro/lds_write_order.hip, every one of 143 326 contested slots in random / periodic / all-equal / same-dword
+                // patterns; tests/test_gpu_parity.py runs it on every box), and it is what the model's ascending loop does.  Groups are
+                // 64-aligned, so a group's positions never wrap in 16 bits.  Were a chip to resolve such stores differently the frames
+                // would still be valid (a candidate is only ever a position to compare with), they would differ from the model's.
+                zd::wave_priority<3>(); // the other seven waves wait for this one: go ahead of the co-resident workgroup
+                uint32_t h[CHUNKS], e[CHUNKS];
+#if ZGE_S2_DUPMASK
+                uint64_t dupmask = 0; // bit k: the next lane of group k has the same hash, so its store supersedes mine
+#endif
+#pragma unroll
+                for (int k = 0; k < CHUNKS; k++) {
+                    h[k] = L.a0[k * 64 + lane];
+#if ZGE_S2_DUPMASK
+                    const uint32_t hn = lane < 63 ? L.a0[k * 64 + lane + 1] : 0xFFFFFFFFu;
+                    if (hn == h[k]) dupmask |= 1ull << k;
+#endif
+                }
+#pragma unroll
+                for (int k = 0; k < CHUNKS; k++) {
+                    e[k] = (uint32_t)Lt16[h[k]];
+                    zd::wave_lds_order(); // lookups of this 64-group precede its stores
+#if ZGE_S2_DUPMASK
+                    if (!((dupmask >> k) & 1))
+#endif
+                    Lt16[h[k]] = (uint16_t)((uint32_t)tile + (uint32_t)(k * 64 + lane));
+                    zd::wave_lds_order(); // stores precede the next group's lookups
+                }
+#pragma unroll
+                for (int k = 0; k < CHUNKS; k++) L.a0[k * 64 + lane] = e[k]; // the entries as they are: S3 turns them into distances
+                zd::wave_priority<0>();
+              }
+            } else
             if (wave < 2 && !(dbg & 4)) {
                 zd::wave_priority<3>(); // the other six waves wait for these two: go ahead of the co-resident workgroup
-                uint32_t *tab = wave == 0 ? L.tl : L.ts;
+                uint32_t *tab = wave == 0 ? Ltl : Lts;
                 uint32_t *hc = wave == 0 ? L.a0 : L.a1; // hashes in, candidates out
                 uint32_t h[CHUNKS], e[CHUNKS];
                 uint64_t dupmask = 0; // bit k: the next lane of group k has the same hash, so its insert supersedes mine
@@ -442,6 +524,41 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
             // idx + rep_back rule) are LDS reads at a lane offset; hash candidates are global loads `frame base (SGPR) + position`.
             // Phase A requests the first 8 source bytes of every candidate of BOTH positions, phase B scores them and loads more
             // only for candidates that match 8 bytes. ----
+            uint32_t near_e[PER] = {0, 0}; // NEAR16: the near table's entries of this thread's positions (S2 left them in a0)
+            if (FAR_CDC) {
+                // the NEXT tile's far entries, content-defined: every thread hashes its own two positions of that tile out of its window
+                // in the other LDS buffer (written in S0, two barriers ago) and asks for the entry where the position is a far position;
+                // the bucket | check bits stay in a register until that tile's inserts.  The requests have S3 to come back.
+                // (all LDS reads of this stage -- the next tile's 12 bytes and the near table's entries of both positions -- go out together:
+                // under their conditions each would be a round trip of its own)
+                uint64_t vnx[PER];
+                uint32_t wnx[PER];
+#pragma unroll
+                for (int u = 0; u < PER; u++) {
+                    const uint32_t pn = ntile + ZGE_IDX(u);
+                    const uint32_t at = pn < far_end ? (uint32_t)(pn + wofs_n) : 0u; // no next position: any address inside the buffer
+                    vnx[u] = zd::load_u64(tbn + at);
+                    wnx[u] = zd::load_u32(tbn + at + 8);
+                    if (NEAR16) near_e[u] = L.a0[ZGE_IDX(u)];
+                }
+#pragma unroll
+                for (int u = 0; u < PER; u++) {
+                    const uint32_t pn = ntile + ZGE_IDX(u);
+                    hfn[u] = 0xFFFFFFFFu;
+                    fnext[u][0] = 0;
+                    if (pn < far_end && !(dbg & (2048 | 32768))) {
+                        const uint64_t vn = vnx[u];
+                        const uint32_t wn = wnx[u];
+                        const uint32_t h32f = hash_far32(vn, wn);
+                        // (windows of period 1, 2 or 4 -- three equal words: runs, zero padding -- are no far positions: every position of such a stretch would hit one bucket)
+                        if (((h32f >> (far_shift - FAR_CDC)) & cdc_mask) == 0 && !((uint32_t)vn == (uint32_t)(vn >> 32) && (uint32_t)vn == wn)) {
+                            hfn[u] = h32f >> far_shift;
+                            fnext[u][0] = zd::load_l2_u32(far_l + (size_t)(hfn[u] >> TAG_BITS));
+                        }
+                    }
+                }
+                pf_far_tile = ntile;
+            } else
             if (NFAR) {
                 // the NEXT tile's far entries: hashes out of its window in the other LDS buffer; requested here, behind two barriers since S0 wrote that buffer; the requests have S3 to come back
 #pragma unroll
@@ -467,11 +584,22 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
             uint32_t mo[PER], mw[PER];
             uint32_t offs[PER][NTAB];
             U128 q16[PER];                    // near candidate: source[-8 .. 8)
+            // NEAR16, runs: inside a repeat every position's 5-byte hash leads to the same distance, and then its match at that distance is
+            // its left neighbour's minus one byte.  A position whose (validated) near distance equals its left neighbour's -- same
+            // 64-position chunk, i.e. the lane below -- is a FOLLOWER: it requests no source and compares nothing, its near length is
+            // handed down from the head of its run (the nearest lane below that is no follower) after the heads have compared.  What S3
+            // costs is source requests per CU; in compressible data most positions are followers.
+            bool fol[PER];
 #pragma unroll
             for (int u = 0; u < PER; u++) {
                 const uint32_t idx = ZGE_IDX(u);
                 const uint32_t p = tile + idx;
                 uint32_t cn = 0;
+                fol[u] = false;
+                if (NEAR16) { // S2 left the table entry: the candidate lies d = 1 .. 65536 bytes back, d = (p - entry) mod 2^16 (0 -> 65536)
+                    const uint32_t d = ((p - (FAR_CDC ? near_e[u] : L.a0[idx]) - 1u) & 0xFFFFu) + 1u;
+                    cn = (idx < tcount && p < hash_end && d <= p && !(dbg & (5 | 64))) ? p - d + 1 : 0u;
+                } else
                 if (idx < tcount && !(dbg & 5)) {
                     // candidate position (+1): a table hit whose check bits agreed.  One near candidate: the long table's when it has a
                     // hit, the short table's only otherwise (with a long-hash hit at hand the short-hash candidate changes 0.003 % of the
@@ -484,14 +612,16 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
                 // the source needs 8 bytes in front of it (frame positions 0..7 are not used as sources)
                 if (on + 8 > p || on > window || idx >= tcount || (dbg & 1)) on = 0;
                 offs[u][0] = on;
+                if (NEAR16) { const uint32_t below = zd::shfl_up1(on); fol[u] = lane > 0 && on != 0 && on == below && !(dbg & 16); }
                 // one 16-byte request: source[-8 .. 0) for the backward extension, source[0 .. 8)
                 q16[u] = U128{0, 0};
-                if (on) __builtin_memcpy(&q16[u], src + (p - on - 8), 16);
+                if (on && !fol[u]) __builtin_memcpy(&q16[u], src + (p - on - 8), 16);
                 if (NFAR && !far_ahead) { // entries asked for in S1 of this very tile: their sources can only be requested now
 #pragma unroll
                     for (int k = 0; k < NFAR; k++) {
                         const uint32_t e = fe[u][k];
-                        uint32_t o = (e && (e & TAG_MASK) == ftag[u][k / (FAR_WAYS ? FAR_WAYS : 1)] && !(dbg & 4096)) ? p - (segbase + (e >> TAG_BITS) - 1) : 0u;
+                        const uint32_t want = FAR_CDC ? (L.a1[idx] == 0xFFFFFFFFu ? 0xFFFFFFFFu : (L.a1[idx] & TAG_MASK)) : ftag[u][k / (FAR_WAYS ? FAR_WAYS : 1)];
+                        uint32_t o = (e && (e & TAG_MASK) == want && !(dbg & 4096)) ? p - (segbase + (e >> TAG_BITS) - 1) : 0u;
 #pragma unroll
                         for (int j = 0; j < k; j++) if (o == foffs[u][j]) o = 0;
                         if (o + 8 > p || o > window || idx >= tcount || (dbg & 1)) o = 0;
@@ -548,16 +678,13 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
                 int32_t best_score = -1000000;
                 uint64_t best_before = 0; // the 8 bytes in front of the best candidate's source
                 bool best_far = false;    // ... still to be fetched (far candidates are requested without them)
-#pragma unroll
-                for (int k = 0; k < NTAB; k++) {
-                    const uint32_t off = offs[u][k];
-                    if (!off) continue;
-                    if (FAR_SKIP && k >= 1 && best_len >= (uint32_t)FAR_SKIP) continue; // with that many bytes in hand a far candidate is not looked at: it would be the tile's longest compare
-                    const bool is_rep = off == erep0 || off == erep1;
-                    uint64_t x = (k < 1 ? q16[u].hi : qf[u][k < 1 ? 0 : k - 1]) ^ p8[u];
+                bool best_fol = false;    // the winner is a follower's handed-down near match: no backward extension (the positions in front of it belong to the same run)
+                // common prefix with the source `off` bytes back whose first 8 bytes are `first8`: 8 bytes per step, 16 per global round trip;
+                // reads past `cap` stay inside the staged window / the padded arena
+                auto prefix_len = [&](uint32_t off, uint64_t first8) -> uint32_t {
+                    uint64_t x = first8 ^ p8[u];
                     uint32_t len = 0;
-                    // common prefix, 8 bytes per step; reads past `cap` stay inside the staged window / the padded arena
-                    while (!x && len + 8 < cap) { // 16 bytes per global round trip
+                    while (!x && len + 8 < cap) {
                         U128 sv;
                         __builtin_memcpy(&sv, src + (p - off + len + 8), 16);
                         const uint64_t a0 = zd::load_u64(tbb + (uint32_t)(p + len + 8 + wofs)), a1 = zd::load_u64(tbb + (uint32_t)(p + len + 16 + wofs));
@@ -566,10 +693,26 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
                         if (!x && len + 8 < cap) { len += 8; x = a1 ^ sv.hi; }
                     }
                     len += x ? (uint32_t)(zd::ctz64(x) >> 3) : 8u;
-                    if (len > cap) len = cap;
+                    return len > cap ? cap : len;
+                };
+                uint32_t near_len = 0; // NEAR16: the near candidate's length -- compared by the heads, handed down to the followers
+                if (NEAR16) {
+                    if (offs[u][0] && !fol[u]) near_len = prefix_len(offs[u][0], q16[u].hi);
+                    const uint64_t heads = zd::ballot(!fol[u]);                                  // lane 0 is never a follower
+                    const uint32_t hl = 63u - (uint32_t)__clzll((long long)(heads & (~0ull >> (63 - lane)))); // the nearest head at or below this lane
+                    const uint32_t handed = zd::shfl(near_len, (int)hl);
+                    if (fol[u]) { const uint32_t j = (uint32_t)lane - hl; near_len = handed > j ? handed - j : 0u; }
+                }
+#pragma unroll
+                for (int k = 0; k < NTAB; k++) {
+                    const uint32_t off = offs[u][k];
+                    if (!off) continue;
+                    if (FAR_SKIP && k >= 1 && best_len >= (uint32_t)FAR_SKIP) continue; // with that many bytes in hand a far candidate is not looked at: it would be the tile's longest compare
+                    const bool is_rep = off == erep0 || off == erep1;
+                    const uint32_t len = (NEAR16 && k < 1) ? near_len : prefix_len(off, k < 1 ? q16[u].hi : qf[u][k < 1 ? 0 : k - 1]);
                     if (len < (uint32_t)(is_rep ? F_MIN_REP : P.min_match)) continue;
                     const int32_t sc = score_of(P, len, off, is_rep);
-                    if (sc > best_score) { best_score = sc; best_len = len; best_off = off; best_rep = is_rep; best_far = k >= 1; if (k < 1) best_before = q16[u].lo; }
+                    if (sc > best_score) { best_score = sc; best_len = len; best_off = off; best_rep = is_rep; best_far = k >= 1; best_fol = NEAR16 && k < 1 && fol[u]; if (k < 1) best_before = q16[u].lo; }
                 }
                 bool from_guess = false;
                 { // the recent-offset guesses rank after the table candidates (ties keep the earlier candidate)
@@ -577,7 +720,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
                     if (r) {
                         const uint32_t len = r & 0x1FFu;
                         const int32_t sc = score_of(P, len, 1, true);
-                        if (sc > best_score) { best_score = sc; best_len = len; best_off = (r >> 9) ? erep1 : erep0; best_rep = true; from_guess = true; best_far = false; }
+                        if (sc > best_score) { best_score = sc; best_len = len; best_off = (r >> 9) ? erep1 : erep0; best_rep = true; from_guess = true; best_far = false; best_fol = false; }
                     }
                 }
                 if (best_len && best_score > 0) {
@@ -588,7 +731,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
                     uint32_t maxb = bcap;
                     if (p - bs < maxb) maxb = (uint32_t)(p - bs);
                     uint32_t back = 0;
-                    if (maxb && q >= bcap) { // then p - bcap and (for a guess) q - 8 are inside the staged window
+                    if (maxb && q >= bcap && !best_fol) { // then p - bcap and (for a guess) q - 8 are inside the staged window
                         if (from_guess) best_before = zd::load_u64(tbb + (uint32_t)(q - 8 + wofs));
                         if (NFAR && best_far) best_before = zd::load_u64(src + (q - 8));
                         const uint64_t x = zd::load_u64(tbb + (uint32_t)(p - 8 + wofs)) ^ best_before;
@@ -616,7 +759,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
             for (int u = 0; u < PER; u++) L.a0[ZGE_IDX(u)] = match_pack(mo[u], mw[u] & 0xFFFF, (mw[u] >> 24) & 1);
             if (mo[0] | mo[1]) L.ctrl[K_ANY] = 1; // benign race: every writer stores 1
             // ---- S4: backward propagation.  A position whose match extends b bytes backwards offers it to the b
-            // positions before it (ds_max of score << 6 | 32-k: best score wins, then the nearest source); every position
+            // positions before it (ds_max of score << 6 | 63-k: best score wins, then the nearest source); every position
             // then adopts the best offer if it beats its own match.  Same result as scanning the 8 following positions.
 #pragma unroll
             for (int u = 0; u < PER; u++) {
@@ -626,7 +769,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
                     const bool rep = (mw[u] >> 24) & 1;
                     for (uint32_t k = 1; k <= back && k <= idx; k++) {
                         const int32_t sc = score_of(P, len + k, mo[u], rep);
-                        if (sc > 0) atomicMax(&L.ex[idx - k], ((uint32_t)sc << 6) | (32u - k));
+                        if (sc > 0) atomicMax(&L.ex[idx - k], ((uint32_t)sc << 6) | (63u - k));
                     }
                 }
             }
@@ -641,6 +784,11 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
                 for (int u = 0; u < PER; u++) {
                     const uint32_t idx = ZGE_IDX(u);
                     const uint32_t p = tile + idx;
+                    if (FAR_CDC) { // the far positions of this tile: bucket | check bits known since S1
+                        const uint32_t hfc = L.a1[idx];
+                        if (hfc != 0xFFFFFFFFu && !(dbg & (64 | 8192)))
+                            zd::atomic_max_l2(far_l + (size_t)(hfc >> TAG_BITS), ((((uint32_t)(tile - segbase) + idx + 1) << TAG_BITS)) | (hfc & TAG_MASK));
+                    } else
                     if (idx < tcount && p < far_end && (p & far_smask) <= far_rmask && !(dbg & (64 | 8192))) {
                         const uint32_t code = ((uint32_t)(tile - segbase) + idx + 1) << TAG_BITS;
                         const uint32_t hf = hash_far32(p8[u], zd::load_u32(tbb + (uint32_t)(p + 8 + wofs))) >> far_shift;
@@ -677,7 +825,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG> &L, const ZgePa
                 if (offer) {
                     const int32_t own = blen_ ? score_of(P, blen_, boff, brep) : 0;
                     if ((int32_t)(offer >> 6) > own) {
-                        const uint32_t k = 32u - (offer & 63u);
+                        const uint32_t k = 63u - (offer & 63u);
                         const uint32_t nm = L.a0[idx + k];
                         boff = match_off(nm);
                         blen_ = match_len(nm) + k;
@@ -830,8 +978,8 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                                                       uint64_t *__restrict__ seq_scratch, uint8_t *__restrict__ lit_scratch, uint32_t *__restrict__ queue,
                                                       uint32_t *__restrict__ far_scratch)
 {
-    __shared__ MatchLds<13> L;
-    zge_match_body<13, 5, 12, 16, 1, false, 5, 2, 64, 24, false>(L, P, src_base, src_off, src_len, order, units, n_units, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
+    __shared__ MatchLds<15, true> L;
+    zge_match_body<15, 5, 12, 16, 1, false, 5, 2, 64, 32, false, true, 4>(L, P, src_base, src_off, src_len, order, units, n_units, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
 }
 
 #ifdef ZARC_GPU_DIAG
@@ -843,8 +991,8 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match_diag(ZgeParams P, const
                                                            uint64_t *__restrict__ seq_scratch, uint8_t *__restrict__ lit_scratch, uint32_t *__restrict__ queue,
                                                            uint32_t *__restrict__ far_scratch)
 {
-    __shared__ MatchLds<13> L;
-    zge_match_body<13, 5, 12, 16, 1, false, 5, 2, 64, 24, true>(L, P, src_base, src_off, src_len, order, units, n_units, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
+    __shared__ MatchLds<15, true> L;
+    zge_match_body<15, 5, 12, 16, 1, false, 5, 2, 64, 32, true, true, 4>(L, P, src_base, src_off, src_len, order, units, n_units, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
 }
 #endif
 
@@ -854,6 +1002,6 @@ __global__ void __launch_bounds__(512, 2) zarc_zge_match_deep(ZgeParams P, const
                                                            uint64_t *__restrict__ seq_scratch, uint8_t *__restrict__ lit_scratch, uint32_t *__restrict__ queue,
                                                            uint32_t *__restrict__ far_scratch)
 {
-    __shared__ MatchLds<14> L;
-    zge_match_body<14, 4, 10, 16, 2, true, 1, 0, 0, 8, false>(L, P, src_base, src_off, src_len, order, units, n_units, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
+    __shared__ MatchLds<14, false> L;
+    zge_match_body<14, 4, 10, 16, 2, true, 1, 0, 0, 8, false, false, 0>(L, P, src_base, src_off, src_len, order, units, n_units, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
 }
