@@ -60,7 +60,9 @@ enum {
     ZARC_GPU_FRAME_DSTSIZE = 4,        /* "Destination buffer is too small"                          */
     ZARC_GPU_FRAME_BAD_MAGIC = 5,      /* "Unknown frame descriptor"                                 */
     ZARC_GPU_FRAME_UNSUPPORTED = 6,    /* dictionary id / window beyond the engine limit             */
-    ZARC_GPU_FRAME_SRCSIZE = 7         /* "Src size is incorrect" (frame shorter/longer than given)  */
+    ZARC_GPU_FRAME_SRCSIZE = 7,        /* "Src size is incorrect" (frame shorter/longer than given)  */
+    ZARC_GPU_FRAME_DUPLICATE = 8       /* pack, hash-first entry points only: content already known to the caller, nothing was compressed
+                                          ("frame already exists, skipping", content_frame.rs:30-33); not an error                       */
 };
 
 /* Parameter ids are libzstd's ZSTD_cParameter values, which is what zstd_safe::CParameter maps to and
@@ -84,17 +86,26 @@ enum {
     ZARC_GPU_PX_STAGE_CHUNK = 9002,  /* host-pointer entry points: content bytes per staged chunk (0 = 2 GiB pack / 4 GiB unpack; >= 4096)         */
     ZARC_GPU_PX_STAGE_THREAD = 9003, /* 1 (default) = a helper thread moves neighbouring chunks over PCIe while the kernels run                     */
     ZARC_GPU_PX_COPY_THREADS = 9004, /* host threads that fill / drain the pinned staging ring (default 8)                                          */
-    ZARC_GPU_PX_DEC_GROUPS = 9005    /* unpack: frames are dealt by descending size into this many groups whose stages overlap (1..4; 0 = by the
+    ZARC_GPU_PX_DEC_GROUPS = 9005,   /* unpack: frames are dealt by descending size into this many groups whose stages overlap (1..4; 0 = by the
                                         batch: 2 when its largest frame has 4 MiB and more and four times the mean size, else 1)                                                    */
+    ZARC_GPU_PX_ZERO_COPY = 9006     /* host-pointer entry points: when every buffer of a chunk is page-locked memory the device can reach (hipHostMalloc /
+                                        hipHostRegister by the caller, same HIP runtime) AND the buffers form runs -- contiguous in the caller's memory and in
+                                        batch order -- of at least this many KiB on average, the DMA engines move them directly and the staging ring with its
+                                        host memcpy pass is skipped.  Default 4096 (a DMA per small scattered buffer is slower than the ring); 0 = always stage.
+                                        Ordinary (pageable) buffers are staged either way. */
 };
 /* What the engine does with the libzstd ids (pack.rs:86-217 forwards them all):
- *   CompressionLevel  -131072..22 accepted.  Levels <= 8 run the level-3 finder (LDS tables of 2^13 entries on an 8-byte and a
- *                     5-byte hash, a 2^16-bucket far table in HBM, one-byte lazy evaluation from level 2 on); levels >= 9 run the
- *                     deep finder (2^14-entry LDS tables, 4-byte short hash, 2-way far tables on both hashes).
+ *   CompressionLevel  -131072..22 accepted.  Levels <= 8 run the level-3 finder (one LDS table of 2^15 16-bit entries on a 5-byte
+ *                     hash, candidates up to 64 KiB back; a 2^16-bucket far table in HBM on a 12-byte hash, content-sampled one
+ *                     position in 16; one-byte lazy evaluation from level 2 on); levels >= 9 run the deep finder (2^14-entry LDS
+ *                     tables, 4-byte short hash, 2-way far tables on both hashes).  Levels 10..22 are NOT stronger than 9 and
+ *                     negative levels are NOT faster than 1: there are exactly these two finders.
  *   WindowLog         honoured for the frame header / the farthest offset (10..27; default 21, level >= 9: 22).
  *   MinMatch          4..7 honoured (3 is raised to 4); default 5, level >= 9: 4.
  *   HashLog, ChainLog, SearchLog, TargetLength, Strategy
- *                     ZARC_GPU_E_UNSUPPORTED for any value but 0 (= default): table sizes and the search are fixed by the kernels.
+ *                     accepted inside libzstd's bounds (6..30, 6..30, 1..30, 0..131072, 1..9; 0 = default), returned by
+ *                     zarc_gpu_get_params, and ADVISORY: table sizes and the search are fixed by the kernels, so the frames are the
+ *                     level's frames whatever these say (libzstd would search harder or less hard; the frames are valid either way).
  *   ContentSizeFlag   only 1.  ChecksumFlag honoured.  DictIdFlag accepted (zarc has no dictionaries).
  *   LDM (160-164), NbWorkers / JobSize / OverlapLog (400-402), experimental ids: ZARC_GPU_E_UNSUPPORTED. */
 
@@ -145,6 +156,22 @@ int zarc_gpu_pack_batch(zarc_gpu_t *h, size_t n, const void *const *src, const s
 int zarc_gpu_pack_batch_device(zarc_gpu_t *h, size_t n, const void *d_src_base, const uint64_t *src_off,
                                const uint64_t *src_len, void *d_dst, size_t dst_cap, uint64_t *dst_off,
                                uint64_t *dst_len, uint8_t *digest /* n*32 */, int *status);
+
+/* Hash first, like the reference (content_frame.rs:26-33 hashes, looks the digest up and returns before compressing known content):
+ * every entry is digested, then `known(ctx, digest, i)` is called once per entry in index order on the calling thread; a nonzero
+ * return skips the entry (status[i] = ZARC_GPU_FRAME_DUPLICATE, dst_len[i] = 0, digest[i] set, nothing compressed).  A callback that
+ * returns 0 should remember the digest so that a later copy inside the same batch is skipped too: first occurrence wins.  known == NULL
+ * is zarc_gpu_pack_batch.  dst_off[i] is meaningful for compressed entries only.  The digest pass costs about 0.5 ms per GiB where
+ * the match finder costs 20: on content that repeats (the reference's own benchmark tree is half duplicates) the saving is the
+ * duplicates' whole share. */
+typedef int (*zarc_gpu_known_fn)(void *ctx, const uint8_t digest[ZARC_GPU_DIGEST_LEN], size_t index);
+int zarc_gpu_pack_batch_dedup(zarc_gpu_t *h, size_t n, const void *const *src, const size_t *src_len,
+                              void *dst, size_t dst_cap, size_t *dst_off, size_t *dst_len,
+                              uint8_t (*digest)[ZARC_GPU_DIGEST_LEN], int *status, zarc_gpu_known_fn known, void *ctx);
+int zarc_gpu_pack_batch_device_dedup(zarc_gpu_t *h, size_t n, const void *d_src_base, const uint64_t *src_off,
+                                     const uint64_t *src_len, void *d_dst, size_t dst_cap, uint64_t *dst_off,
+                                     uint64_t *dst_len, uint8_t *digest /* n*32 */, int *status,
+                                     zarc_gpu_known_fn known, void *ctx);
 
 /* ---- unpack: Zstandard frame decode (+ XXH64 verify) + BLAKE3 verify --------------------------- */
 /* frame[i]/frame_len[i] = Frame.offset/.length slice of the archive, raw_len[i] = Frame.uncompressed

@@ -82,6 +82,19 @@ hipError_t hipHostMalloc(void **p, size_t n, unsigned flags = 0);
 hipError_t hipHostFree(void *p);
 static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { if (n) memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t = 0) { if (n) memcpy(d, s, n); return hipSuccess; }
+// pointer attributes: the emulator has one kind of memory.  HIPEMU_ALL_PINNED=1 reports every address as page-locked host memory, so
+// that the engine's zero-copy path for pinned caller buffers runs in the CPU tests; otherwise every query fails as for ordinary memory.
+enum hipMemoryType { hipMemoryTypeHost = 1, hipMemoryTypeDevice = 2 };
+struct hipPointerAttribute_t { hipMemoryType type; int device; void *devicePointer; void *hostPointer; int isManaged; unsigned allocationFlags; };
+static inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t *a, const void *p)
+{
+    const char *e = getenv("HIPEMU_ALL_PINNED");
+    if (!(e && atoi(e) > 0)) return hipErrorInvalidValue;
+    memset(a, 0, sizeof *a);
+    a->type = hipMemoryTypeHost;
+    a->hostPointer = (void *)p;
+    return hipSuccess;
+}
 static inline hipError_t hipMemset(void *d, int v, size_t n) { if (n) memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t = 0) { if (n) memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipStreamCreate(hipStream_t *s) { *s = 0; return hipSuccess; }

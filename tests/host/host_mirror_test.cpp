@@ -105,6 +105,14 @@ int main(int argc, char **argv)
         uint64_t e1 = 0, e2 = 0, e3 = 0;
         const size_t f1 = run({0}, &one, &d1, &e1), f2 = run({0, 0}, &two, &d2, &e2);
         CHECK(f1 == 8 && f2 == 8 && one == two && d1 == d2 && e1 == e2 && e1 == one.size());
+        { // hash-first dedup (the default) against compress-everything-and-drop-later: the same archive (content_frame.rs:26-33)
+            std::ostringstream f3;
+            zarc::Encoder e3x(f3, std::vector<int>{0});
+            e3x.set_hash_first(false);
+            e3x.set_zstd_parameter(ZARC_GPU_P_CHECKSUM_FLAG, 1);
+            d3 = e3x.add_data_frames(p2.data(), l2.data(), p2.size());
+            CHECK(f3.str() == one && d3 == d1 && e3x.frames().size() == 8);
+        }
         const auto share = zarc::shard_assign(l2.data(), l2.size(), 2);
         CHECK(share[0].size() + share[1].size() == 11);
         // equal sizes: index mod G

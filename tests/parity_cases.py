@@ -189,11 +189,16 @@ def check_params(engine):
         engine.set_parameter(_lib.P_COMPRESSION_LEVEL, 23)
     with pytest.raises(ZarcGpuError):
         engine.set_parameter(400, 4)      # NbWorkers: known to libzstd, unsupported here
-    for pid in (_lib.P_HASH_LOG, _lib.P_CHAIN_LOG, _lib.P_SEARCH_LOG, _lib.P_TARGET_LENGTH, _lib.P_STRATEGY):
-        engine.set_parameter(pid, 0)      # "use the default" is the one value the fixed-size kernels can honour
+    # search-effort hints: accepted inside libzstd's bounds and remembered (the reference forwards them all, pack.rs:86-217), advisory
+    for pid, good, bad, field in ((_lib.P_HASH_LOG, 20, 31, "hash_log"), (_lib.P_CHAIN_LOG, 16, 5, "chain_log"), (_lib.P_SEARCH_LOG, 4, 31, "search_log"),
+                                  (_lib.P_TARGET_LENGTH, 64, 131073, "target_length"), (_lib.P_STRATEGY, 7, 10, "strategy")):
+        engine.set_parameter(pid, good)
+        assert getattr(engine.params(), field) == good
         with pytest.raises(ZarcGpuError) as ei:
-            engine.set_parameter(pid, 7)
-        assert ei.value.code == _lib.E_UNSUPPORTED
+            engine.set_parameter(pid, bad)
+        assert ei.value.code == _lib.E_PARAM
+        engine.set_parameter(pid, 0)      # back to "use the default"
+        assert getattr(engine.params(), field) == 0
     with pytest.raises(ZarcGpuError):
         engine.set_parameter(31337, 1)    # unknown id
     assert engine.params().checksum_flag == 1

@@ -154,3 +154,50 @@ def test_emu_frame_pass_in_pieces(emu_engine, oracle, corpus, libzstd15):
     bad = bytearray(frames[0]); bad[len(bad) // 2] ^= 0x55
     res = emu_engine.unpack([bytes(bad), frames[1]], [len(text), len(rnd)], [oracle.blake3(text), oracle.blake3(rnd)])
     assert res[0][2] != _lib.FRAME_OK and res[1][2] == _lib.FRAME_OK and res[1][0] == rnd
+
+
+def test_emu_zero_copy_for_pinned_caller_memory(emu_lib_path, oracle, corpus, golden_frames, monkeypatch):
+    """Host-pointer entry points with page-locked caller buffers (engine.hip: segs_pinned / direct_copy): the staging ring is skipped,
+    the DMA copies run straight between the caller's memory and the device arenas.  The emulator reports every address as pinned
+    when HIPEMU_ALL_PINNED=1; results must equal the staged path's, in one chunk and in many, and ZARC_GPU_PX_ZERO_COPY=0 switches
+    the path off."""
+    from zarc_amd import Engine
+    monkeypatch.setenv("HIPEMU_ALL_PINNED", "1")
+    e = Engine(0, emu_lib_path)
+    e.set_parameter(_lib.P_CHECKSUM_FLAG, 1)
+    e.set_parameter(_lib.PX_ZERO_COPY, 1)      # runs of 1 KiB and more go direct (default: 4 MiB, more than the emulator's test entries)
+    try:
+        pc.check_roundtrip(e, oracle, corpus, big=False)
+        e.set_parameter(_lib.PX_STAGE_CHUNK, 30000)
+        pc.check_roundtrip(e, oracle, corpus, big=False)
+        pc.check_unpack_errors(e, oracle, corpus, golden_frames)
+        ents = [corpus.entry(60 + i, 20000 + 3000 * i, -1) for i in range(6)] + [b""]
+        direct = e.pack(ents)
+        e.set_parameter(_lib.PX_ZERO_COPY, 0)
+        assert e.pack(ents) == direct
+    finally:
+        e.close()
+
+
+def test_emu_hash_first_dedup(emu_engine, oracle, corpus):
+    """zarc_gpu_pack_batch_dedup (content_frame.rs:26-33: hash, look the digest up, compress only new content): the callback is asked
+    once per entry in index order; known content and later copies inside the batch come back as FRAME_DUPLICATE with no frame; the
+    frames of what IS compressed equal the plain pack's; across calls the caller's set carries on.  Also through many staged chunks."""
+    a, b, c = corpus.entry(80, 30000, 0), corpus.entry(81, 70000, 1), corpus.entry(82, 5000, 2)
+    ents = [a, b, a, c, b, b"", a, b""]
+    plain = emu_engine.pack(ents)
+    for chunk in (0, 20000):
+        emu_engine.set_parameter(_lib.PX_STAGE_CHUNK, chunk)
+        try:
+            seen = set()
+            res = emu_engine.pack_dedup(ents, seen)
+            assert [r[2] for r in res] == [0, 0, _lib.FRAME_DUPLICATE, 0, _lib.FRAME_DUPLICATE, 0, _lib.FRAME_DUPLICATE, _lib.FRAME_DUPLICATE]
+            for (frame, dig, st), (pf, pd), raw in zip(res, plain, ents):
+                assert dig == pd == oracle.blake3(raw)
+                assert frame == (pf if st == 0 else None)
+            assert seen == {oracle.blake3(x) for x in (a, b, c, b"")}
+            again = emu_engine.pack_dedup([c, corpus.entry(83, 100, 0)], seen)          # the set carries over to the next call
+            assert again[0][2] == _lib.FRAME_DUPLICATE and again[1][2] == 0 and again[1][0] == oracle.zge_encode(corpus.entry(83, 100, 0))
+            assert emu_engine.pack_dedup([a, a], {oracle.blake3(a)}) == [(None, oracle.blake3(a), _lib.FRAME_DUPLICATE)] * 2   # nothing to compress at all
+        finally:
+            emu_engine.set_parameter(_lib.PX_STAGE_CHUNK, 0)

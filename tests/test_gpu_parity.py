@@ -360,3 +360,87 @@ def test_gpu_lds_same_address_stores_keep_the_highest_lane(tmp_path):
     assert m, out
     n, hi16, lo16, ot16, hi32, lo32, ot32 = map(int, m.groups())
     assert n > 100000 and hi16 == n and hi32 == n and lo16 == ot16 == lo32 == ot32 == 0, out
+
+
+def test_gpu_hash_first_dedup_halves_the_work(engine, oracle, corpus):
+    """A device-resident batch whose second half repeats its first (the reference's own benchmark tree is half duplicates,
+    README.md:350-388): hash-first packing (zarc_gpu_pack_batch_device_dedup) compresses only the first copies -- frames identical to the
+    plain pack's, duplicates reported as FRAME_DUPLICATE -- and takes clearly less time than packing everything."""
+    import time
+    n, size = 1024, 1 << 20
+    lens = np.full(2 * n, size, dtype=np.uint64)
+    off = np.arange(2 * n, dtype=np.uint64) * np.uint64(size)
+    bound = int(engine.bound(size))
+    d_src, d_dst = engine.malloc(2 * n * size + _lib.PAD), engine.malloc(2 * n * bound + _lib.PAD)
+    try:
+        engine.corpus_fill(d_src, off[:n], lens[:n], first_index=9000, kind=-1)
+        engine.corpus_fill(d_src + n * size, off[:n], lens[:n], first_index=9000, kind=-1)       # the same n entries again
+        engine.pack_device(d_src, off, lens, d_dst, 2 * n * bound)                                 # warm-up (scratch allocation)
+        t0 = time.perf_counter()
+        doff, dlen, dig, st = engine.pack_device(d_src, off, lens, d_dst, 2 * n * bound)
+        t_all = time.perf_counter() - t0
+        frames_all = [bytes(engine.d2h(d_dst + int(doff[i]), int(dlen[i]))) for i in (0, 1, n - 1)]
+        t0 = time.perf_counter()
+        doff2, dlen2, dig2, st2 = engine.pack_device_dedup(d_src, off, lens, d_dst, 2 * n * bound, set())
+        t_dedup = time.perf_counter() - t0
+        assert (dig2 == dig).all() and (dig[:n] == dig[n:]).all()
+        assert (st2[:n] == 0).all() and (st2[n:] == _lib.FRAME_DUPLICATE).all() and (dlen2[n:] == 0).all() and (dlen2[:n] == dlen[:n]).all()
+        assert [bytes(engine.d2h(d_dst + int(doff2[i]), int(dlen2[i]))) for i in (0, 1, n - 1)] == frames_all
+        print("hash-first dedup: %d x 1 MiB, half duplicates: %.1f ms against %.1f ms for packing everything (%.0f %%)" % (2 * n, t_dedup * 1e3, t_all * 1e3, 100 * t_dedup / t_all))
+        assert t_dedup < 0.7 * t_all
+    finally:
+        engine.free(d_src)
+        engine.free(d_dst)
+
+
+def test_gpu_zero_copy_for_pinned_caller_memory(engine, oracle, corpus):
+    """Page-locked caller buffers that are contiguous are moved by the DMA engines directly (engine.hip: segs_pinned / direct_copy),
+    ordinary ones through the staging ring: same frames, same bytes back, and the pinned path is not slower.  The buffers come from
+    hipHostMalloc of the HIP runtime the engine itself uses (not torch's: two runtimes in one process do not know each other's memory)."""
+    import ctypes
+    import time
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipHostMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t, ctypes.c_uint]
+    hip.hipHostFree.argtypes = [ctypes.c_void_p]
+    n, size = 512, 1 << 20
+    raw = b"".join(corpus.entry(9500 + i, size, -1) for i in range(8)) * (n // 8)
+    cap = int(engine.bound(size)) * n
+    res = {}
+    for mode in ("pageable", "pinned"):
+        bufs = []
+        for nbytes in (n * size, cap, n * size):
+            if mode == "pinned":
+                p = ctypes.c_void_p()
+                assert hip.hipHostMalloc(ctypes.byref(p), nbytes, 0) == 0
+                bufs.append(p.value)
+            else:
+                b = ctypes.create_string_buffer(nbytes)
+                bufs.append(b)
+        addr = [b if isinstance(b, int) else ctypes.addressof(b) for b in bufs]
+        src, dst, back = addr
+        ctypes.memmove(src, raw, n * size)
+        ptrs = (ctypes.c_void_p * n)(*[src + i * size for i in range(n)])
+        ln = (ctypes.c_size_t * n)(*[size] * n)
+        doff, dlen = (ctypes.c_size_t * n)(), (ctypes.c_size_t * n)()
+        dig, dig2 = np.zeros((n, 32), dtype=np.uint8), np.zeros((n, 32), dtype=np.uint8)
+        st = (ctypes.c_int * n)()
+        best = [1e9, 1e9]
+        for _ in range(2):
+            t0 = time.perf_counter()
+            engine._check(engine.lib.zarc_gpu_pack_batch(engine.h, n, ptrs, ln, ctypes.c_void_p(dst), cap, doff, dlen, dig.ctypes.data_as(ctypes.c_void_p), st))
+            t1 = time.perf_counter()
+            fptrs = (ctypes.c_void_p * n)(*[dst + doff[i] for i in range(n)])
+            flens = (ctypes.c_size_t * n)(*[dlen[i] for i in range(n)])
+            optrs = (ctypes.c_void_p * n)(*[back + i * size for i in range(n)])
+            t2 = time.perf_counter()
+            engine._check(engine.lib.zarc_gpu_unpack_batch(engine.h, n, fptrs, flens, ln, optrs, dig.ctypes.data_as(ctypes.c_void_p), dig2.ctypes.data_as(ctypes.c_void_p), st))
+            t3 = time.perf_counter()
+            best = [min(best[0], t1 - t0), min(best[1], t3 - t2)]
+        assert all(s == 0 for s in st) and (dig == dig2).all() and ctypes.string_at(back, n * size) == raw
+        res[mode] = (best, [ctypes.string_at(dst + doff[i], dlen[i]) for i in (0, 7, n - 1)], dig.copy())
+        if mode == "pinned":
+            for a_ in addr:
+                hip.hipHostFree(ctypes.c_void_p(a_))
+    assert res["pinned"][1] == res["pageable"][1] and (res["pinned"][2] == res["pageable"][2]).all()
+    print("host path, %d x 1 MiB: pageable pack %.1f / unpack %.1f ms, pinned %.1f / %.1f ms" % (n, res["pageable"][0][0] * 1e3, res["pageable"][0][1] * 1e3, res["pinned"][0][0] * 1e3, res["pinned"][0][1] * 1e3))
+    assert res["pinned"][0][0] < 1.15 * res["pageable"][0][0] and res["pinned"][0][1] < 1.15 * res["pageable"][0][1]

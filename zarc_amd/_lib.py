@@ -17,22 +17,26 @@ PAD = 64
 # call-level errors
 OK, E_DEVICE, E_NOMEM, E_PARAM, E_UNSUPPORTED, E_DSTSIZE = 0, -1, -2, -3, -4, -5
 # per-frame status
-FRAME_OK, FRAME_CORRUPT, FRAME_CHECKSUM, FRAME_DIGEST, FRAME_DSTSIZE, FRAME_BAD_MAGIC, FRAME_UNSUPPORTED, FRAME_SRCSIZE = range(8)
+FRAME_OK, FRAME_CORRUPT, FRAME_CHECKSUM, FRAME_DIGEST, FRAME_DSTSIZE, FRAME_BAD_MAGIC, FRAME_UNSUPPORTED, FRAME_SRCSIZE, FRAME_DUPLICATE = range(9)
 # parameter ids (ZSTD_cParameter values, what zstd_safe::CParameter maps to)
 P_COMPRESSION_LEVEL, P_WINDOW_LOG, P_HASH_LOG, P_CHAIN_LOG, P_SEARCH_LOG, P_MIN_MATCH, P_TARGET_LENGTH, P_STRATEGY = 100, 101, 102, 103, 104, 105, 106, 107
 P_CONTENT_SIZE_FLAG, P_CHECKSUM_FLAG, P_DICT_ID_FLAG = 200, 201, 202
 # engine tuning (batching only; frames are identical for every value)
-PX_SCRATCH_MB, PX_STAGE_CHUNK, PX_STAGE_THREAD, PX_COPY_THREADS, PX_DEC_GROUPS = 9001, 9002, 9003, 9004, 9005
+PX_SCRATCH_MB, PX_STAGE_CHUNK, PX_STAGE_THREAD, PX_COPY_THREADS, PX_DEC_GROUPS, PX_ZERO_COPY = 9001, 9002, 9003, 9004, 9005, 9006
 # timers
 T_BLAKE3, T_XXH64, T_MATCH, T_ENTROPY, T_ASSEMBLE, T_DECODE, T_TOTAL, T_DEC_SEQS, T_DEC_LITS, T_DEC_FRAMES = range(10)
 
 EXPORTS = [
     "zarc_gpu_abi_version", "zarc_gpu_device_count", "zarc_gpu_create", "zarc_gpu_destroy", "zarc_gpu_set_parameter", "zarc_gpu_get_params",
     "zarc_gpu_enable_compression", "zarc_gpu_bound", "zarc_gpu_error_name", "zarc_gpu_frame_status_name", "zarc_gpu_last_error",
-    "zarc_gpu_pack_batch", "zarc_gpu_pack_batch_device", "zarc_gpu_unpack_batch", "zarc_gpu_unpack_batch_device",
+    "zarc_gpu_pack_batch", "zarc_gpu_pack_batch_device", "zarc_gpu_pack_batch_dedup", "zarc_gpu_pack_batch_device_dedup", "zarc_gpu_unpack_batch", "zarc_gpu_unpack_batch_device",
     "zarc_gpu_blake3_batch", "zarc_gpu_blake3_batch_device", "zarc_gpu_xxh64_batch_device", "zarc_gpu_last_kernel_ms",
     "zarc_gpu_corpus_fill_device", "zarc_gpu_device_malloc", "zarc_gpu_device_free", "zarc_gpu_memcpy_h2d", "zarc_gpu_memcpy_d2h",
 ]
+
+
+# int known(void *ctx, const uint8_t digest[32], size_t index): nonzero = the caller has this content already (hash-first dedup)
+KNOWN_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint8), ctypes.c_size_t)
 
 
 class Params(ctypes.Structure):
@@ -75,6 +79,8 @@ def load(path=None):
     lib.zarc_gpu_last_error.restype = c.c_char_p
     lib.zarc_gpu_pack_batch.argtypes = [vp, sz, vpp, szp, vp, sz, szp, szp, vp, ip]
     lib.zarc_gpu_pack_batch_device.argtypes = [vp, sz, vp, u64p, u64p, vp, sz, u64p, u64p, vp, ip]
+    lib.zarc_gpu_pack_batch_dedup.argtypes = [vp, sz, vpp, szp, vp, sz, szp, szp, vp, ip, KNOWN_FN, vp]
+    lib.zarc_gpu_pack_batch_device_dedup.argtypes = [vp, sz, vp, u64p, u64p, vp, sz, u64p, u64p, vp, ip, KNOWN_FN, vp]
     lib.zarc_gpu_unpack_batch.argtypes = [vp, sz, vpp, szp, szp, vpp, vp, vp, ip]
     lib.zarc_gpu_unpack_batch_device.argtypes = [vp, sz, vp, u64p, u64p, vp, u64p, u64p, vp, vp, ip]
     lib.zarc_gpu_blake3_batch.argtypes = [vp, sz, vpp, szp, vp]

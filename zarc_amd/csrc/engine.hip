@@ -87,6 +87,7 @@ struct zarc_gpu {
     uint64_t stage_chunk = 0;  // 0 = default per entry point (ZARC_GPU_PX_STAGE_CHUNK)
     int stage_thread = 1;      // ZARC_GPU_PX_STAGE_THREAD
     int copy_threads = 8;      // ZARC_GPU_PX_COPY_THREADS
+    int zero_copy = 4096;      // ZARC_GPU_PX_ZERO_COPY: page-locked caller memory in runs of this many KiB on average is read / written by the DMA engines directly (0 = never)
 };
 
 namespace {
@@ -324,9 +325,14 @@ int zarc_gpu_set_parameter(zarc_gpu_t *h, int id, int value)
     case ZARC_GPU_P_WINDOW_LOG:
         if (value != 0 && (value < 10 || value > 27)) return ZARC_GPU_E_PARAM;
         h->params.window_log = value; return ZARC_GPU_OK;
-    case ZARC_GPU_P_HASH_LOG: case ZARC_GPU_P_CHAIN_LOG: case ZARC_GPU_P_SEARCH_LOG: case ZARC_GPU_P_TARGET_LENGTH: case ZARC_GPU_P_STRATEGY:
-        // table sizes, search depth and strategy are fixed by the kernels: 0 (= libzstd's "use the default") is the only value taken
-        return value == 0 ? ZARC_GPU_OK : ZARC_GPU_E_UNSUPPORTED;
+    // Search-effort hints: libzstd accepts them inside its bounds and the reference forwards whatever the user gives (pack.rs:86-217), so
+    // `zarc pack --zstd Strategy=btopt` has to work.  They are range-checked as libzstd does (ZSTD_cParam_getBounds), remembered (get_params
+    // returns them) and ADVISORY: table sizes, search depth and strategy are fixed by the kernels, the frames are the level's frames.
+    case ZARC_GPU_P_HASH_LOG: if (value != 0 && (value < 6 || value > 30)) return ZARC_GPU_E_PARAM; h->params.hash_log = value; return ZARC_GPU_OK;
+    case ZARC_GPU_P_CHAIN_LOG: if (value != 0 && (value < 6 || value > 30)) return ZARC_GPU_E_PARAM; h->params.chain_log = value; return ZARC_GPU_OK;
+    case ZARC_GPU_P_SEARCH_LOG: if (value != 0 && (value < 1 || value > 30)) return ZARC_GPU_E_PARAM; h->params.search_log = value; return ZARC_GPU_OK;
+    case ZARC_GPU_P_TARGET_LENGTH: if (value < 0 || value > 131072) return ZARC_GPU_E_PARAM; h->params.target_length = value; return ZARC_GPU_OK;
+    case ZARC_GPU_P_STRATEGY: if (value < 0 || value > 9) return ZARC_GPU_E_PARAM; h->params.strategy = value; return ZARC_GPU_OK;
     case ZARC_GPU_P_MIN_MATCH:
         if (value != 0 && (value < 3 || value > 7)) return ZARC_GPU_E_PARAM;
         h->params.min_match = value; return ZARC_GPU_OK;
@@ -343,6 +349,7 @@ int zarc_gpu_set_parameter(zarc_gpu_t *h, int id, int value)
     case ZARC_GPU_PX_DEC_GROUPS:
         if (value < 0 || value > zarc_gpu::DEC_GROUPS) return ZARC_GPU_E_PARAM;
         h->dec_groups = value; return ZARC_GPU_OK;
+    case ZARC_GPU_PX_ZERO_COPY: if (value < 0 || value > (1 << 20)) return ZARC_GPU_E_PARAM; h->zero_copy = value; return ZARC_GPU_OK;
     case ZARC_GPU_P_CONTENT_SIZE_FLAG:
         if (value != 1) return ZARC_GPU_E_UNSUPPORTED; // frames always carry their content size
         return ZARC_GPU_OK;
@@ -388,6 +395,7 @@ const char *zarc_gpu_frame_status_name(int s)
     case ZARC_GPU_FRAME_BAD_MAGIC: return "Unknown frame descriptor";
     case ZARC_GPU_FRAME_UNSUPPORTED: return "Unsupported frame parameter";
     case ZARC_GPU_FRAME_SRCSIZE: return "Src size is incorrect";
+    case ZARC_GPU_FRAME_DUPLICATE: return "frame already exists, skipping";
     default: return "Unspecified error code";
     }
 }
@@ -435,13 +443,16 @@ int zarc_gpu_xxh64_batch_device(zarc_gpu_t *h, size_t n, const void *d_base, con
     return ZARC_GPU_OK;
 }
 
-int zarc_gpu_pack_batch_device(zarc_gpu_t *h, size_t n, const void *d_src_base, const uint64_t *src_off, const uint64_t *src_len, void *d_dst,
-                               size_t dst_cap, uint64_t *dst_off, uint64_t *dst_len, uint8_t *digest, int *status)
+} // extern "C"
+namespace {
+// have_digests: the caller has hashed the entries already (hash-first dedup): no digest kernels, `digest` is not written
+int pack_device_impl(zarc_gpu_t *h, size_t n, const void *d_src_base, const uint64_t *src_off, const uint64_t *src_len, void *d_dst,
+                     size_t dst_cap, uint64_t *dst_off, uint64_t *dst_len, uint8_t *digest, int *status, bool have_digests)
 {
     int rc = check_common(h, n);
     if (rc) return rc;
     if (n == 0) return ZARC_GPU_OK;
-    if (!d_src_base || !src_off || !src_len || !d_dst || !dst_off || !dst_len || !digest) return ZARC_GPU_E_PARAM;
+    if (!d_src_base || !src_off || !src_len || !d_dst || !dst_off || !dst_len || (!digest && !have_digests)) return ZARC_GPU_E_PARAM;
     const ZgeParams P = derive_params(h->params);
     // the match finder has these compiled in (zge_match.hip: F_*)
     if (P.rep_back != 256 || P.back_cap != 8 || P.lazy_delta != 5 || P.min_rep != 3 || P.rep_search != 2 || P.seg_log != 21 || P.short_window_log < 30 ||
@@ -478,9 +489,9 @@ int zarc_gpu_pack_batch_device(zarc_gpu_t *h, size_t n, const void *d_src_base, 
     }
     // the digest: in store mode right here; otherwise its kernels are queued on the low-priority side stream right behind the first
     // match-finder launch (below), fill the tail of that launch and are joined before the digests travel back
-    if ((rc = run_blake3(h, n, base, src_off, src_len, d_off, d_len, /*prepare_only=*/h->params.compress != 0))) return rc;
+    if (!have_digests && (rc = run_blake3(h, n, base, src_off, src_len, d_off, d_len, /*prepare_only=*/h->params.compress != 0))) return rc;
     ZHIP(t.mark(&e1));
-    bool digest_queued = false;
+    bool digest_queued = have_digests; // nothing to queue
     if (!h->params.compress) {
         // store mode (Encoder::enable_compression(false)): raw-block frames, no checksum (lowlevel_frames.rs:47-84)
         hipLaunchKernelGGL(zarc_zge_store, dim3((unsigned)n), dim3(256), 0, h->stream, base, d_off, d_len, (uint32_t)n, (uint8_t *)d_dst,
@@ -488,7 +499,7 @@ int zarc_gpu_pack_batch_device(zarc_gpu_t *h, size_t n, const void *d_src_base, 
         ZHIP(hipGetLastError());
         ZHIP(t.mark(&e2));
         ZHIP(hipMemcpyAsync(dst_len, h->d_dst_len.p, n * 8, hipMemcpyDeviceToHost, h->stream));
-        ZHIP(hipMemcpyAsync(digest, h->d_digests.p, n * 32, hipMemcpyDeviceToHost, h->stream));
+        if (!have_digests) ZHIP(hipMemcpyAsync(digest, h->d_digests.p, n * 32, hipMemcpyDeviceToHost, h->stream));
         ZHIP(hipStreamSynchronize(h->stream));
         if (status) for (size_t i = 0; i < n; i++) status[i] = ZARC_GPU_FRAME_OK;
         h->ms[ZARC_GPU_T_BLAKE3] = elapsed(h, e0, e1);
@@ -572,7 +583,7 @@ int zarc_gpu_pack_batch_device(zarc_gpu_t *h, size_t n, const void *d_src_base, 
         // match launch: measured on the configs[4] shape, a second launch that found the last 4 ms of them still running took 326 ms
         // instead of 209 (kernel trace in gpurun_out/trace_dpp.txt) -- the persistent workgroups keep whatever uneven placement the
         // launch moment gave them.
-        if (digest_queued) ZHIP(hipStreamWaitEvent(h->stream, h->ev_join3, 0));
+        if (digest_queued && !have_digests) ZHIP(hipStreamWaitEvent(h->stream, h->ev_join3, 0));
         auto match_kernel = deep ? zarc_zge_match_deep : zarc_zge_match;
 #ifdef ZARC_GPU_DIAG
         if (!deep && P.dbg) match_kernel = zarc_zge_match_diag;
@@ -623,18 +634,65 @@ int zarc_gpu_pack_batch_device(zarc_gpu_t *h, size_t n, const void *d_src_base, 
         t.next = 3;
         start = end;
     }
-    ZHIP(hipStreamWaitEvent(h->stream, h->ev_join3, 0)); // the digests are done
+    if (!have_digests) ZHIP(hipStreamWaitEvent(h->stream, h->ev_join3, 0)); // the digests are done
     ZHIP(hipMemcpyAsync(dst_len, h->d_dst_len.p, n * 8, hipMemcpyDeviceToHost, h->stream));
-    ZHIP(hipMemcpyAsync(digest, h->d_digests.p, n * 32, hipMemcpyDeviceToHost, h->stream));
+    if (!have_digests) ZHIP(hipMemcpyAsync(digest, h->d_digests.p, n * 32, hipMemcpyDeviceToHost, h->stream));
     ZHIP(hipStreamSynchronize(h->stream));
     if (status) for (size_t i = 0; i < n; i++) status[i] = ZARC_GPU_FRAME_OK;
-    { float ms = -1.f; if (hipEventElapsedTime(&ms, h->ev_b3[0], h->ev_b3[1]) == hipSuccess) h->ms[ZARC_GPU_T_BLAKE3] = ms; } // side stream: queue wait + kernels
+    if (have_digests) h->ms[ZARC_GPU_T_BLAKE3] = 0;
+    else { float ms = -1.f; if (hipEventElapsedTime(&ms, h->ev_b3[0], h->ev_b3[1]) == hipSuccess) h->ms[ZARC_GPU_T_BLAKE3] = ms; } // side stream: queue wait + kernels
     h->ms[ZARC_GPU_T_XXH64] = elapsed(h, 14, 15); // side stream: overlaps the match finder, not part of the total
     h->ms[ZARC_GPU_T_MATCH] = ms_match;
     h->ms[ZARC_GPU_T_ENTROPY] = ms_ent;
     h->ms[ZARC_GPU_T_ASSEMBLE] = ms_asm;
     h->ms[ZARC_GPU_T_TOTAL] = elapsed(h, e0, e1) + ms_match + ms_ent + ms_asm; // the digest and the checksum run beside these
     return ZARC_GPU_OK;
+}
+
+// Hash first (content_frame.rs:26-33): digest every entry, ask the caller which digests it has a frame for already, compress the rest.
+// `known(ctx, digest, i)` is called once per entry in index order on the calling thread; nonzero = skip this entry
+// (status ZARC_GPU_FRAME_DUPLICATE, dst_len 0).  A caller that returns 0 is expected to remember the digest, so that a later copy
+// inside the same batch is skipped as well (first occurrence wins).
+int pack_device_dedup_impl(zarc_gpu_t *h, size_t n, const void *d_src_base, const uint64_t *src_off, const uint64_t *src_len, void *d_dst,
+                           size_t dst_cap, uint64_t *dst_off, uint64_t *dst_len, uint8_t *digest, int *status, zarc_gpu_known_fn known, void *ctx)
+{
+    if (!known) return pack_device_impl(h, n, d_src_base, src_off, src_len, d_dst, dst_cap, dst_off, dst_len, digest, status, false);
+    if (!status) return ZARC_GPU_E_PARAM;
+    int rc = zarc_gpu_blake3_batch_device(h, n, d_src_base, src_off, src_len, digest);
+    if (rc) return rc;
+    const float ms_b3 = h->ms[ZARC_GPU_T_BLAKE3];
+    std::vector<size_t> keep;
+    for (size_t i = 0; i < n; i++) {
+        dst_off[i] = 0; dst_len[i] = 0;
+        if (known(ctx, digest + i * 32, i)) status[i] = ZARC_GPU_FRAME_DUPLICATE;
+        else keep.push_back(i);
+    }
+    if (keep.empty()) { for (int t = 0; t < ZARC_GPU_T_COUNT; t++) if (t != ZARC_GPU_T_BLAKE3 && t != ZARC_GPU_T_TOTAL) h->ms[t] = 0; return ZARC_GPU_OK; }
+    const size_t m = keep.size();
+    std::vector<uint64_t> off(m), len(m), doff(m), dlen(m);
+    std::vector<int> st(m);
+    for (size_t j = 0; j < m; j++) { off[j] = src_off[keep[j]]; len[j] = src_len[keep[j]]; }
+    rc = pack_device_impl(h, m, d_src_base, off.data(), len.data(), d_dst, dst_cap, doff.data(), dlen.data(), nullptr, st.data(), true);
+    if (rc) return rc;
+    for (size_t j = 0; j < m; j++) { dst_off[keep[j]] = doff[j]; dst_len[keep[j]] = dlen[j]; status[keep[j]] = st[j]; }
+    h->ms[ZARC_GPU_T_BLAKE3] = ms_b3;
+    h->ms[ZARC_GPU_T_TOTAL] += ms_b3;
+    return ZARC_GPU_OK;
+}
+} // namespace
+extern "C" {
+
+int zarc_gpu_pack_batch_device(zarc_gpu_t *h, size_t n, const void *d_src_base, const uint64_t *src_off, const uint64_t *src_len, void *d_dst,
+                               size_t dst_cap, uint64_t *dst_off, uint64_t *dst_len, uint8_t *digest, int *status)
+{
+    return pack_device_impl(h, n, d_src_base, src_off, src_len, d_dst, dst_cap, dst_off, dst_len, digest, status, false);
+}
+
+int zarc_gpu_pack_batch_device_dedup(zarc_gpu_t *h, size_t n, const void *d_src_base, const uint64_t *src_off, const uint64_t *src_len, void *d_dst,
+                                     size_t dst_cap, uint64_t *dst_off, uint64_t *dst_len, uint8_t *digest, int *status, zarc_gpu_known_fn known, void *ctx)
+{
+    if (n && (!digest || !dst_off || !dst_len)) return ZARC_GPU_E_PARAM;
+    return pack_device_dedup_impl(h, n, d_src_base, src_off, src_len, d_dst, dst_cap, dst_off, dst_len, digest, status, known, ctx);
 }
 
 // The decoder's stages (sequences + literals ahead, frame pass, checksum + digest) of ONE frame are a chain, and a large frame's chain
@@ -1080,9 +1138,55 @@ void piece_copy(const std::vector<Seg> &segs, size_t first_seg, uint64_t lo, uin
     for (auto &x : th) x.join();
 }
 
-// caller memory -> device range [0, total) at `dev_base`, through the pinned ring on `stream`
+// Is every byte of every segment page-locked host memory the device can reach (hipHostMalloc / hipHostRegister)?  Then the DMA engines
+// can read and write the caller's buffers themselves and the staging ring -- one more pass of host memcpy over every byte, which is
+// what bounds the pageable path at about half the link rate -- is skipped.  One attribute query per segment boundary: segments that
+// follow each other in host memory share the answer of the byte between them.
+bool segs_pinned(const std::vector<Seg> &segs, uint64_t min_run)
+{
+    if (segs.empty()) return false;
+    { // A DMA per small scattered buffer loses to one pass through the ring (measured: 8192 frames of 0.5 MiB each into separate slots,
+      // 26 GiB/s direct against 31 staged): go direct only when the runs that are contiguous on both sides average 4 MiB
+        uint64_t bytes = 0, runs = 0;
+        for (size_t k = 0; k < segs.size(); k++) {
+            bytes += segs[k].len;
+            if (k == 0 || segs[k].host != segs[k - 1].host + segs[k - 1].len || segs[k].dev != segs[k - 1].dev + segs[k - 1].len) runs++;
+        }
+        if (bytes / runs < min_run) return false;
+    }
+    auto pinned = [](const uint8_t *p) {
+        hipPointerAttribute_t a;
+        if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; } // ordinary memory: an error, which must not stay behind as the "last error"
+        return a.type == hipMemoryTypeHost;
+    };
+    const uint8_t *verified_end = nullptr; // one past a byte known to be pinned
+    for (const Seg &sg : segs) {
+        if (sg.host != verified_end && !pinned(sg.host)) return false;
+        if (!pinned(sg.host + sg.len - 1)) return false;
+        verified_end = sg.host + sg.len;
+    }
+    return true;
+}
+
+// pinned caller memory <-> device range at `dev_base`: one asynchronous copy per run of segments that are contiguous on both sides
+int direct_copy(zarc_gpu *h, hipStream_t stream, const std::vector<Seg> &segs, uint8_t *dev_base, bool to_device)
+{
+    size_t k = 0;
+    while (k < segs.size()) {
+        size_t e = k + 1;
+        uint64_t len = segs[k].len;
+        while (e < segs.size() && segs[e].host == segs[k].host + len && segs[e].dev == segs[k].dev + len && len + segs[e].len < ((uint64_t)1 << 31)) { len += segs[e].len; e++; }
+        if (to_device) ZHIP(hipMemcpyAsync(dev_base + segs[k].dev, segs[k].host, len, hipMemcpyHostToDevice, stream));
+        else ZHIP(hipMemcpyAsync(segs[k].host, dev_base + segs[k].dev, len, hipMemcpyDeviceToHost, stream));
+        k = e;
+    }
+    return 0;
+}
+
+// caller memory -> device range [0, total) at `dev_base`, through the pinned ring on `stream` (or straight from pinned caller memory)
 int staged_h2d(zarc_gpu *h, hipStream_t stream, const std::vector<Seg> &segs, uint8_t *dev_base, uint64_t total)
 {
+    if (h->zero_copy && segs_pinned(segs, (uint64_t)h->zero_copy << 10)) return direct_copy(h, stream, segs, dev_base, true);
     int rc = pin_ring(h);
     if (rc) return rc;
     size_t first = 0;
@@ -1101,6 +1205,12 @@ int staged_h2d(zarc_gpu *h, hipStream_t stream, const std::vector<Seg> &segs, ui
 // device range [0, total) at `dev_base` -> caller memory; the scatter of piece p overlaps the transfer of piece p+1
 int staged_d2h(zarc_gpu *h, hipStream_t stream, const std::vector<Seg> &segs, const uint8_t *dev_base, uint64_t total)
 {
+    if (h->zero_copy && segs_pinned(segs, (uint64_t)h->zero_copy << 10)) { // the callers synchronise the stream before they hand the buffers back
+        const int r = direct_copy(h, stream, segs, (uint8_t *)dev_base, false);
+        if (r) return r;
+        ZHIP(hipStreamSynchronize(stream));
+        return 0;
+    }
     int rc = pin_ring(h);
     if (rc) return rc;
     struct Piece { uint64_t lo, hi; int slot; size_t first; };
@@ -1177,10 +1287,16 @@ int zarc_gpu_blake3_batch(zarc_gpu_t *h, size_t n, const void *const *src, const
 int zarc_gpu_pack_batch(zarc_gpu_t *h, size_t n, const void *const *src, const size_t *src_len, void *dst, size_t dst_cap, size_t *dst_off,
                         size_t *dst_len, uint8_t (*digest)[ZARC_GPU_DIGEST_LEN], int *status)
 {
+    return zarc_gpu_pack_batch_dedup(h, n, src, src_len, dst, dst_cap, dst_off, dst_len, digest, status, nullptr, nullptr);
+}
+
+int zarc_gpu_pack_batch_dedup(zarc_gpu_t *h, size_t n, const void *const *src, const size_t *src_len, void *dst, size_t dst_cap, size_t *dst_off,
+                              size_t *dst_len, uint8_t (*digest)[ZARC_GPU_DIGEST_LEN], int *status, zarc_gpu_known_fn known, void *ctx)
+{
     int rc = check_common(h, n);
     if (rc) return rc;
     if (n == 0) return ZARC_GPU_OK;
-    if (!src || !src_len || !dst || !dst_off || !dst_len || !digest) return ZARC_GPU_E_PARAM;
+    if (!src || !src_len || !dst || !dst_off || !dst_len || !digest || (known && !status)) return ZARC_GPU_E_PARAM;
     std::vector<uint64_t> in_sz(n), out_sz(n), l64(n);
     uint64_t need = 0;
     for (size_t i = 0; i < n; i++) {
@@ -1249,8 +1365,12 @@ int zarc_gpu_pack_batch(zarc_gpu_t *h, size_t n, const void *const *src, const s
         std::vector<uint64_t> off(m);
         uint64_t at = 0;
         for (size_t k = 0; k < m; k++) { off[k] = at; at += in_sz[i0 + k]; }
-        rc = zarc_gpu_pack_batch_device(h, m, ain + (c & 1) * in_half, off.data(), l64.data() + i0, aout + (c & 1) * out_half, cs[c].out_bytes, doff.data() + i0,
-                                        dlen.data() + i0, (uint8_t *)digest[i0], status ? status + i0 : nullptr);
+        // hash first when the caller can tell known content (the chunk is resident: the digest pass costs 0.5 ms per GiB): the callback sees
+        // indices of the whole batch
+        struct Shift { zarc_gpu_known_fn fn; void *ctx; size_t base; } shift{known, ctx, i0};
+        auto shifted = [](void *c, const uint8_t *d, size_t i) -> int { Shift *s = (Shift *)c; return s->fn(s->ctx, d, s->base + i); };
+        rc = pack_device_dedup_impl(h, m, ain + (c & 1) * in_half, off.data(), l64.data() + i0, aout + (c & 1) * out_half, cs[c].out_bytes, doff.data() + i0,
+                                    dlen.data() + i0, (uint8_t *)digest[i0], status ? status + i0 : nullptr, known ? (zarc_gpu_known_fn)shifted : nullptr, &shift);
         if (helper.joinable()) helper.join();
         if (helper_out.joinable()) helper_out.join();
         if (rc) return rc;

@@ -160,6 +160,56 @@ class Engine:
                                                  dig.ctypes.data_as(ctypes.c_void_p), status))
         return [(bytes(dst[dst_off[i]:dst_off[i] + dst_len[i]]), bytes(dig[i])) for i in range(n)]
 
+    def pack_dedup(self, entries, seen):
+        """Hash-first pack (Encoder::add_data_frame: hash, look the digest up, compress only new content; content_frame.rs:26-33).
+        `seen` is a set of digests (bytes) the caller has frames for; it is updated with what this call compresses.
+        -> list of (frame_bytes or None for a skipped duplicate, digest, status)."""
+        n = len(entries)
+        bufs = [bytes(e) for e in entries]
+        ptrs = (ctypes.c_void_p * n)(*[ctypes.cast(ctypes.c_char_p(b), ctypes.c_void_p) for b in bufs])
+        lens = (ctypes.c_size_t * n)(*[len(b) for b in bufs])
+        cap = sum(self.bound(len(b)) for b in bufs)
+        dst = np.zeros(max(cap, 1), dtype=np.uint8)
+        dst_off, dst_len = (ctypes.c_size_t * n)(), (ctypes.c_size_t * n)()
+        dig = np.zeros((n, 32), dtype=np.uint8)
+        status = (ctypes.c_int * n)()
+        calls = []
+
+        def known(_ctx, d, i):
+            key = bytes(d[:32])
+            calls.append(i)
+            if key in seen:
+                return 1
+            seen.add(key)
+            return 0
+        cb = _lib.KNOWN_FN(known)
+        self._check(self.lib.zarc_gpu_pack_batch_dedup(self.h, n, ptrs, lens, dst.ctypes.data_as(ctypes.c_void_p), cap, dst_off, dst_len,
+                                                       dig.ctypes.data_as(ctypes.c_void_p), status, cb, None))
+        assert calls == list(range(n))       # once per entry, in index order
+        return [(bytes(dst[dst_off[i]:dst_off[i] + dst_len[i]]) if status[i] != _lib.FRAME_DUPLICATE else None, bytes(dig[i]), int(status[i]))
+                for i in range(n)]
+
+    def pack_device_dedup(self, d_src, off, length, d_dst, dst_cap, seen):
+        off, poff = _u64(off)
+        length, plen = _u64(length)
+        n = len(off)
+        dst_off, dst_len = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64)
+        dig = np.zeros((n, 32), dtype=np.uint8)
+        status = np.zeros(n, dtype=np.int32)
+
+        def known(_ctx, d, i):
+            key = bytes(d[:32])
+            if key in seen:
+                return 1
+            seen.add(key)
+            return 0
+        cb = _lib.KNOWN_FN(known)
+        self._check(self.lib.zarc_gpu_pack_batch_device_dedup(
+            self.h, n, ctypes.c_void_p(d_src), poff, plen, ctypes.c_void_p(d_dst), dst_cap,
+            dst_off.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), dst_len.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)),
+            dig.ctypes.data_as(ctypes.c_void_p), status.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), cb, None))
+        return dst_off, dst_len, dig, status
+
     def unpack(self, frames, raw_lens, expect=None):
         """-> list of (bytes, digest, status).  Mirrors read_content_frame + FrameIterator::verify for a batch."""
         n = len(frames)

@@ -29,6 +29,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <numeric>
 #include <optional>
 #include <ostream>
@@ -138,10 +139,11 @@ class Encoder {
     }
 
     // Batched add_data_frame: returns the digest of every entry in call order.
-    // The reference hashes first and skips compression of known content (content_frame.rs:26-33).  Over PCIe a separate
-    // hashing pass would move every byte twice, so the batch is packed in one pass (the engine returns digest AND frame)
-    // and duplicates are dropped afterwards: same archive bytes, some wasted compression when content repeats (SURVEY
-    // quirk 6 names both orders).
+    // Hash first, like the reference (content_frame.rs:26-33): the engine digests the batch, asks `claim` below for every entry, and
+    // compresses only content that neither an earlier call nor an earlier entry of this batch has brought -- on the reference's own
+    // benchmark tree (half of the bytes are duplicates) that halves the work.  With several devices the claims of one digest may come
+    // in any order; whichever device compresses it, the bytes are the same (the encoder is deterministic), and they are written where
+    // the FIRST entry with that digest stands in call order.
     std::vector<Digest> add_data_frames(const void *const *content, const size_t *len, size_t n)
     {
         std::vector<Digest> digests(n);
@@ -151,10 +153,21 @@ class Encoder {
         const size_t g = engines_.size();
         const auto share = shard_assign(len, n, g);
         std::vector<std::vector<uint8_t>> buffers(g);
-        std::vector<size_t> dlen(n);
-        std::vector<const uint8_t *> where(n, nullptr); // frame k lives at where[k]
         std::vector<int> status(n, ZARC_GPU_FRAME_OK);
         std::vector<int> rc(g, ZARC_GPU_OK);
+        struct Made { const uint8_t *at; size_t len; };
+        std::map<Digest, Made> made;   // digest -> the frame some device compressed in this call
+        struct Claims { std::mutex mu; std::map<Digest, int> taken; const std::map<Digest, Frame> *written; } claims;
+        claims.written = &frames_;
+        auto claim = [](void *ctx, const uint8_t *d, size_t) -> int { // "frame already exists, skipping" (content_frame.rs:30-33)
+            Claims *c = (Claims *)ctx;
+            Digest dg;
+            std::memcpy(dg.bytes.data(), d, 32);
+            std::lock_guard<std::mutex> lk(c->mu);
+            if (c->written->count(dg)) return 1;
+            return c->taken.emplace(dg, 1).second ? 0 : 1;
+        };
+        std::mutex made_mu;
         auto pack_share = [&](size_t d) {
             const std::vector<size_t> &idx = share[d];
             const size_t m = idx.size();
@@ -166,10 +179,15 @@ class Encoder {
             size_t cap = 0;
             for (size_t j = 0; j < m; j++) { src[j] = content[idx[j]]; l[j] = len[idx[j]]; cap += zarc_gpu_bound(l[j]); }
             buffers[d].resize(cap);
-            rc[d] = zarc_gpu_pack_batch(engines_[d]->get(), m, src.data(), l.data(), buffers[d].data(), cap, off.data(), out_len.data(),
-                                        (uint8_t(*)[32])dig.data(), st.data());
+            rc[d] = zarc_gpu_pack_batch_dedup(engines_[d]->get(), m, src.data(), l.data(), buffers[d].data(), cap, off.data(), out_len.data(),
+                                              (uint8_t(*)[32])dig.data(), st.data(), hash_first_ ? (zarc_gpu_known_fn)claim : nullptr, &claims);
             if (rc[d] != ZARC_GPU_OK) return;
-            for (size_t j = 0; j < m; j++) { digests[idx[j]] = dig[j]; dlen[idx[j]] = out_len[j]; where[idx[j]] = buffers[d].data() + off[j]; status[idx[j]] = st[j]; }
+            std::lock_guard<std::mutex> lk(made_mu);
+            for (size_t j = 0; j < m; j++) {
+                digests[idx[j]] = dig[j];
+                status[idx[j]] = st[j];
+                if (st[j] == ZARC_GPU_FRAME_OK) made.emplace(dig[j], Made{buffers[d].data() + off[j], out_len[j]}); // (without hash-first: the first copy inserted stays, all copies are equal)
+            }
         };
         if (g == 1) pack_share(0);
         else {
@@ -182,22 +200,26 @@ class Encoder {
         //    inside this batch, across devices -- later duplicates write nothing; offsets are the running sum of the lengths of
         //    what was written (content_frame.rs:22,45-57)
         for (size_t k = 0; k < n; k++) {
-            if (status[k] != ZARC_GPU_FRAME_OK) throw Error(status[k], zarc_gpu_frame_status_name(status[k]));
+            if (status[k] != ZARC_GPU_FRAME_OK && status[k] != ZARC_GPU_FRAME_DUPLICATE) throw Error(status[k], zarc_gpu_frame_status_name(status[k]));
             if (frames_.count(digests[k])) continue; // "frame already exists, skipping"
+            const auto it = made.find(digests[k]);
+            if (it == made.end()) throw Error(ZARC_GPU_E_DEVICE, "internal: no frame was made for a new digest");
             Frame f;
             f.edition = edition_;
             f.offset = offset_;
             f.digest = digests[k];
-            f.length = dlen[k];
+            f.length = it->second.len;
             f.uncompressed = len[k];
-            writer_.write((const char *)where[k], (std::streamsize)dlen[k]);
+            writer_.write((const char *)it->second.at, (std::streamsize)it->second.len);
             if (!writer_) throw Error(ZARC_GPU_E_DEVICE, "write failed");
-            offset_ += dlen[k];
+            offset_ += it->second.len;
             frames_.emplace(f.digest, f);
             order_.push_back(f.digest);
         }
         return digests;
     }
+    // hash-first dedup (default on; off = every entry is compressed and duplicates are dropped afterwards: same archive, more work)
+    void set_hash_first(bool on) { hash_first_ = on; }
 
     const std::map<Digest, Frame> &frames() const { return frames_; }
     const std::vector<Digest> &frame_order() const { return order_; } // insertion order (the reference uses a HashMap)
@@ -208,6 +230,7 @@ class Encoder {
     std::vector<std::unique_ptr<Engine>> engines_; // one per device; engines_[0] also serves the directory frame / digest
     Engine &engine0() { return *engines_[0]; }
     uint16_t edition_ = 1;
+    bool hash_first_ = true;
     std::map<Digest, Frame> frames_;
     std::vector<Digest> order_;
     uint64_t offset_ = 0;
