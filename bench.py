@@ -69,8 +69,16 @@ def cpu_baseline(sample, size, first_index, level, kind=-1):
     one = harness.cpu_baseline(zbest.path, level, 1, sample, size, first_index, kind)
     many = harness.cpu_baseline(zbest.path, level, cores, min(4 * sample, 4096), size, first_index, kind) if cores > 1 else None
     ref = harness.cpu_baseline(z15.path, level, cores, min(sample, 256), size, first_index, kind)  # ratio yardstick: the 1.5.x build
+    one15 = harness.cpu_baseline(z15.path, level, 1, max(sample // 4, 16), size, first_index, kind) if z15.path != zbest.path else one
     out = {"value": one["bytes"] / one["pack_seconds"] / GIB, "unit": "GiB/s", "cores": 1, "kind": "port",
            "unpack_value": one["bytes"] / one["unpack_seconds"] / GIB,
+           # the codec alone (the driver's BLAKE3 is the oracle's portable port; the reference's blake3 crate has SIMD code several times faster,
+           # so the reference's true single-thread rate lies between `value` and this)
+           "value_without_hash": one["bytes"] / max(one["pack_seconds"] - one["pack_hash_seconds"], 1e-9) / GIB,
+           "unpack_value_without_hash": one["bytes"] / max(one["unpack_seconds"] - one["unpack_hash_seconds"], 1e-9) / GIB,
+           # the same driver on the libzstd 1.5.x build (the ratio yardstick; the reference pins 1.5.5), one thread
+           "libzstd_1_5": {"version": z15.version, "value": one15["bytes"] / one15["pack_seconds"] / GIB, "unpack_value": one15["bytes"] / one15["unpack_seconds"] / GIB,
+                           "value_without_hash": one15["bytes"] / max(one15["pack_seconds"] - one15["pack_hash_seconds"], 1e-9) / GIB, "entries": one15["bytes"] // size},
            "sample": "%d x %d B corpus entries (kind %d) from index %d, level %d; C driver tests/support/cpu_baseline.c (one CCtx + session reset per "
                      "entry, decompressStream in 131075/131072-byte steps, oracle BLAKE3 port on both sides); %s; %d host cores usable by this process"
                      % (sample, size, kind, first_index, level, one["info"], cores),
@@ -101,6 +109,7 @@ def src_sha16():
 def workload(args, rank, world):
     """(sizes of this rank's entries, corpus index of each, kind, level, description) -- the global list dealt by the product's sharder."""
     from zarc_amd import shard
+    import math
     import random
     if args.config == "c5":   # BASELINE configs[4] shape: 64 KiB .. 16 MiB log-uniform, kinds round-robin, level 3
         rnd = random.Random(5)
@@ -112,6 +121,13 @@ def workload(args, rank, world):
             tot += s
         level, kind = 3, -1
         desc = "zarc pack %d mixed entries 64 KiB..16 MiB (log-uniform, %.1f GiB), zstd level 3 (BASELINE configs[4] shape)" % (len(sizes), tot / GIB)
+    elif args.config == "small":  # the reference's own published workload (README.md:288-329): 172 k files, median 822 B -- log-normal sizes
+        rnd = random.Random(822)
+        n = args.entries * world
+        sizes = [max(1, min(16 << 20, int(math.exp(rnd.gauss(math.log(822.0), 1.819))))) for _ in range(n)]   # 95th percentile about 16 KiB
+        level, kind = 3, -1
+        desc = "zarc pack %d small entries per GPU (log-normal sizes, median 822 B, 95th percentile 16 KiB, %.2f GiB), zstd level 3 (shape of the reference's README benchmark tree)" % (
+            args.entries, sum(sizes) / GIB / world)
     elif args.config == "c4":  # BASELINE configs[3] shape: one long lz stream cut into 4 MiB frames, level 9
         n = int(args.gib * GIB) // (4 << 20) * world
         sizes = [4 << 20] * n
@@ -197,7 +213,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", choices=["c2", "c4", "c5"], default="c2", help="c2: BASELINE configs[1]/[2] (the headline); c4 / c5: configs[3] / [4] shapes")
+    ap.add_argument("--config", choices=["c2", "c4", "c5", "small"], default="c2", help="c2: BASELINE configs[1]/[2] (the headline); c4 / c5: configs[3] / [4] shapes; small: log-normal sizes with median 822 B (use --entries 1000000)")
     ap.add_argument("--gib", type=float, default=32.0, help="c4 / c5: uncompressed GiB per GPU")
     ap.add_argument("--entries", type=int, default=10000, help="entries per GPU (BASELINE configs[1]: 10000)")
     ap.add_argument("--size", type=int, default=1 << 20, help="bytes per entry (BASELINE configs[1]: 1 MiB)")
@@ -327,7 +343,7 @@ def main():
             "metric": "uncompressed GiB/s (pack) at zstd -%d" % level, "value": round(pack_gibs, 3), "unit": "GiB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(tp / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": desc, "entries_per_gpu": n, "entries_total": n_global, "entry_bytes": args.size if args.config == "c2" else "mixed" if args.config == "c5" else 4 << 20,
+            "config": {"workload": desc, "entries_per_gpu": n, "entries_total": n_global, "entry_bytes": args.size if args.config == "c2" else "mixed" if args.config in ("c5", "small") else 4 << 20,
                        "level": level, "kinds": "text/records/lz/random round-robin" if kind < 0 else "kind %d" % kind,
                        "parallelism": "frames dealt to %d GPU(s) by the product's sharder (index mod G / greedy by bytes), no collective" % world},
             "unpack_gibs": round(unpack_gibs, 3), "unpack_ms_per_step": round(tu / args.steps * 1e3, 3),
@@ -351,9 +367,19 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             size0 = int(lens[0])
             sample = min(args.cpu_sample, n) if args.config == "c2" else min(64, n)
-            cb, ref = cpu_baseline(sample, size0 if args.config != "c5" else 1 << 20, int(index[0]), level, kind)
+            cb, ref = cpu_baseline(sample, {"c5": 1 << 20, "small": 4096}.get(args.config, size0), int(index[0]), level, kind)
             if cb:
                 line["cpu_baseline"] = cb
+                if args.config == "small":   # the ratio on the very entries of the batch: the first 20 000 through libzstd 1.5.x, entry by entry
+                    sys.path.insert(0, os.path.join(ROOT, "tests", "support"))
+                    import harness
+                    z15 = next((z for z in harness.libzstds() if z.version.startswith("1.5")), None)
+                    if z15:
+                        m = min(20000, n)
+                        corpus = harness.Corpus()
+                        ref_comp = sum(len(z15.compress(corpus.entry(int(index[i]), int(lens[i]), kind), level, 1)) for i in range(m))
+                        line["ratio_vs_reference"] = round(ref_comp / float(dlen[:m].sum()), 4)
+                        line["ratio_reference"] = "libzstd %s -%d on the first %d entries, entry by entry" % (z15.version, level, m)
                 if args.config in ("c2", "c4"):   # same entries on both sides (c5's sizes are mixed: its baseline sample is 1 MiB entries)
                     ref_comp, ref_n, ref_name = ref
                     ours = float(dlen[:ref_n].sum())

@@ -46,6 +46,8 @@ typedef struct {
                          bits of its 12-byte hash just below the bucket and check bits are zero (far_step_log / far_res_log unused) and its three
                          4-byte words are not all equal (no runs / periods 1, 2, 4: those are the near table's business): both
                          occurrences of a repeat sample the same relative positions, so a repeat is found if it contains one sample */
+    int far_min_frame; /* frames of at most this many bytes do without the far table (the 16-bit near table reaches 64 KiB): the engine
+                          then has no 256 KiB slab to clear per frame -- what a batch of small entries spent most of its time on */
 } zge_params;
 
 typedef struct { uint32_t ll, ml, off, ofv; } zge_seq;

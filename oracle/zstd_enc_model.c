@@ -958,17 +958,20 @@ void zge_default_params(zge_params *P, int level)
     P->lit_cost = 5; P->match_cost = 12; P->rep_cost = 9;
     P->window_log = 21; P->short_window_log = 30;
     P->far_log = 16; P->far_ways = 1; P->far_step_log = 5; P->far_res_log = 2; P->far_short = 0; P->far_skip = 64; P->far_back = 32;
+    P->far_min_frame = 65536;
     P->near16 = 1; P->short_log = 15; P->far_cdc_log = 4; /* round 3: one 16-bit near table of 2^15 entries, content-defined far sampling */
     if (level >= 9) { /* the engine's deep finder (engine.hip: derive_params) */
-        P->near16 = 0; P->far_cdc_log = 0; P->far_back = 8;
+        P->near16 = 0; P->far_cdc_log = 0; P->far_back = 8; P->far_min_frame = 0;
         P->long_log = 14; P->short_log = 14; P->short_bytes = 4; P->min_match = 4; P->match_cost = 10; P->window_log = 22;
         P->far_log = 16; P->far_ways = 2; P->far_step_log = 1; P->far_res_log = 0; P->far_short = 1; P->far_skip = 0; P->far_back = 8;
     }
 }
 
-int zge_encode_frame(const zge_params *P, const void *src_, size_t n, void *dst_, size_t cap,
+int zge_encode_frame(const zge_params *P_in, const void *src_, size_t n, void *dst_, size_t cap,
                      size_t *out_len, zge_stats *st)
 {
+    zge_params Pn = *P_in;
+    const zge_params *P = &Pn;
     const uint8_t *src = (const uint8_t *)src_;
     uint8_t *dst = (uint8_t *)dst_;
     size_t pos = 0, bs;
@@ -978,6 +981,7 @@ int zge_encode_frame(const zge_params *P, const void *src_, size_t n, void *dst_
     int wlog, single;
     if (cap < zge_bound(n)) return -1;
     if (st) memset(st, 0, sizeof *st);
+    if (n <= (size_t)Pn.far_min_frame) Pn.far_log = 0; /* small frames: no far table */
     /* frame header */
     dst[pos++] = 0x28; dst[pos++] = 0xB5; dst[pos++] = 0x2F; dst[pos++] = 0xFD;
     wlog = P->window_log;

@@ -54,6 +54,8 @@ typedef struct {
     size_t *frame_len;
     uint8_t (*digest)[32];
     int phase;          /* 0 pack, 1 unpack */
+    double hash_s;      /* seconds this thread spent inside BLAKE3 (the oracle's portable port: the blake3 crate's SIMD code is several times
+                           faster, so the codec's share is reported beside the total) */
 } job;
 
 static double now_s(void)
@@ -76,7 +78,7 @@ static void *worker(void *arg)
         for (i = (size_t)j->tid; i < j->n; i += (size_t)j->threads) {
             const size_t len = j->entry_bytes, cap = len + (len / 10 > 1024 ? len / 10 : 1024); /* lowlevel_frames.rs:21 */
             size_t r;
-            oracle_blake3(j->raw[i], len, j->digest[i]);            /* content_frame.rs:26 */
+            { const double h0 = now_s(); oracle_blake3(j->raw[i], len, j->digest[i]); j->hash_s += now_s() - h0; } /* content_frame.rs:26 */
             z->reset(c, 1 /* ZSTD_reset_session_only */);           /* content_frame.rs:37-39 */
             j->frame[i] = (uint8_t *)malloc(cap);
             r = z->compress2(c, j->frame[i], cap, j->raw[i], len);  /* lowlevel_frames.rs:29-31 */
@@ -104,7 +106,7 @@ static void *worker(void *arg)
                     ob.dst = out; ob.size = out_step; ob.pos = 0;
                     hint = z->decompressStream(d, &ob, &in);
                     if (z->isError(hint)) { j->fail = 1; hint = 0; break; }
-                    oracle_blake3_update(&h, out, ob.pos);          /* frame_iterator.rs:99 */
+                    { const double h0 = now_s(); oracle_blake3_update(&h, out, ob.pos); j->hash_s += now_s() - h0; } /* frame_iterator.rs:99 */
                     produced += ob.pos;
                     if (hint == 0 || (ob.pos < ob.size && in.pos == in.size)) break;
                 }
@@ -119,7 +121,7 @@ static void *worker(void *arg)
     return NULL;
 }
 
-static int run_phase(job *proto, int threads, int phase, double *seconds)
+static int run_phase(job *proto, int threads, int phase, double *seconds, double *hash_seconds)
 {
     pthread_t *th = (pthread_t *)calloc((size_t)threads, sizeof *th);
     job *jobs = (job *)calloc((size_t)threads, sizeof *jobs);
@@ -127,10 +129,11 @@ static int run_phase(job *proto, int threads, int phase, double *seconds)
     const double t0 = now_s();
     for (t = 0; t < threads; t++) {
         jobs[t] = *proto;
-        jobs[t].tid = t; jobs[t].threads = threads; jobs[t].phase = phase; jobs[t].fail = 0;
+        jobs[t].tid = t; jobs[t].threads = threads; jobs[t].phase = phase; jobs[t].fail = 0; jobs[t].hash_s = 0;
         if (pthread_create(&th[t], NULL, worker, &jobs[t]) != 0) { jobs[t].fail = 1; th[t] = 0; }
     }
-    for (t = 0; t < threads; t++) { if (th[t]) pthread_join(th[t], NULL); fail |= jobs[t].fail; }
+    *hash_seconds = 0;
+    for (t = 0; t < threads; t++) { if (th[t]) pthread_join(th[t], NULL); fail |= jobs[t].fail; if (jobs[t].hash_s > *hash_seconds) *hash_seconds = jobs[t].hash_s; }
     *seconds = now_s() - t0;
     free(th); free(jobs);
     return fail;
@@ -138,7 +141,8 @@ static int run_phase(job *proto, int threads, int phase, double *seconds)
 
 /* Returns 0 on success.  info receives "libzstd <version>; <cpu model>; <online cores> cores". */
 int cpu_baseline_run(const char *libzstd_path, int level, int threads, size_t n, size_t entry_bytes, uint64_t first_index, int kind,
-                     double *pack_seconds, double *unpack_seconds, uint64_t *compressed_bytes, char *info, size_t info_cap)
+                     double *pack_seconds, double *unpack_seconds, uint64_t *compressed_bytes, char *info, size_t info_cap,
+                     double *pack_hash_seconds, double *unpack_hash_seconds /* the slowest thread's time inside BLAKE3, part of the totals */)
 {
     zapi z;
     job j;
@@ -163,8 +167,9 @@ int cpu_baseline_run(const char *libzstd_path, int level, int threads, size_t n,
         zarc_corpus_entry(j.raw[i], entry_bytes, first_index + i, kind);
     }
     if (threads < 1) threads = 1;
-    rc = run_phase(&j, threads, 0, pack_seconds);
-    if (!rc) rc = run_phase(&j, threads, 1, unpack_seconds);
+    *pack_hash_seconds = *unpack_hash_seconds = 0;
+    rc = run_phase(&j, threads, 0, pack_seconds, pack_hash_seconds);
+    if (!rc) rc = run_phase(&j, threads, 1, unpack_seconds, unpack_hash_seconds);
     *compressed_bytes = 0;
     for (i = 0; i < n; i++) *compressed_bytes += j.frame_len[i];
     if (info && info_cap) {

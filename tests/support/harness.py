@@ -45,22 +45,22 @@ def cpu_baseline(libzstd_path, level, threads, n, entry_bytes, first_index=0, ki
     lib = ctypes.CDLL(_build_cpu_baseline())
     lib.cpu_baseline_run.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_uint64, ctypes.c_int,
                                      ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64),
-                                     ctypes.c_char_p, ctypes.c_size_t]
-    tp, tu, cb = ctypes.c_double(), ctypes.c_double(), ctypes.c_uint64()
+                                     ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+    tp, tu, cb, hp, hu = ctypes.c_double(), ctypes.c_double(), ctypes.c_uint64(), ctypes.c_double(), ctypes.c_double()
     info = ctypes.create_string_buffer(400)
     rc = lib.cpu_baseline_run(libzstd_path.encode(), level, threads, n, entry_bytes, first_index, kind, ctypes.byref(tp), ctypes.byref(tu),
-                              ctypes.byref(cb), info, len(info))
+                              ctypes.byref(cb), info, len(info), ctypes.byref(hp), ctypes.byref(hu))
     if rc != 0:
         raise RuntimeError("cpu_baseline_run failed: %d" % rc)
     return {"pack_seconds": tp.value, "unpack_seconds": tu.value, "compressed_bytes": cb.value, "info": info.value.decode(),
-            "bytes": n * entry_bytes, "threads": threads}
+            "bytes": n * entry_bytes, "threads": threads, "pack_hash_seconds": hp.value, "unpack_hash_seconds": hu.value}
 
 
 class ZgeParams(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in (
         "level", "checksum", "window_log", "long_log", "short_log", "short_bytes", "tile", "sub", "cap",
         "min_match", "min_rep", "rep_search", "back_cap", "lazy", "lazy_delta", "lit_cost", "match_cost",
-        "rep_cost", "short_window_log", "rep_back", "tag_bits", "seg_log", "far_log", "far_ways", "far_step_log", "far_res_log", "far_short", "far_skip", "far_back", "near16", "far_cdc_log")]
+        "rep_cost", "short_window_log", "rep_back", "tag_bits", "seg_log", "far_log", "far_ways", "far_step_log", "far_res_log", "far_short", "far_skip", "far_back", "near16", "far_cdc_log", "far_min_frame")]
 
 
 class ZgeStats(ctypes.Structure):

@@ -201,3 +201,16 @@ def test_emu_hash_first_dedup(emu_engine, oracle, corpus):
             assert emu_engine.pack_dedup([a, a], {oracle.blake3(a)}) == [(None, oracle.blake3(a), _lib.FRAME_DUPLICATE)] * 2   # nothing to compress at all
         finally:
             emu_engine.set_parameter(_lib.PX_STAGE_CHUNK, 0)
+
+
+def test_emu_many_tiny_entries(emu_engine, oracle, corpus):
+    """More than 4096 entries in one call: the O(n) size ordering of large batches (engine.hip: order_by_size_desc), slot sizes that
+    follow the sub-batch's largest block, frames too small for the far table.  Frames equal the model's, round trip, caller's order."""
+    import random
+    rnd = random.Random(4)
+    ents = [corpus.entry(3000 + i, rnd.choice((0, 1, 7, 20, 33, 64, 200)), i % 3) for i in range(4300)] + [corpus.entry(9, 70000, 0), corpus.entry(10, 3000, 1)]
+    res = emu_engine.pack(ents)
+    for i in list(range(0, 4302, 97)) + [4300, 4301]:
+        assert res[i][0] == oracle.zge_encode(ents[i]) and res[i][1] == oracle.blake3(ents[i]), i
+    out = emu_engine.unpack([f for f, _ in res], [len(e) for e in ents], [d for _, d in res])
+    assert all(st == 0 and o == e for e, (o, d, st) in zip(ents, out))

@@ -141,6 +141,7 @@ ZgeParams derive_params(const zarc_gpu_params &p)
     // every 2nd position inserted, all looked up
     z.far_log = 16; z.far_ways = deep ? 2 : 1; z.far_step_log = deep ? 1 : 5; z.far_res_log = deep ? 0 : 2; z.far_short = deep ? 1 : 0;
     z.far_cdc_log = deep ? 0 : 4;
+    z.far_min_frame = deep ? 0 : 65536; // smaller frames do without the far table: the near table reaches 64 KiB
     z.far_back = deep ? 8 : 32; z.far_skip = deep ? 0 : 64;
     z.dbg = diag_env("ZARC_GPU_DBG", 0); // timing-only ablations (outputs invalid when set): diagnostic build only
     return z;
@@ -151,6 +152,25 @@ inline hipError_t create_low_priority_stream(hipStream_t *s)
     int least = 0, greatest = 0;
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return hipStreamCreate(s);
     return hipStreamCreateWithPriority(s, hipStreamDefault, least);
+}
+
+// indices 0 .. n-1 by descending len[], equal lengths in index order (what std::stable_sort gives, in O(n): a batch of a million small
+// entries spent 80 ms per call in the comparison sort).  Lengths are below 2^32 (larger entries are refused before).
+inline std::vector<uint32_t> order_by_size_desc(const uint64_t *len, size_t n)
+{
+    std::vector<uint32_t> order(n);
+    std::iota(order.begin(), order.end(), 0u);
+    if (n < 4096) { std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return len[a] > len[b]; }); return order; }
+    std::vector<uint32_t> tmp(n);
+    for (int pass = 0; pass < 3; pass++) { // least significant digit first, 11 bits a pass; descending = ascending in the inverted key
+        const int shift = 11 * pass;
+        size_t count[2049] = {0};
+        for (size_t i = 0; i < n; i++) count[((~(uint32_t)len[order[i]]) >> shift & 2047u) + 1]++;
+        for (int d = 0; d < 2048; d++) count[d + 1] += count[d];
+        for (size_t i = 0; i < n; i++) tmp[count[(~(uint32_t)len[order[i]]) >> shift & 2047u]++] = order[i];
+        order.swap(tmp);
+    }
+    return order;
 }
 
 inline uint64_t chunks_of(uint64_t len) { return len == 0 ? 1 : (len + 1023) / 1024; }
@@ -453,7 +473,7 @@ int pack_device_impl(zarc_gpu_t *h, size_t n, const void *d_src_base, const uint
     if (rc) return rc;
     if (n == 0) return ZARC_GPU_OK;
     if (!d_src_base || !src_off || !src_len || !d_dst || !dst_off || !dst_len || (!digest && !have_digests)) return ZARC_GPU_E_PARAM;
-    const ZgeParams P = derive_params(h->params);
+    ZgeParams P = derive_params(h->params); // (slot_bytes is set per sub-batch below)
     // the match finder has these compiled in (zge_match.hip: F_*)
     if (P.rep_back != 256 || P.back_cap != 8 || P.lazy_delta != 5 || P.min_rep != 3 || P.rep_search != 2 || P.seg_log != 21 || P.short_window_log < 30 ||
         P.lit_cost != 5 || P.rep_cost != 9 || P.tag_bits != 10 || P.far_log != 16 || P.match_cost != (P.long_log == 14 ? 10 : 12) || P.far_ways != (P.long_log == 14 ? 2 : 1) ||
@@ -514,10 +534,8 @@ int pack_device_impl(zarc_gpu_t *h, size_t n, const void *d_src_base, const uint
     bool xxh_joined = false;
 
     // ---- encoder: frames sorted by size (largest first), processed in sub-batches that fit the scratch budget ----
-    std::vector<uint32_t> order(n);
-    std::iota(order.begin(), order.end(), 0u);
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return src_len[a] > src_len[b]; });
-    const size_t per_block = (size_t)ZARC_MAX_SEQ * 8 + (ZARC_BLOCK + 64) + (ZARC_BLOCK + 1024) + sizeof(ZgeBlock);
+    const std::vector<uint32_t> order = order_by_size_desc(src_len, n);
+    auto per_block_of = [](uint32_t slot) { return (size_t)(zge_seq_stride(slot) * 8 + zge_lit_stride(slot) + zge_out_stride(slot) + sizeof(ZgeBlock)); };
     size_t budget = h->scratch_budget;
     if (!budget) {
         // up to 64 GiB of scratch (BASELINE configs[1] needs 46 GiB to run as ONE launch per kernel), at most 45 % of what is free
@@ -526,15 +544,22 @@ int pack_device_impl(zarc_gpu_t *h, size_t n, const void *d_src_base, const uint
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / 100 * 45 < budget) budget = free_b / 100 * 45;
         if (budget < ((size_t)1 << 30)) budget = (size_t)1 << 30;
     }
-    size_t max_blocks = std::max<size_t>(budget / per_block, 1);
     float ms_match = 0, ms_ent = 0, ms_asm = 0;
     size_t start = 0;
     std::vector<uint64_t> bp;
     while (start < n) {
+        // Scratch slots are sized by the largest block of the sub-batch (frames come in descending size): slot_bytes.  A sub-batch also
+        // ends where the frames have become four times smaller than its slots, so that a batch of a few large and a million small
+        // entries does not give every small one a large slot.
+        const uint64_t first_len = src_len[order[start]];
+        const uint32_t slot = (uint32_t)std::min<uint64_t>(ZARC_BLOCK, std::max<uint64_t>(align_up((size_t)first_len, 16), 1024));
+        P.slot_bytes = (int)slot;
+        const size_t max_blocks = std::max<size_t>(budget / per_block_of(slot), 1);
         size_t end = start, nb = 0;
         while (end < n) {
             const size_t b = (size_t)blocks_of(src_len[order[end]]);
             if (end > start && nb + b > max_blocks) break;
+            if (end > start + 4096 && slot > 1024 && src_len[order[end]] * 4 <= slot) break;
             nb += b;
             end++;
         }
@@ -544,9 +569,9 @@ int pack_device_impl(zarc_gpu_t *h, size_t n, const void *d_src_base, const uint
         if ((rc = upload_u64(h, h->d_block_prefix, bp.data(), m + 1))) return rc;
         if ((rc = upload_u32(h, h->d_order, order.data() + start, m))) return rc;
         ZHIP(h->d_blocks.reserve(nb * sizeof(ZgeBlock)));
-        ZHIP(h->d_seq.reserve(nb * (size_t)ZARC_MAX_SEQ * 8));
-        ZHIP(h->d_lit.reserve(nb * (size_t)(ZARC_BLOCK + 64)));
-        ZHIP(h->d_out.reserve(nb * (size_t)(ZARC_BLOCK + 1024)));
+        ZHIP(h->d_seq.reserve(nb * (size_t)zge_seq_stride(slot) * 8));
+        ZHIP(h->d_lit.reserve(nb * (size_t)zge_lit_stride(slot)));
+        ZHIP(h->d_out.reserve(nb * (size_t)zge_out_stride(slot)));
         ZHIP(h->d_queue.reserve(256));
         int a, b, c, d;
         ZHIP(t.mark(&a));
@@ -571,7 +596,7 @@ int pack_device_impl(zarc_gpu_t *h, size_t n, const void *d_src_base, const uint
                         us.push_back(U{std::min<uint64_t>(len - at, (uint64_t)seg_blocks * ZARC_BLOCK), (uint32_t)j, (uint32_t)b0});
                     }
             for (size_t j = n_split; j < m; j++) us.push_back(U{src_len[order[start + j]], (uint32_t)j, 0u}); // smaller frames are one unit (zge_match.hip)
-            std::stable_sort(us.begin(), us.end(), [](const U &x, const U &y) { return x.bytes > y.bytes; });
+            if (n_split) std::stable_sort(us.begin(), us.end(), [](const U &x, const U &y) { return x.bytes > y.bytes; }); // (without split frames the list is in `order` already)
             units.reserve(us.size() * 2);
             for (const U &u : us) { units.push_back(u.slot); units.push_back(u.b0); }
         }
@@ -602,7 +627,7 @@ int pack_device_impl(zarc_gpu_t *h, size_t n, const void *d_src_base, const uint
             digest_queued = true;
         }
         ZHIP(t.mark(&b));
-        hipLaunchKernelGGL(zarc_zge_entropy, dim3((unsigned)nb), dim3(64), 0, h->stream, (uint32_t)nb, h->d_blocks.as<ZgeBlock>(),
+        hipLaunchKernelGGL(zarc_zge_entropy, dim3((unsigned)nb), dim3(64), 0, h->stream, (uint32_t)nb, slot, h->d_blocks.as<ZgeBlock>(),
                            h->d_seq.as<uint64_t>(), h->d_lit.as<uint8_t>(), h->d_out.as<uint8_t>(),
                            (P.dbg & 1024) ? (unsigned long long *)((char *)h->d_queue.p + 128) : (unsigned long long *)nullptr);
         ZHIP(hipGetLastError());
@@ -714,9 +739,7 @@ int unpack_device_once(zarc_gpu_t *h, size_t n, const void *d_frames_base, const
         if (frame_len_in[i] >= 0xFFFFFFF0ull || raw_len_in[i] >= 0xFFFFFFF0ull) { set_error(h, "frames of 4 GiB or more are not supported"); return ZARC_GPU_E_UNSUPPORTED; }
         total_raw += raw_len_in[i];
     }
-    std::vector<uint32_t> order(n);
-    std::iota(order.begin(), order.end(), 0u);
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return raw_len_in[a] > raw_len_in[b]; });
+    const std::vector<uint32_t> order = order_by_size_desc(raw_len_in, n);
     std::vector<uint64_t> frame_off(n), frame_len(n), dst_off(n), raw_len(n);
     for (size_t i = 0; i < n; i++) { const uint32_t f = order[i]; frame_off[i] = frame_off_in[f]; frame_len[i] = frame_len_in[f]; dst_off[i] = dst_off_in[f]; raw_len[i] = raw_len_in[f]; }
     if ((rc = upload_u64(h, h->d_frame_off, frame_off.data(), n))) return rc;

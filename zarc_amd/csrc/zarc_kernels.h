@@ -16,8 +16,13 @@ constexpr uint32_t ZARC_MAX_SEQ = ZARC_BLOCK / 3 + 8; // sequences per block (ev
 struct ZgeParams {
     int level, checksum, window_log, long_log, short_log, short_bytes, tile, sub, cap, min_match, min_rep, rep_search,
         back_cap, lazy, lazy_delta, lit_cost, match_cost, rep_cost, short_window_log, rep_back, tag_bits, seg_log,
-        far_log, far_ways, far_step_log, far_res_log, far_short, far_skip, far_back, near16, far_cdc_log, dbg;
+        far_log, far_ways, far_step_log, far_res_log, far_short, far_skip, far_back, near16, far_cdc_log, far_min_frame, slot_bytes, dbg;
 };
+// Encoder scratch of one block slot (sequences, literals, coded block): sized by the largest block of the SUB-BATCH (slot_bytes <=
+// ZARC_BLOCK, a multiple of 16) -- a batch of a million 1 KiB entries must not reserve 600 KiB per entry.
+__host__ __device__ inline uint64_t zge_seq_stride(uint32_t slot_bytes) { return slot_bytes / 3 + 8; }   // sequences (8 bytes each)
+__host__ __device__ inline uint64_t zge_lit_stride(uint32_t slot_bytes) { return (uint64_t)slot_bytes + 64; }
+__host__ __device__ inline uint64_t zge_out_stride(uint32_t slot_bytes) { return (uint64_t)slot_bytes + 1024; }
 // words of far-table scratch one match-finder workgroup needs (HBM): 2^far_log buckets x ways, once or twice
 __host__ __device__ inline size_t zge_far_words(const ZgeParams &P) { return P.far_log ? (((size_t)P.far_ways << P.far_log) * (P.far_short ? 2 : 1)) : 0; }
 
@@ -123,7 +128,7 @@ __global__ void zarc_zge_match_diag(ZgeParams P, const uint8_t *src_base, const 
 __global__ void zarc_zge_match_deep(ZgeParams P, const uint8_t *src_base, const uint64_t *src_off, const uint64_t *src_len,
                                     const uint32_t *order, const uint32_t *units /* (queue slot, first block) per 2 MiB segment */, uint32_t n_units, const uint64_t *block_prefix, ZgeBlock *blocks,
                                     uint64_t *seq_scratch, uint8_t *lit_scratch, uint32_t *queue, uint32_t *far_scratch);
-__global__ void zarc_zge_entropy(uint32_t n_blocks, ZgeBlock *blocks, uint64_t *seq_scratch, const uint8_t *lit_scratch,
+__global__ void zarc_zge_entropy(uint32_t n_blocks, uint32_t slot_bytes, ZgeBlock *blocks, uint64_t *seq_scratch, const uint8_t *lit_scratch,
                                  uint8_t *out_scratch, unsigned long long *prof);
 __global__ void zarc_zge_assemble(ZgeParams P, const uint8_t *src_base, const uint64_t *src_off, const uint64_t *src_len,
                                   const uint32_t *order, uint32_t n_frames, const uint64_t *block_prefix, const ZgeBlock *blocks, const uint8_t *out_scratch,

@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(256) zarc_zge_assemble(ZgeParams P, const uint
             pos += 3;
             const uint8_t *from;
             uint32_t cnt;
-            if (rec.type == 2) { from = out_scratch + (first + b) * (uint64_t)(ZARC_BLOCK + 1024); cnt = rec.out_len; }
+            if (rec.type == 2) { from = out_scratch + (first + b) * zge_out_stride((uint32_t)P.slot_bytes); cnt = rec.out_len; }
             else if (rec.type == 1) { from = src + (uint64_t)b * ZARC_BLOCK; cnt = 1; }
             else { from = src + (uint64_t)b * ZARC_BLOCK; cnt = rec.src_len; }
             group_copy(dst + pos, from, cnt, tid, (int)blockDim.x);

@@ -477,7 +477,7 @@ struct WavePacker {
 
 } // namespace
 
-__global__ void __launch_bounds__(64, 5) zarc_zge_entropy(uint32_t n_blocks, ZgeBlock *__restrict__ blocks, uint64_t *__restrict__ seq_scratch,
+__global__ void __launch_bounds__(64, 5) zarc_zge_entropy(uint32_t n_blocks, uint32_t slot_bytes, ZgeBlock *__restrict__ blocks, uint64_t *__restrict__ seq_scratch,
                                                        const uint8_t *__restrict__ lit_scratch, uint8_t *__restrict__ out_scratch,
                                                        unsigned long long *__restrict__ prof /* stage ticks (diagnostics) or null */)
 {
@@ -490,10 +490,10 @@ __global__ void __launch_bounds__(64, 5) zarc_zge_entropy(uint32_t n_blocks, Zge
     if (rec->type == 1) return; // RLE block: nothing to code
     const uint32_t nlit = rec->nlit, src_len = rec->src_len;
     uint32_t nseq = rec->nseq;
-    uint64_t *seq = seq_scratch + (uint64_t)bi * ZARC_MAX_SEQ;
-    const uint8_t *lit = lit_scratch + (uint64_t)bi * (ZARC_BLOCK + 64);
-    uint8_t *out = out_scratch + (uint64_t)bi * (ZARC_BLOCK + 1024);
-    const uint32_t out_cap = ZARC_BLOCK + 1024;
+    uint64_t *seq = seq_scratch + (uint64_t)bi * zge_seq_stride(slot_bytes);
+    const uint8_t *lit = lit_scratch + (uint64_t)bi * zge_lit_stride(slot_bytes);
+    uint8_t *out = out_scratch + (uint64_t)bi * zge_out_stride(slot_bytes);
+    const uint32_t out_cap = (uint32_t)zge_out_stride(slot_bytes);
     bool fail = false;
 
     // ================= literals section =================

@@ -207,13 +207,15 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG, NEAR16> &L, con
     const uint32_t n = (uint32_t)src_len[f]; // the engine rejects entries of 4 GiB or more: positions are 32-bit
     const uint32_t window = n <= (1u << P.window_log) ? (n ? n : 1u) : (1u << P.window_log);
     const uint32_t hash_end = n >= 8 ? n - 7 : 0;
-    const uint32_t far_end = n >= 12 ? n - 11 : 0; // the far tables' long hash reads 12 bytes
+    // frames of at most far_min_frame bytes do without the far table (the near table reaches that far): no slab to clear, no requests
+    const bool far_on = NFAR && n > (uint32_t)P.far_min_frame;
+    const uint32_t far_end = (far_on && n >= 12) ? n - 11 : 0; // the far tables' long hash reads 12 bytes
     // block records / scratch slots are numbered within the sub-batch: block_prefix is indexed by queue slot
     const uint64_t first_block = block_prefix[slot];
     const uint32_t nblocks = (uint32_t)(block_prefix[slot + 1] - first_block);
 
     for (int i = tid; i < MatchLds<TAB_LOG, NEAR16>::TAB_WORDS; i += THREADS) L.tab[i] = 0;
-    if (NFAR) { // the slab still holds the previous frame (whose last inserts were waited for in its last tile)
+    if (NFAR && far_on) { // the slab still holds the previous frame (whose last inserts were waited for in its last tile)
         uint4 *f4 = (uint4 *)far_l;
         for (uint32_t i = (uint32_t)tid; i < far_words / 4; i += THREADS) f4[i] = make_uint4(0, 0, 0, 0);
         zd::wait_vmem(); // the zeros are in L2 before any wave passes the barrier and looks something up
@@ -253,8 +255,8 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG, NEAR16> &L, con
         const uint32_t be = n - bs > ZARC_BLOCK ? bs + ZARC_BLOCK : n;
         const uint32_t blen = (uint32_t)(be - bs);
         ZgeBlock *rec = blocks + first_block + b;
-        uint64_t *seq_out = seq_scratch + (first_block + b) * (uint64_t)ZARC_MAX_SEQ;
-        uint8_t *lit_out = lit_scratch + (first_block + b) * (uint64_t)(ZARC_BLOCK + 64);
+        uint64_t *seq_out = seq_scratch + (first_block + b) * zge_seq_stride((uint32_t)P.slot_bytes);
+        uint8_t *lit_out = lit_scratch + (first_block + b) * zge_lit_stride((uint32_t)P.slot_bytes);
 
         if (b > ub0 && (bs & seg_mask) == 0) { // a frame that is one unit: new 2^seg_log segment (a multiple of the block size), table positions restart
             for (int i = tid; i < MatchLds<TAB_LOG, NEAR16>::TAB_WORDS; i += THREADS) L.tab[i] = 0;
