@@ -10,6 +10,9 @@
  * Pinned by decoding frames produced by real libzstd builds (tests/golden/zstd_frames).
  */
 #include "oracle.h"
+/* optional sequence trace (tools/seqdiff.py: which sequence two encoders first disagree on) */
+void (*oracle_zstd_trace)(void *ctx, uint64_t pos, uint32_t ll, uint32_t ml, uint32_t offset) = 0;
+void *oracle_zstd_trace_ctx = 0;
 #include <stdlib.h>
 #include <string.h>
 
@@ -466,6 +469,7 @@ static int decode_block(dctx *d, const uint8_t *src, size_t len, uint8_t *dst_ba
                 d->rep[0] = offset;
             }
         }
+        if (oracle_zstd_trace) oracle_zstd_trace(oracle_zstd_trace_ctx, (uint64_t)pos + ll, ll, ml, offset); /* test tooling: where a match starts, its lengths and offset */
         if (lit_pos + ll > lit_len) return ORACLE_ZSTD_E_CORRUPT;
         if (pos + ll + ml > dst_cap) return ORACLE_ZSTD_E_DSTSIZE;
         memcpy(dst_base + pos, d->lit + lit_pos, ll);

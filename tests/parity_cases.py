@@ -68,6 +68,9 @@ def encode_cases(corpus, big):
          "per7n": bytes((i % 7) * 31 + (rnd.randrange(256) if rnd.randrange(40) == 0 else 0) & 255 for i in range(30000)),
          "wrap64k": corpus.entry(31, 100, 0) + corpus.entry(32, 1500, 1) + corpus.entry(33, 65536 - 1500, 0) + corpus.entry(32, 1500, 1)
                     + corpus.entry(34, 1, 0) + corpus.entry(33, 65536 - 1500, 0)[:30000] + corpus.entry(35, 65537 - 30000 - 1, 2) + corpus.entry(33, 65536 - 1500, 0)[:2000]}
+    # found by tools/soak.py (round 3): a position whose near candidate is a hash collision at the very distance of its right neighbour's true
+    # candidate -- the neighbour, a "follower", inherits length 0 and must still get the match through the far table's candidate
+    c["follower_collision"] = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "enc_follower_collision.bin"), "rb").read()
     if big:
         for k in range(4):
             c["k%d_1m" % k] = corpus.entry(40 + k, 1 << 20, k)

@@ -632,7 +632,9 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG, NEAR16> &L, con
                     }
                 }
 #pragma unroll
-                for (int k = 0; k < NFAR; k++) offs[u][1 + k] = foffs[u][k] == on ? 0u : foffs[u][k]; // the near table has offered it already
+                // the near table has offered it already -- unless this position is a follower: its handed-down near length is the head's
+                // minus the distance, and a head whose candidate was a hash collision at the very same distance hands down nothing
+                for (int k = 0; k < NFAR; k++) offs[u][1 + k] = (foffs[u][k] == on && !fol[u]) ? 0u : foffs[u][k];
             }
             ZGE_PROF(9);
             // while those loads are in flight: the two recent-offset guesses of both positions.  Both sides are inside the staged
