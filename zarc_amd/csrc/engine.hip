@@ -161,15 +161,19 @@ inline std::vector<uint32_t> order_by_size_desc(const uint64_t *len, size_t n)
     std::vector<uint32_t> order(n);
     std::iota(order.begin(), order.end(), 0u);
     if (n < 4096) { std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return len[a] > len[b]; }); return order; }
-    std::vector<uint32_t> tmp(n);
-    for (int pass = 0; pass < 3; pass++) { // least significant digit first, 11 bits a pass; descending = ascending in the inverted key
-        const int shift = 11 * pass;
+    // (inverted length << 32 | index) pairs, sorted by the upper half: least significant digit first, 11 bits a pass, the pairs walked in
+    // memory order (descending length = ascending inverted key; equal keys keep their order)
+    std::vector<uint64_t> a(n), b(n);
+    for (size_t i = 0; i < n; i++) a[i] = (uint64_t)(~(uint32_t)len[i]) << 32 | (uint32_t)i;
+    for (int pass = 0; pass < 3; pass++) {
+        const int shift = 32 + 11 * pass;
         size_t count[2049] = {0};
-        for (size_t i = 0; i < n; i++) count[((~(uint32_t)len[order[i]]) >> shift & 2047u) + 1]++;
+        for (size_t i = 0; i < n; i++) count[(a[i] >> shift & 2047u) + 1]++;
         for (int d = 0; d < 2048; d++) count[d + 1] += count[d];
-        for (size_t i = 0; i < n; i++) tmp[count[(~(uint32_t)len[order[i]]) >> shift & 2047u]++] = order[i];
-        order.swap(tmp);
+        for (size_t i = 0; i < n; i++) b[count[a[i] >> shift & 2047u]++] = a[i];
+        a.swap(b);
     }
+    for (size_t i = 0; i < n; i++) order[i] = (uint32_t)a[i];
     return order;
 }
 
@@ -595,10 +599,15 @@ int pack_device_impl(zarc_gpu_t *h, size_t n, const void *d_src_base, const uint
                         const uint64_t len = src_len[order[start + j]], at = b0 * (uint64_t)ZARC_BLOCK;
                         us.push_back(U{std::min<uint64_t>(len - at, (uint64_t)seg_blocks * ZARC_BLOCK), (uint32_t)j, (uint32_t)b0});
                     }
-            for (size_t j = n_split; j < m; j++) us.push_back(U{src_len[order[start + j]], (uint32_t)j, 0u}); // smaller frames are one unit (zge_match.hip)
-            if (n_split) std::stable_sort(us.begin(), us.end(), [](const U &x, const U &y) { return x.bytes > y.bytes; }); // (without split frames the list is in `order` already)
-            units.reserve(us.size() * 2);
-            for (const U &u : us) { units.push_back(u.slot); units.push_back(u.b0); }
+            if (n_split == 0) { // every frame is one unit (zge_match.hip) and the list is in `order` already: longest first
+                units.resize(2 * m);
+                for (size_t j = 0; j < m; j++) { units[2 * j] = (uint32_t)j; units[2 * j + 1] = 0u; }
+            } else {
+                for (size_t j = n_split; j < m; j++) us.push_back(U{src_len[order[start + j]], (uint32_t)j, 0u});
+                std::stable_sort(us.begin(), us.end(), [](const U &x, const U &y) { return x.bytes > y.bytes; });
+                units.reserve(us.size() * 2);
+                for (const U &u : us) { units.push_back(u.slot); units.push_back(u.b0); }
+            }
         }
         const size_t n_units = units.size() / 2;
         if ((rc = upload_u32(h, h->d_units, units.data(), units.size()))) return rc;

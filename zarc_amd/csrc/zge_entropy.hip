@@ -308,8 +308,9 @@ __device__ int huf_build_lengths(EntLds &L, int lane)
     zd::wave_sync();
     const int n = (int)present;
     if (n < 2) { if (n == 1 && lane == 0) L.h.len8[L.h.order[0]] = 1; zd::wave_sync(); return n; }
-    if (lane == 0) {
-        for (int i = 0; i < n; i++) L.h.w[i] = L.h.count[L.h.order[i]];
+    for (int i = lane; i < n; i += 64) L.h.w[i] = L.h.count[L.h.order[i]];
+    zd::wave_sync();
+    if (lane == 0) { // the two-queue merge is a chain: one lane
         int leaf = 0, inode = n, next = n;
         while (next < 2 * n - 1) {
             int a, b;
@@ -320,11 +321,27 @@ __device__ int huf_build_lengths(EntLds &L, int lane)
             L.h.parent[b] = (uint16_t)next;
             next++;
         }
-        L.h.depth[2 * n - 2] = 0;
-        for (int i = 2 * n - 3; i >= 0; i--) { const int d = L.h.depth[L.h.parent[i]] + 1; L.h.depth[i] = (uint8_t)(d > 63 ? 63 : d); }
-        int *const num = (int *)&L.h.w[0]; // the merge weights are dead from here on; a local array would live in scratch (HBM)
-        for (int k = 0; k < 64; k++) num[k] = 0;
-        for (int i = 0; i < n; i++) num[L.h.depth[i]]++;
+    }
+    zd::wave_sync();
+    // leaf depths: every lane walks its leaves up to the root (only the leaves' depths are used; the serial top-down pass over all 2n - 1
+    // nodes was a sixth of this function), capped at 63 like the model; histogram of the depths with LDS atomics
+    int *const num = (int *)&L.h.w[0]; // the merge weights are dead from here on; a local array would live in scratch (HBM)
+    {
+        uint32_t dep[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int i = r * 64 + lane;
+            dep[r] = 0;
+            if (i < n) { int j = i; uint32_t d = 0; while (j != 2 * n - 2) { j = L.h.parent[j]; d++; } dep[r] = d > 63 ? 63 : d; }
+        }
+        zd::wave_sync(); // every walk is done before w[] is reused
+        for (int k = lane; k < 64; k += 64) num[k] = 0;
+        zd::wave_sync();
+#pragma unroll
+        for (int r = 0; r < 4; r++) if (r * 64 + lane < n) atomicAdd(&num[dep[r]], 1);
+        zd::wave_sync();
+    }
+    if (lane == 0) { // limit to HUF_MAXBITS and repair the Kraft sum: a few steps over at most 64 counters
         for (int k = HUF_MAXBITS + 1; k < 64; k++) { num[HUF_MAXBITS] += num[k]; num[k] = 0; }
         uint32_t total = 0;
         for (int k = 1; k <= HUF_MAXBITS; k++) total += (uint32_t)num[k] << (HUF_MAXBITS - k);
@@ -333,41 +350,75 @@ __device__ int huf_build_lengths(EntLds &L, int lane)
             for (int k = HUF_MAXBITS - 1; k > 0; k--) if (num[k]) { num[k]--; num[k + 1] += 2; break; }
             total--;
         }
-        int i = n - 1;
-        for (int k = 1; k <= HUF_MAXBITS; k++) for (int c = 0; c < num[k]; c++) L.h.len8[L.h.order[i--]] = (uint8_t)k;
+    }
+    zd::wave_sync();
+    // the most frequent symbols (end of `order`) get the shortest codes: the symbol t places from the top gets the smallest length k with
+    // num[1] + .. + num[k] > t
+    {
+        uint32_t cum[HUF_MAXBITS + 1];
+        uint32_t c = 0;
+#pragma unroll
+        for (int k = 1; k <= HUF_MAXBITS; k++) { c += (uint32_t)num[k]; cum[k] = c; }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int j = r * 64 + lane;
+            if (j < n) {
+                const uint32_t t = (uint32_t)(n - 1 - j);
+                uint32_t k = 1;
+#pragma unroll
+                for (int q = 1; q < HUF_MAXBITS; q++) k += cum[q] <= t ? 1u : 0u;
+                L.h.len8[L.h.order[j]] = (uint8_t)k;
+            }
+        }
     }
     zd::wave_sync();
     return n;
 }
 
-// lane 0: canonical codes in zstd weight order; fills L.code, ctrl[X_MAXBITS], ctrl[X_NSYM_LAST]
-__device__ void huf_assign_codes(EntLds &L)
+// Canonical codes in zstd weight order; fills L.code, ctrl[X_MAXBITS], ctrl[X_NSYM_LAST].  Whole wave, four symbols per lane (symbol
+// r * 64 + lane): a symbol's code is the first code of its weight plus the number of lower symbols of the same length -- a ballot and a
+// population count per length and round instead of three 256-step loops on one lane (they were a third of the stage's fixed cost per
+// block).  Same arithmetic as the model: rank_start[w] = sum over lighter weights of count << (weight - 1), code = (rank_start[w] +
+// index << (w - 1)) >> (w - 1).
+__device__ void huf_assign_codes(EntLds &L, int lane)
 {
-    int maxlen = 0, last = 0;
-    for (int i = 0; i < 256; i++) if (L.h.len8[i]) { if (L.h.len8[i] > maxlen) maxlen = L.h.len8[i]; last = i; }
-    uint32_t *const rank_start = &L.h.w[64], *const rank_count = &L.h.w[80]; // LDS, not scratch (w[] is free after the tree is built)
-    for (int w = 0; w < 16; w++) rank_count[w] = 0;
-    for (int i = 0; i < 256; i++) if (L.h.len8[i]) rank_count[maxlen + 1 - L.h.len8[i]]++;
+    uint32_t len[4], idx[4];
+    uint32_t maxlen = 0, last = 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) { len[r] = L.h.len8[r * 64 + lane]; idx[r] = 0; if (len[r] > maxlen) maxlen = len[r]; if (len[r]) last = (uint32_t)(r * 64 + lane); }
+    maxlen = zd::uniform(zd::wave_max(maxlen));
+    last = zd::uniform(zd::wave_max(last));
+    const uint64_t lt = (1ull << lane) - 1;
+    uint32_t *const rank_start = &L.h.w[64]; // LDS (w[] is free after the tree is built)
     uint32_t pos = 0;
-    for (int w = 1; w <= maxlen; w++) { rank_start[w] = pos; pos += rank_count[w] << (w - 1); }
-    for (int i = 0; i < 256; i++) {
-        if (!L.h.len8[i]) { L.code[i] = 0; continue; }
-        const int w = maxlen + 1 - L.h.len8[i];
-        L.code[i] = (uint16_t)((rank_start[w] >> (w - 1)) | ((uint32_t)L.h.len8[i] << 11));
-        rank_start[w] += 1u << (w - 1);
+    for (uint32_t w = 1; w <= maxlen; w++) { // uniform: weight w = code length maxlen + 1 - w, lightest first
+        const uint32_t lv = maxlen + 1 - w;
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const uint64_t m = zd::ballot(len[r] == lv);
+            if (len[r] == lv) idx[r] = cnt + (uint32_t)__popcll(m & lt);
+            cnt += (uint32_t)__popcll(m);
+        }
+        if (lane == 0) rank_start[w] = pos;
+        pos += cnt << (w - 1);
     }
-    L.ctrl[X_MAXBITS] = maxlen;
-    L.ctrl[X_NSYM_LAST] = last;
+    zd::wave_sync();
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        uint32_t code = 0;
+        if (len[r]) { const uint32_t w = maxlen + 1 - len[r]; code = ((rank_start[w] >> (w - 1)) + idx[r]) | (len[r] << 11); }
+        L.code[r * 64 + lane] = (uint16_t)code;
+    }
+    if (lane == 0) { L.ctrl[X_MAXBITS] = (int)maxlen; L.ctrl[X_NSYM_LAST] = (int)last; }
+    zd::wave_sync();
 }
 
 // lane 0: Huffman tree description into L.h.hdesc; returns its length (0 = not representable)
 __device__ uint32_t huf_write_desc(EntLds &L)
 {
-    const int n = L.ctrl[X_NSYM_LAST], max_bits = L.ctrl[X_MAXBITS];
-    for (int i = 0; i < n; i++) L.h.wt[i] = L.h.len8[i] ? (uint8_t)(max_bits + 1 - L.h.len8[i]) : 0;
-    if (n > 1) {
-        for (int s = 0; s < 16; s++) L.h.cw[s] = 0;
-        for (int i = 0; i < n; i++) L.h.cw[L.h.wt[i]]++;
+    const int n = L.ctrl[X_NSYM_LAST]; // (the weights L.h.wt[] were filled in by the whole wave)
+    if (n > 1) { // (so was the histogram of the weights of symbols 0 .. n-1, L.h.cw[])
         int nsym = 0, distinct = 0, al = 6;
         uint32_t maxc = 0;
         for (int s = 0; s < 13; s++) if (L.h.cw[s]) { nsym = s + 1; distinct++; if (L.h.cw[s] > maxc) maxc = L.h.cw[s]; }
@@ -535,12 +586,27 @@ __global__ void __launch_bounds__(64, 5) zarc_zge_entropy(uint32_t n_blocks, uin
         if (n >= 2 && distinct == 1) kind = 1;
         else if (n >= MIN_HUF_LITERALS && distinct >= 2 && !flat) {
             huf_build_lengths(L, lane);
+            huf_assign_codes(L, lane);
+            uint32_t est_bits = 0; // at most 131 072 literals x 11 bits
+            {
+                const int max_bits = L.ctrl[X_MAXBITS], nlast = L.ctrl[X_NSYM_LAST];
+                if (lane < 16) L.h.cw[lane] = 0;
+                zd::wave_sync();
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int sym = r * 64 + lane;
+                    const uint32_t l = L.h.len8[sym];
+                    const uint32_t wgt = l ? (uint32_t)(max_bits + 1 - (int)l) : 0u;
+                    L.h.wt[sym] = (uint8_t)wgt;       // weights for the tree description (symbols below the last present one are read)
+                    if (sym < nlast) atomicAdd(&L.h.cw[wgt], 1u); // ... and their histogram (the description codes them with FSE)
+                    est_bits += L.h.count[sym] * l;
+                }
+                est_bits = zd::uniform(zd::wave_sum(est_bits));
+            }
+            zd::wave_sync();
             if (lane == 0) {
-                huf_assign_codes(L);
                 const uint32_t dlen = huf_write_desc(L);
-                uint64_t est_bits = 0;
-                for (int i = 0; i < 256; i++) est_bits += (uint64_t)L.h.count[i] * L.h.len8[i];
-                const uint64_t est = dlen + (est_bits + 7) / 8 + (n >= 256 ? 10 : 1);
+                const uint64_t est = dlen + ((uint64_t)est_bits + 7) / 8 + (n >= 256 ? 10 : 1);
                 L.ctrl[X_DLEN] = (dlen && est + 3 < n) ? (int)dlen : 0;
             }
             zd::wave_sync();
