@@ -207,7 +207,8 @@ enum {
     ZARC_GPU_T_ENTROPY = 3,   /* encoder: Huffman/FSE block coder      */
     ZARC_GPU_T_ASSEMBLE = 4,  /* encoder: frame assembly               */
     ZARC_GPU_T_DECODE = 5,    /* decoder                               */
-    ZARC_GPU_T_TOTAL = 6,     /* first launch .. last launch of the call */
+    ZARC_GPU_T_TOTAL = 6,     /* pack: setup + match + entropy + assembly (the digest and the checksum run on side streams beside them and
+                                 have their own entries); unpack / digest-only calls: first launch .. last launch                       */
     ZARC_GPU_T_DEC_SEQS = 7,  /* decoder stage 2: sequence entropy decoding (zarc_zdec_seqs)             */
     ZARC_GPU_T_DEC_LITS = 8,  /* decoder stage 2: Huffman literals (zarc_zdec_literals, side stream)      */
     ZARC_GPU_T_DEC_FRAMES = 9,/* decoder frame pass (zarc_zstd_frames + the inline decoder for the rest)  */

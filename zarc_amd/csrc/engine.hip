@@ -201,7 +201,8 @@ int upload_u32(zarc_gpu *h, DevBuf &b, const uint32_t *src, size_t n)
 
 // BLAKE3 of n entries described by device arrays d_off/d_len (already uploaded); result in h->d_digests
 // `side` (pack): the two kernels go to the low-priority side stream behind an event of the engine stream -- the caller launches the
-// match finder first, so the digest fills the tail of that launch instead of standing in front of it
+// match finder first: the side stream waits for an event recorded BEHIND that launch, so the digest kernels start when the match finder
+// has finished and run beside the entropy stage (low priority) instead of standing in front of the persistent workgroups
 int run_blake3(zarc_gpu *h, size_t n, const uint8_t *d_base, const uint64_t *off, const uint64_t *len, const uint64_t *d_off, const uint64_t *d_len,
                bool prepare_only = false, bool launch_only = false, hipStream_t stream = nullptr)
 {
@@ -512,7 +513,7 @@ int pack_device_impl(zarc_gpu_t *h, size_t n, const void *d_src_base, const uint
         ZHIP(hipEventRecord(h->ev_join, h->stream2));
     }
     // the digest: in store mode right here; otherwise its kernels are queued on the low-priority side stream right behind the first
-    // match-finder launch (below), fill the tail of that launch and are joined before the digests travel back
+    // match-finder launch (below): they start when it ends, run beside the entropy stage, and are joined before the digests travel back
     if (!have_digests && (rc = run_blake3(h, n, base, src_off, src_len, d_off, d_len, /*prepare_only=*/h->params.compress != 0))) return rc;
     ZHIP(t.mark(&e1));
     bool digest_queued = have_digests; // nothing to queue
