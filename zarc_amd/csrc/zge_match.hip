@@ -671,71 +671,115 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG, NEAR16> &L, con
                 }
             }
             ZGE_PROF(10);
+            // common prefix of position p (first 8 bytes p8v) with the source `off` bytes back whose first 8 bytes are `first8`, at most `cap`:
+            // 8 bytes per step, 16 per global round trip; reads past `cap` stay inside the staged window / the padded arena
+            auto prefix_len = [&](uint32_t p, uint64_t p8v, uint32_t cap, uint32_t off, uint64_t first8) -> uint32_t {
+                uint64_t x = first8 ^ p8v;
+                uint32_t len = 0;
+                while (!x && len + 8 < cap) {
+                    U128 sv;
+                    __builtin_memcpy(&sv, src + (p - off + len + 8), 16);
+                    const uint64_t a0 = zd::load_u64(tbb + (uint32_t)(p + len + 8 + wofs)), a1 = zd::load_u64(tbb + (uint32_t)(p + len + 16 + wofs));
+                    len += 8;
+                    x = a0 ^ sv.lo;
+                    if (!x && len + 8 < cap) { len += 8; x = a1 ^ sv.hi; }
+                }
+                len += x ? (uint32_t)(zd::ctz64(x) >> 3) : 8u;
+                return len > cap ? cap : len;
+            };
+            // FAR_MERGED (the level-3 finder): a position in 16 has a far candidate, so running its comparison inside the per-position
+            // code below means two instances per wave executed for a lane or two each.  Instead the near candidate and the recent-offset
+            // guesses are settled per position first, and ONE instance afterwards takes every lane's far candidate (of whichever of its
+            // two positions has one; a lane with two goes round again).  The model's order is near, far, guesses with ties to the earlier:
+            // merged last, the far candidate therefore wins a tie against a guess and loses one against the near candidate.
+            constexpr bool FAR_MERGED = NEAR16 && FAR_CDC && NFAR == 1;
+            uint32_t b_len[PER], b_off[PER], b_flags[PER], near_acc[PER]; // flags: 1 rep, 2 from a guess, 4 follower's near match, 8 far
+            int32_t b_score[PER];
 #pragma unroll
             for (int u = 0; u < PER; u++) {
                 const uint32_t idx = ZGE_IDX(u);
                 const uint32_t p = tile + idx;
                 mo[u] = 0; mw[u] = 0;
                 const uint32_t limit = idx < tcount ? (uint32_t)(be - p) : 0u, cap = limit < cap_max ? limit : cap_max;
-                uint32_t best_len = 0, best_off = 0;
-                bool best_rep = false;
+                uint32_t best_len = 0, best_off = 0, best_flags = 0;
                 int32_t best_score = -1000000;
-                uint64_t best_before = 0; // the 8 bytes in front of the best candidate's source
-                bool best_far = false;    // ... still to be fetched (far candidates are requested without them)
-                bool best_fol = false;    // the winner is a follower's handed-down near match: no backward extension (the positions in front of it belong to the same run)
-                // common prefix with the source `off` bytes back whose first 8 bytes are `first8`: 8 bytes per step, 16 per global round trip;
-                // reads past `cap` stay inside the staged window / the padded arena
-                auto prefix_len = [&](uint32_t off, uint64_t first8) -> uint32_t {
-                    uint64_t x = first8 ^ p8[u];
-                    uint32_t len = 0;
-                    while (!x && len + 8 < cap) {
-                        U128 sv;
-                        __builtin_memcpy(&sv, src + (p - off + len + 8), 16);
-                        const uint64_t a0 = zd::load_u64(tbb + (uint32_t)(p + len + 8 + wofs)), a1 = zd::load_u64(tbb + (uint32_t)(p + len + 16 + wofs));
-                        len += 8;
-                        x = a0 ^ sv.lo;
-                        if (!x && len + 8 < cap) { len += 8; x = a1 ^ sv.hi; }
-                    }
-                    len += x ? (uint32_t)(zd::ctz64(x) >> 3) : 8u;
-                    return len > cap ? cap : len;
-                };
                 uint32_t near_len = 0; // NEAR16: the near candidate's length -- compared by the heads, handed down to the followers
                 if (NEAR16) {
-                    if (offs[u][0] && !fol[u]) near_len = prefix_len(offs[u][0], q16[u].hi);
+                    if (offs[u][0] && !fol[u]) near_len = prefix_len(p, p8[u], cap, offs[u][0], q16[u].hi);
                     const uint64_t heads = zd::ballot(!fol[u]);                                  // lane 0 is never a follower
                     const uint32_t hl = 63u - (uint32_t)__clzll((long long)(heads & (~0ull >> (63 - lane)))); // the nearest head at or below this lane
                     const uint32_t handed = zd::shfl(near_len, (int)hl);
                     if (fol[u]) { const uint32_t j = (uint32_t)lane - hl; near_len = handed > j ? handed - j : 0u; }
                 }
+                near_acc[u] = 0;
 #pragma unroll
                 for (int k = 0; k < NTAB; k++) {
+                    if (FAR_MERGED && k >= 1) break;
                     const uint32_t off = offs[u][k];
                     if (!off) continue;
                     if (FAR_SKIP && k >= 1 && best_len >= (uint32_t)FAR_SKIP) continue; // with that many bytes in hand a far candidate is not looked at: it would be the tile's longest compare
                     const bool is_rep = off == erep0 || off == erep1;
-                    const uint32_t len = (NEAR16 && k < 1) ? near_len : prefix_len(off, k < 1 ? q16[u].hi : qf[u][k < 1 ? 0 : k - 1]);
+                    const uint32_t len = (NEAR16 && k < 1) ? near_len : prefix_len(p, p8[u], cap, off, k < 1 ? q16[u].hi : qf[u][k < 1 ? 0 : k - 1]);
                     if (len < (uint32_t)(is_rep ? F_MIN_REP : P.min_match)) continue;
                     const int32_t sc = score_of(P, len, off, is_rep);
-                    if (sc > best_score) { best_score = sc; best_len = len; best_off = off; best_rep = is_rep; best_far = k >= 1; best_fol = NEAR16 && k < 1 && fol[u]; if (k < 1) best_before = q16[u].lo; }
+                    if (sc > best_score) { best_score = sc; best_len = len; best_off = off; best_flags = (is_rep ? 1u : 0u) | ((NEAR16 && k < 1 && fol[u]) ? 4u : 0u) | (k >= 1 ? 8u : 0u); if (k < 1) near_acc[u] = len; }
                 }
-                bool from_guess = false;
                 { // the recent-offset guesses rank after the table candidates (ties keep the earlier candidate)
                     const uint32_t r = rres[u];
                     if (r) {
                         const uint32_t len = r & 0x1FFu;
                         const int32_t sc = score_of(P, len, 1, true);
-                        if (sc > best_score) { best_score = sc; best_len = len; best_off = (r >> 9) ? erep1 : erep0; best_rep = true; from_guess = true; best_far = false; best_fol = false; }
+                        if (sc > best_score) { best_score = sc; best_len = len; best_off = (r >> 9) ? erep1 : erep0; best_flags = 1u | 2u; }
                     }
                 }
+                b_len[u] = best_len; b_off[u] = best_off; b_flags[u] = best_flags; b_score[u] = best_score;
+            }
+            if (FAR_MERGED) {
+                uint32_t pend = (offs[0][1] ? 1u : 0u) | (offs[1][1] ? 2u : 0u);
+                while (zd::ballot(pend != 0)) { // uniform; usually one round, rarely two
+                    if (pend) {
+                        const int sel = (pend & 1u) ? 0 : 1;
+                        pend &= sel ? ~2u : ~1u;
+                        const uint32_t idx = sel ? ZGE_IDX(1) : ZGE_IDX(0);
+                        const uint32_t p = tile + idx;
+                        const uint32_t limit = (uint32_t)(be - p), cap = limit < cap_max ? limit : cap_max; // (a far candidate exists only for idx < tcount)
+                        const uint32_t off = sel ? offs[1][1] : offs[0][1];
+                        const uint64_t pv = sel ? p8[1] : p8[0], first8 = sel ? qf[1][0] : qf[0][0];
+                        const uint32_t nacc = sel ? near_acc[1] : near_acc[0];
+                        if (!(FAR_SKIP && nacc >= (uint32_t)FAR_SKIP)) {
+                            const bool is_rep = off == erep0 || off == erep1;
+                            const uint32_t len = prefix_len(p, pv, cap, off, first8);
+                            if (len >= (uint32_t)(is_rep ? F_MIN_REP : P.min_match)) {
+                                const int32_t sc = score_of(P, len, off, is_rep);
+                                const int32_t cur = sel ? b_score[1] : b_score[0];
+                                const uint32_t cfl = sel ? b_flags[1] : b_flags[0];
+                                if ((cfl & 2u) ? sc >= cur : sc > cur) {
+                                    const uint32_t nf = (is_rep ? 1u : 0u) | 8u;
+                                    if (sel) { b_score[1] = sc; b_len[1] = len; b_off[1] = off; b_flags[1] = nf; }
+                                    else { b_score[0] = sc; b_len[0] = len; b_off[0] = off; b_flags[0] = nf; }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < PER; u++) {
+                const uint32_t idx = ZGE_IDX(u);
+                const uint32_t p = tile + idx;
+                const uint32_t best_len = b_len[u], best_off = b_off[u];
+                const int32_t best_score = b_score[u];
+                const bool best_rep = b_flags[u] & 1u, from_guess = b_flags[u] & 2u, best_fol = b_flags[u] & 4u, best_far = b_flags[u] & 8u;
                 if (best_len && best_score > 0) {
                     // backward-extension potential: equal bytes just before the match and its source (none next to the frame start).  Far
-                    // candidates, found up to 2^FAR_STEP_LOG + 2^FAR_RES_LOG - 2 positions into a repeat, may go back FAR_BACK bytes.
+                    // candidates, found some way into a repeat, may go back FAR_BACK bytes.
                     const uint32_t q = p - best_off;
                     const uint32_t bcap = (NFAR && best_far) ? (uint32_t)FAR_BACK : (uint32_t)F_BACK_CAP;
                     uint32_t maxb = bcap;
                     if (p - bs < maxb) maxb = (uint32_t)(p - bs);
                     uint32_t back = 0;
                     if (maxb && q >= bcap && !best_fol) { // then p - bcap and (for a guess) q - 8 are inside the staged window
+                        uint64_t best_before = q16[u].lo; // the 8 bytes in front of the near candidate's source came with its first request
                         if (from_guess) best_before = zd::load_u64(tbb + (uint32_t)(q - 8 + wofs));
                         if (NFAR && best_far) best_before = zd::load_u64(src + (q - 8));
                         const uint64_t x = zd::load_u64(tbb + (uint32_t)(p - 8 + wofs)) ^ best_before;
