@@ -4,6 +4,21 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+// ... and in which order do same-address LDS atomics WITH RETURN of one instruction execute?  (zge_entropy.hip, FSE state tables: every
+// cell takes the next slot of its symbol; 64 cells per instruction need increasing slots in lane order.)
+__global__ void k_add(const uint32_t *slots, uint32_t *out, int rounds)
+{
+    __shared__ uint32_t cnt[4096];
+    const int lane = threadIdx.x;
+    for (int r = 0; r < rounds; r++) {
+        const uint32_t s = slots[r * 64 + lane] & 4095;
+        cnt[s] = 0;
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        out[r * 64 + lane] = atomicAdd(&cnt[s], 1u);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
 __global__ void k(const uint32_t *slots, uint32_t *out16, uint32_t *out32, int rounds)
 {
     __shared__ uint16_t t16[4096];
@@ -49,6 +64,20 @@ int main()
             if (w16 == maxl) hi16++; else if (w16 == minl) lo16++; else other16++;
             if (w32 == maxl) hi32++; else if (w32 == minl) lo32++; else other32++;
         }
+    { // atomics with return: the value a lane gets must be the number of LOWER lanes with the same slot
+        uint32_t *oa, *ra = (uint32_t *)malloc(R * 64 * 4);
+        hipMalloc(&oa, R * 64 * 4);
+        hipLaunchKernelGGL(k_add, dim3(1), dim3(64), 0, 0, d, oa, R);
+        hipMemcpy(ra, oa, R * 64 * 4, hipMemcpyDeviceToHost);
+        long ok = 0, bad = 0;
+        for (int r = 0; r < R; r++)
+            for (int l = 0; l < 64; l++) {
+                uint32_t below = 0;
+                for (int j = 0; j < l; j++) below += (h[r * 64 + j] & 4095) == (h[r * 64 + l] & 4095);
+                if (ra[r * 64 + l] == below) ok++; else bad++;
+            }
+        printf("atomic add with return: lane order %ld, other %ld\n", ok, bad);
+    }
     printf("contested slots %ld | b16: highest lane wins %ld, lowest %ld, other %ld | b32: highest %ld, lowest %ld, other %ld\n", groups, hi16, lo16, other16, hi32, lo32, other32);
     return 0;
 }

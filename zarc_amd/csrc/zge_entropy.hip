@@ -167,6 +167,67 @@ __device__ void fse_build_ctab(FseCtab &t, const int16_t *norm, int nsym, int al
     }
     t.al = al;
 }
+// The same table built by the whole wave (uniform call; norm[] / nsym / al as above, `cellsym` >= 2^al bytes of LDS scratch):
+//   starts      an exclusive prefix sum of the symbols' cell counts (a "less than one" symbol, norm -1, has one cell)
+//   spread      the j-th visited position is (j * step) mod T, positions above `high` (the less-than-one symbols' cells at the top) are
+//               skipped: every lane takes T/64 consecutive j, a wave scan of the valid counts gives each valid j its occupant rank,
+//               a binary search over the starts the rank's symbol -- instead of T dependent steps on one lane
+//   state table every cell takes the next slot of its symbol: 64 cells per ds_add_rtn; same-address LDS atomics of one instruction
+//               execute in lane order (measured: tools/micro/lds_write_order.hip, 1 280 000 lanes; pinned on every GPU box by
+//               tests/test_gpu_parity.py::test_gpu_lds_same_address_stores_keep_the_highest_lane), so cells in rising order get rising
+//               slots, as the serial loop gives them
+//   per symbol  dnb / dfs, one lane per symbol
+__device__ void fse_build_ctab_wave(FseCtab &t, const int16_t *norm, int nsym, int al, uint8_t *cellsym, int lane)
+{
+    const int T = 1 << al, step = (T >> 1) + (T >> 3) + 3, mask = T - 1;
+    // cell counts and their exclusive prefix (nsym <= 64: one symbol per lane)
+    const int n_l = lane < nsym ? (int)norm[lane] : 0;
+    const uint32_t cells_l = n_l == -1 ? 1u : (uint32_t)n_l;          // all cells of this symbol (state-table slots)
+    const uint32_t reg_l = n_l > 0 ? (uint32_t)n_l : 0u;              // its cells in the spread region
+    const uint32_t start_all = zd::wave_scan_incl(cells_l) - cells_l;
+    const uint32_t start_reg = zd::wave_scan_incl(reg_l) - reg_l;
+    const uint64_t lowm = zd::ballot(n_l == -1);
+    const int nlow = (int)__popcll(lowm), high = T - 1 - nlow;
+    if (n_l == -1) cellsym[T - 1 - (int)__popcll(lowm & ((1ull << lane) - 1))] = (uint8_t)lane; // the first less-than-one symbol takes the top cell
+    if (lane < nsym) { t.dfs[lane] = (int32_t)start_all; t.dnb[lane] = (int32_t)start_reg; }     // dnb[] doubles as the spread starts for the search below
+    zd::wave_sync();
+    {
+        const int per = T >= 64 ? T / 64 : 1;
+        const int j0 = lane * per;
+        uint32_t valid = 0; // bit q: position of j0 + q is in the spread region
+        if (j0 < T) for (int q = 0; q < per; q++) if ((((j0 + q) * step) & mask) <= high) valid |= 1u << q;
+        const uint32_t cnt = (uint32_t)__popc(valid);
+        uint32_t rank = zd::wave_scan_incl(cnt) - cnt;
+        for (int q = 0; q < per; q++) {
+            if (!((valid >> q) & 1)) continue;
+            // the symbol whose spread range holds this rank: the last symbol with start_reg <= rank and a positive count
+            int lo = 0, hi = nsym - 1;
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if ((uint32_t)t.dnb[mid] <= rank) lo = mid; else hi = mid - 1; }
+            while (norm[lo] <= 0) lo--; // symbols without cells in the region share their successor's start: step back to the owner
+            cellsym[((j0 + q) * step) & mask] = (uint8_t)lo;
+            rank++;
+        }
+    }
+    zd::wave_sync();
+    for (int i0 = 0; i0 < T; i0 += 64) {
+        const int i = i0 + lane;
+        if (i < T) { const int slot = atomicAdd(&t.dfs[cellsym[i]], 1); t.state_tab[slot] = (uint16_t)(T + i); }
+        zd::wave_lds_order(); // one instruction's 64 cells before the next one's (program order on hardware; the emulator runs lanes one after another)
+    }
+    zd::wave_sync();
+    if (lane < nsym) {
+        const int n = n_l, total = (int)start_all;
+        if (n == 0) { t.dnb[lane] = ((al + 1) << 16) - T; t.dfs[lane] = 0; }
+        else if (n == -1 || n == 1) { t.dnb[lane] = (al << 16) - T; t.dfs[lane] = total - 1; }
+        else {
+            const int max_bits_out = al - zd::hb32((uint32_t)(n - 1));
+            t.dnb[lane] = (max_bits_out << 16) - (n << max_bits_out);
+            t.dfs[lane] = total - n;
+        }
+    }
+    t.al = al;
+    zd::wave_sync();
+}
 __device__ __forceinline__ uint32_t fse_init_state(const FseCtab &t, int s)
 {
     const int nb = (t.dnb[s] + (1 << 15)) >> 16;
@@ -824,10 +885,29 @@ __global__ void __launch_bounds__(64, 5) zarc_zge_entropy(uint32_t n_blocks, uin
                 const int16_t *def = which == 0 ? E_LL_DEFAULT : (which == 1 ? E_OF_DEFAULT : E_ML_DEFAULT);
                 choose_table(L, which, cnt, which == 0 ? 35 : (which == 1 ? 31 : 52), nseq, def, which == 0 ? 36 : (which == 1 ? 29 : 53),
                              which == 1 ? 5 : 6, which == 1 ? 8 : 9);
+            }
+            zd::wave_sync();
+            // ... and the whole wave builds them, one after the other (round 3: the serial build on three lanes was a sixth of the stage)
+#pragma unroll
+            for (int which = 0; which < 3; which++) {
                 FseCtab tt = which == 0 ? FseCtab{L.s.st + ST_LL, L.s.dnb_ll, L.s.dfs_ll, 0}
                                         : (which == 1 ? FseCtab{L.s.st + ST_OF, L.s.dnb_of, L.s.dfs_of, 0} : FseCtab{L.s.st + ST_ML, L.s.dnb_ml, L.s.dfs_ml, 0});
-                uint8_t *cells = (uint8_t *)L.s.pre + (which == 0 ? 0 : (which == 1 ? 512 : 768)); // 512 + 256 + 512 bytes
-                if (L.ctrl[X_MODE_L + which] != 1) fse_build_ctab(tt, L.s.norm[which], L.ctrl[X_NSYM_L + which], L.ctrl[X_AL_L + which], cells);
+                uint8_t *cells = (uint8_t *)L.s.pre; // 512 bytes of scratch, idle until the chains
+                if (L.ctrl[X_MODE_L + which] != 1) fse_build_ctab_wave(tt, L.s.norm[which], L.ctrl[X_NSYM_L + which], L.ctrl[X_AL_L + which], cells, lane);
+#ifdef ZGE_DEBUG_FSE
+                if (L.ctrl[X_MODE_L + which] != 1 && lane == 0) {
+                    static thread_local uint16_t st2[512]; static thread_local int32_t dnb2[64], dfs2[64]; static thread_local uint8_t cs2[512];
+                    FseCtab t2 = {st2, dnb2, dfs2, 0};
+                    const int nsym = L.ctrl[X_NSYM_L + which], al = L.ctrl[X_AL_L + which];
+                    fse_build_ctab(t2, L.s.norm[which], nsym, al, cs2);
+                    bool bad = false;
+                    for (int i = 0; i < (1 << al); i++) bad |= st2[i] != tt.state_tab[i];
+                    for (int i = 0; i < nsym; i++) bad |= dnb2[i] != tt.dnb[i] || dfs2[i] != tt.dfs[i];
+                    if (bad) { for (int i = 0; i < (1 << al); i++) if (st2[i] != tt.state_tab[i]) { printf("st[%d] serial %d wave %d; ", i, st2[i], tt.state_tab[i]); break; }
+                        for (int i = 0; i < nsym; i++) if (dnb2[i] != tt.dnb[i] || dfs2[i] != tt.dfs[i]) { printf("sym %d dnb %d/%d dfs %d/%d; ", i, dnb2[i], tt.dnb[i], dfs2[i], tt.dfs[i]); break; }
+                        printf("FSE mismatch which %d al %d nsym %d mode %d:", which, al, nsym, L.ctrl[X_MODE_L + which]); for (int i = 0; i < nsym; i++) printf(" %d", L.s.norm[which][i]); printf("\n"); }
+                }
+#endif
             }
             zd::wave_sync();
             ENT_PROF(4);
