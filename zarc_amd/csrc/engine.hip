@@ -9,6 +9,7 @@
 #include "../../include/zarc_gpu.h"
 #include "zarc_kernels.h"
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -87,6 +88,8 @@ struct zarc_gpu {
     uint64_t stage_chunk = 0;  // 0 = default per entry point (ZARC_GPU_PX_STAGE_CHUNK)
     int stage_thread = 1;      // ZARC_GPU_PX_STAGE_THREAD
     int copy_threads = 8;      // ZARC_GPU_PX_COPY_THREADS
+    uint8_t *meta_pin = nullptr; // page-locked arena for descriptor uploads (meta_take)
+    size_t meta_cap = 0, meta_used = 0;
     int zero_copy = 4096;      // ZARC_GPU_PX_ZERO_COPY: page-locked caller memory in runs of this many KiB on average is read / written by the DMA engines directly (0 = never)
 };
 
@@ -186,18 +189,34 @@ struct Timer {
     hipError_t mark(int *idx) { *idx = next; return hipEventRecord(h->ev[next++], h->stream); }
 };
 
-int upload_u64(zarc_gpu *h, DevBuf &b, const uint64_t *src, size_t n)
+// Per-entry descriptor arrays travel through a page-locked arena of the handle: an asynchronous copy out of ordinary memory is staged
+// by the runtime at a fraction of the link rate, and a call over half a million entries spent 27 ms in five such copies.  The arena is
+// reset where a call begins (every batch call ends with its stream synchronised) and grows to the largest call's needs.
+void *meta_take(zarc_gpu *h, size_t bytes)
 {
-    ZHIP(b.reserve(std::max<size_t>(n, 1) * 8));
-    if (n) ZHIP(hipMemcpyAsync(b.p, src, n * 8, hipMemcpyHostToDevice, h->stream));
+    bytes = (bytes + 63) & ~(size_t)63;
+    if (bytes < 65536) return nullptr; // small arrays: the runtime's own staging is as good
+    if (h->meta_used + bytes > h->meta_cap) {
+        if (h->meta_used) return nullptr; // part of it is in flight: this array goes the ordinary way, the next call starts with more room
+        if (h->meta_pin) { (void)hipHostFree(h->meta_pin); h->meta_pin = nullptr; h->meta_cap = 0; }
+        const size_t want = std::max<size_t>(bytes * 20, (size_t)16 << 20); // the first array of a call has 8 bytes per entry; an unpack moves about 130
+        if (hipHostMalloc((void **)&h->meta_pin, want, 0) != hipSuccess) { (void)hipGetLastError(); h->meta_pin = nullptr; return nullptr; }
+        h->meta_cap = want;
+    }
+    void *p = h->meta_pin + h->meta_used;
+    h->meta_used += bytes;
+    return p;
+}
+int upload_bytes(zarc_gpu *h, DevBuf &b, const void *src, size_t bytes)
+{
+    ZHIP(b.reserve(std::max<size_t>(bytes, 8)));
+    if (!bytes) return 0;
+    if (void *pin = meta_take(h, bytes)) { memcpy(pin, src, bytes); src = pin; }
+    ZHIP(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, h->stream));
     return 0;
 }
-int upload_u32(zarc_gpu *h, DevBuf &b, const uint32_t *src, size_t n)
-{
-    ZHIP(b.reserve(std::max<size_t>(n, 1) * 4));
-    if (n) ZHIP(hipMemcpyAsync(b.p, src, n * 4, hipMemcpyHostToDevice, h->stream));
-    return 0;
-}
+int upload_u64(zarc_gpu *h, DevBuf &b, const uint64_t *src, size_t n) { return upload_bytes(h, b, src, n * 8); }
+int upload_u32(zarc_gpu *h, DevBuf &b, const uint32_t *src, size_t n) { return upload_bytes(h, b, src, n * 4); }
 
 // BLAKE3 of n entries described by device arrays d_off/d_len (already uploaded); result in h->d_digests
 // `side` (pack): the two kernels go to the low-priority side stream behind an event of the engine stream -- the caller launches the
@@ -262,6 +281,7 @@ int check_common(zarc_gpu *h, size_t n)
     if (n > 0x7FFFFFFFu) { set_error(h, "batch too large"); return ZARC_GPU_E_PARAM; }
     ZHIP(hipSetDevice(h->device));
     for (int i = 0; i < ZARC_GPU_T_COUNT; i++) h->ms[i] = -1.f;
+    h->meta_used = 0; // every batch call ends with its stream synchronised: what the arena held has been copied
     return 0;
 }
 
@@ -335,6 +355,7 @@ void zarc_gpu_destroy(zarc_gpu_t *h)
     if (h->ev_join3) (void)hipEventDestroy(h->ev_join3);
     for (int i = 0; i < zarc_gpu::PIN_SLOTS; i++) { if (h->pin[i]) (void)hipHostFree(h->pin[i]); if (h->pin_ev[i]) (void)hipEventDestroy(h->pin_ev[i]); }
     h->d_dense.release(); h->d_goff.release(); h->d_glen.release(); h->d_gdense.release();
+    if (h->meta_pin) (void)hipHostFree(h->meta_pin);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     delete h;
@@ -479,6 +500,15 @@ int pack_device_impl(zarc_gpu_t *h, size_t n, const void *d_src_base, const uint
     if (n == 0) return ZARC_GPU_OK;
     if (!d_src_base || !src_off || !src_len || !d_dst || !dst_off || !dst_len || (!digest && !have_digests)) return ZARC_GPU_E_PARAM;
     ZgeParams P = derive_params(h->params); // (slot_bytes is set per sub-batch below)
+#ifdef ZARC_GPU_DIAG
+    // host-side phase clock of this call (ZARC_GPU_DBG & 512): where a call over a million entries spends its time outside the kernels
+    double hp[8] = {0};
+    auto hnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double hlast = hnow();
+#define HOST_PHASE(i) do { const double n_ = hnow(); hp[i] += n_ - hlast; hlast = n_; } while (0)
+#else
+#define HOST_PHASE(i) do { } while (0)
+#endif
     // the match finder has these compiled in (zge_match.hip: F_*)
     if (P.rep_back != 256 || P.back_cap != 8 || P.lazy_delta != 5 || P.min_rep != 3 || P.rep_search != 2 || P.seg_log != 21 || P.short_window_log < 30 ||
         P.lit_cost != 5 || P.rep_cost != 9 || P.tag_bits != 10 || P.far_log != 16 || P.match_cost != (P.long_log == 14 ? 10 : 12) || P.far_ways != (P.long_log == 14 ? 2 : 1) ||
@@ -539,7 +569,9 @@ int pack_device_impl(zarc_gpu_t *h, size_t n, const void *d_src_base, const uint
     bool xxh_joined = false;
 
     // ---- encoder: frames sorted by size (largest first), processed in sub-batches that fit the scratch budget ----
+    HOST_PHASE(0); // checks, descriptor uploads, checksum + digest set-up
     const std::vector<uint32_t> order = order_by_size_desc(src_len, n);
+    HOST_PHASE(1); // size ordering
     auto per_block_of = [](uint32_t slot) { return (size_t)(zge_seq_stride(slot) * 8 + zge_lit_stride(slot) + zge_out_stride(slot) + sizeof(ZgeBlock)); };
     size_t budget = h->scratch_budget;
     if (!budget) {
@@ -612,6 +644,7 @@ int pack_device_impl(zarc_gpu_t *h, size_t n, const void *d_src_base, const uint
         }
         const size_t n_units = units.size() / 2;
         if ((rc = upload_u32(h, h->d_units, units.data(), units.size()))) return rc;
+        HOST_PHASE(2); // sub-batch lists + uploads
         const size_t match_grid = std::min<size_t>(n_units, (size_t)h->num_cus * (deep ? 1 : 2)); // two 80 KiB workgroups fit a CU, one of 145 KiB
         ZHIP(h->d_far.reserve(match_grid * zge_far_words(P) * 4 + 16)); // one far-table slab per resident workgroup (cleared by the kernel per frame)
         // The digest kernels (low-priority stream, queued behind the FIRST sub-batch's match launch) must be off the chip before another
@@ -648,7 +681,9 @@ int pack_device_impl(zarc_gpu_t *h, size_t n, const void *d_src_base, const uint
                            (uint8_t *)d_dst, h->d_dst_off.as<uint64_t>(), h->d_dst_len.as<uint64_t>());
         ZHIP(hipGetLastError());
         ZHIP(t.mark(&d));
+        HOST_PHASE(3); // launches
         ZHIP(hipStreamSynchronize(h->stream)); // the scratch is reused by the next sub-batch; also bounds the event pool
+        HOST_PHASE(4); // waiting for the kernels
         if (P.dbg & 1024) { // stage timing of the match finder (diagnostics)
             unsigned long long prof[12];
             ZHIP(hipMemcpy(prof, (const char *)h->d_queue.p + 8, sizeof prof, hipMemcpyDeviceToHost));
@@ -674,6 +709,10 @@ int pack_device_impl(zarc_gpu_t *h, size_t n, const void *d_src_base, const uint
     if (!have_digests) ZHIP(hipMemcpyAsync(digest, h->d_digests.p, n * 32, hipMemcpyDeviceToHost, h->stream));
     ZHIP(hipStreamSynchronize(h->stream));
     if (status) for (size_t i = 0; i < n; i++) status[i] = ZARC_GPU_FRAME_OK;
+    HOST_PHASE(5); // results back
+#ifdef ZARC_GPU_DIAG
+    if (P.dbg & 512) fprintf(stderr, "pack host phases (ms): setup %.2f order %.2f lists %.2f launch %.2f wait %.2f results %.2f\n", hp[0], hp[1], hp[2], hp[3], hp[4], hp[5]);
+#endif
     if (have_digests) h->ms[ZARC_GPU_T_BLAKE3] = 0;
     else { float ms = -1.f; if (hipEventElapsedTime(&ms, h->ev_b3[0], h->ev_b3[1]) == hipSuccess) h->ms[ZARC_GPU_T_BLAKE3] = ms; } // side stream: queue wait + kernels
     h->ms[ZARC_GPU_T_XXH64] = elapsed(h, 14, 15); // side stream: overlaps the match finder, not part of the total
@@ -763,11 +802,12 @@ int unpack_device_once(zarc_gpu_t *h, size_t n, const void *d_frames_base, const
     ZHIP(h->d_status.reserve(n * 4));
     ZHIP(h->d_stored_ck.reserve(n * 8));
     std::vector<uint8_t> expect;
-    if (expect_in) {
-        expect.resize(n * 32);
-        for (size_t i = 0; i < n; i++) memcpy(&expect[i * 32], expect_in + (size_t)order[i] * 32, 32);
+    if (expect_in) { // reordered straight into the page-locked descriptor arena when it has room (32 bytes per frame: the largest array of the call)
+        uint8_t *ex = (uint8_t *)meta_take(h, n * 32);
+        if (!ex) { expect.resize(n * 32); ex = expect.data(); }
+        for (size_t i = 0; i < n; i++) memcpy(ex + i * 32, expect_in + (size_t)order[i] * 32, 32);
         ZHIP(h->d_expect.reserve(n * 32));
-        ZHIP(hipMemcpyAsync(h->d_expect.p, expect.data(), n * 32, hipMemcpyHostToDevice, h->stream));
+        ZHIP(hipMemcpyAsync(h->d_expect.p, ex, n * 32, hipMemcpyHostToDevice, h->stream));
     }
     Timer t{h};
     int e0, e1, e3;
@@ -1043,12 +1083,16 @@ int unpack_device_once(zarc_gpu_t *h, size_t n, const void *d_frames_base, const
                        h->d_stored_ck.as<uint32_t>(), h->d_digests.as<uint32_t>(), expect_in ? h->d_expect.as<uint32_t>() : (const uint32_t *)nullptr,
                        h->d_status.as<int32_t>());
     ZHIP(hipGetLastError());
-    std::vector<int32_t> st(n);
-    std::vector<uint8_t> dg(n * 32);
-    ZHIP(hipMemcpyAsync(st.data(), h->d_status.p, n * 4, hipMemcpyDeviceToHost, h->stream));
-    ZHIP(hipMemcpyAsync(dg.data(), h->d_digests.p, n * 32, hipMemcpyDeviceToHost, h->stream));
+    std::vector<int32_t> st_v;
+    std::vector<uint8_t> dg_v;
+    int32_t *st = (int32_t *)meta_take(h, n * 4); // results come back through the page-locked arena too, then go to the caller's order
+    uint8_t *dg = (uint8_t *)meta_take(h, n * 32);
+    if (!st) { st_v.resize(n); st = st_v.data(); }
+    if (!dg) { dg_v.resize(n * 32); dg = dg_v.data(); }
+    ZHIP(hipMemcpyAsync(st, h->d_status.p, n * 4, hipMemcpyDeviceToHost, h->stream));
+    ZHIP(hipMemcpyAsync(dg, h->d_digests.p, n * 32, hipMemcpyDeviceToHost, h->stream));
     ZHIP(hipStreamSynchronize(h->stream));
-    for (size_t i = 0; i < n; i++) { status[order[i]] = st[i]; memcpy(digest + (size_t)order[i] * 32, &dg[i * 32], 32); }
+    for (size_t i = 0; i < n; i++) { status[order[i]] = st[i]; memcpy(digest + (size_t)order[i] * 32, dg + i * 32, 32); }
     if (fastpath && diag_env("ZARC_GPU_DEC_STATS", 0)) { // diagnostics: how many frames had their sequences decoded ahead
         std::vector<uint32_t> fl(n);
         ZHIP(hipMemcpy(fl.data(), h->d_fast.p, n * 4, hipMemcpyDeviceToHost));
