@@ -957,7 +957,7 @@ void zge_default_params(zge_params *P, int level)
     P->back_cap = 8; P->lazy = level >= 2 || level == 0 ? 1 : 0; P->lazy_delta = 5; /* engine.hip: derive_params */
     P->lit_cost = 5; P->match_cost = 12; P->rep_cost = 9;
     P->window_log = 21; P->short_window_log = 30;
-    P->far_log = 16; P->far_ways = 1; P->far_step_log = 5; P->far_res_log = 2; P->far_short = 0; P->far_skip = 64; P->far_back = 32;
+    P->far_log = 16; P->far_ways = 1; P->far_step_log = 5; P->far_res_log = 2; P->far_short = 0; P->far_skip = 64; P->far_back = 48;
     P->far_min_frame = 65536;
     P->near16 = 1; P->short_log = 15; P->far_cdc_log = 4; /* round 3: one 16-bit near table of 2^15 entries, content-defined far sampling */
     if (level >= 9) { /* the engine's deep finder (engine.hip: derive_params) */

@@ -114,7 +114,7 @@ def reloc_like(n, seed=3):
 # prints every item with its ratio, so the table below is always next to the numbers it excuses.
 CONTRACT = 1.05
 EXCEPTIONS = {
-    (3, "hsaco_2m"): (1.38, "GPU code objects (thousands of near-identical kernels, 70x compressible): repeats of 10 - 40 bytes at MiB "
+    (3, "hsaco_2m"): (1.22, "GPU code objects (thousands of near-identical kernels, 70x compressible): repeats of 10 - 40 bytes at MiB "
                             "distances; libzstd's 2^17-entry long table holds every position, the sampled far table one in 16"),
     (9, "elf_head_4m"): (1.09, "level 9: libzstd's lazy2 parser tries the live repeat offset at every position; the tile-parallel finder "
                                "knows the previous tile's"),

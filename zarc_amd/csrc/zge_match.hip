@@ -1027,7 +1027,7 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                                                       uint32_t *__restrict__ far_scratch)
 {
     __shared__ MatchLds<15, true> L;
-    zge_match_body<15, 5, 12, 16, 1, false, 5, 2, 64, 32, false, true, 4>(L, P, src_base, src_off, src_len, order, units, n_units, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
+    zge_match_body<15, 5, 12, 16, 1, false, 5, 2, 64, 48, false, true, 4>(L, P, src_base, src_off, src_len, order, units, n_units, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
 }
 
 #ifdef ZARC_GPU_DIAG
@@ -1040,7 +1040,7 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match_diag(ZgeParams P, const
                                                            uint32_t *__restrict__ far_scratch)
 {
     __shared__ MatchLds<15, true> L;
-    zge_match_body<15, 5, 12, 16, 1, false, 5, 2, 64, 32, true, true, 4>(L, P, src_base, src_off, src_len, order, units, n_units, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
+    zge_match_body<15, 5, 12, 16, 1, false, 5, 2, 64, 48, true, true, 4>(L, P, src_base, src_off, src_len, order, units, n_units, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
 }
 #endif
 
