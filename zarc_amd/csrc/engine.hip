@@ -685,12 +685,12 @@ int pack_device_impl(zarc_gpu_t *h, size_t n, const void *d_src_base, const uint
         ZHIP(hipStreamSynchronize(h->stream)); // the scratch is reused by the next sub-batch; also bounds the event pool
         HOST_PHASE(4); // waiting for the kernels
         if (P.dbg & 1024) { // stage timing of the match finder (diagnostics)
-            unsigned long long prof[12];
+            unsigned long long prof[14];
             ZHIP(hipMemcpy(prof, (const char *)h->d_queue.p + 8, sizeof prof, hipMemcpyDeviceToHost));
             unsigned long long tot = 0;
-            for (int i = 0; i < 12; i++) tot += prof[i];
+            for (int i = 0; i < 14; i++) tot += prof[i];
             fprintf(stderr, "zge_match stage ticks (%% of %llu):", tot);
-            for (int i = 0; i < 12; i++) fprintf(stderr, " %d:%.1f", i, tot ? 100.0 * (double)prof[i] / (double)tot : 0.0);
+            for (int i = 0; i < 14; i++) fprintf(stderr, " %d:%.1f", i, tot ? 100.0 * (double)prof[i] / (double)tot : 0.0);
             fprintf(stderr, "\n");
             ZHIP(hipMemcpy(prof, (const char *)h->d_queue.p + 128, 6 * 8, hipMemcpyDeviceToHost));
             tot = 0;

@@ -73,7 +73,7 @@ template <int TAB_LOG, bool NEAR16> struct MatchLds {
     uint32_t tb[2][(TB_BYTES + 3) / 4]; // the window of a tile lives in buffer (tile / TILE) & 1: the current tile's and the next one's
     uint32_t wcnt[CHUNKS];       // S6: selected matches << 16 | literals of each chunk
     uint32_t ctrl[16];
-    unsigned long long prof[12]; // ZARC_GPU_DBG & 1024: shader-clock ticks per stage, workgroup view from thread 0
+    unsigned long long prof[14]; // ZARC_GPU_DBG & 1024: shader-clock ticks per stage, workgroup view from thread 0
 };
 enum { K_POS = 0, K_REP0 = 1, K_REP1 = 2, K_FLAG = 3, K_SLOT = 4, K_ANY = 5 };
 
@@ -187,7 +187,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG, NEAR16> &L, con
     const uint32_t seg_mask = (1u << F_SEG_LOG) - 1;
     const uint32_t cap_max = (uint32_t)(P.cap < CAP_MAX ? P.cap : CAP_MAX);
     unsigned long long tprev = ZGE_CLOCK();
-    if (tid < 12) L.prof[tid] = 0;
+    if (tid < 14) L.prof[tid] = 0;
 
     // Persistent workgroups: the grid is what the chip holds at once (two per CU); every workgroup takes the next UNIT from a queue
     // (largest frames first), so slow and fast frames balance across XCDs whatever their order in the batch.  A unit is one 2^seg_log
@@ -815,13 +815,24 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG, NEAR16> &L, con
                 const uint32_t len = mw[u] & 0xFFFF, back = (mw[u] >> 16) & 0xFF;
                 if (len && back && !(dbg & 8)) {
                     const bool rep = (mw[u] >> 24) & 1;
-                    for (uint32_t k = 1; k <= back && k <= idx; k++) {
-                        const int32_t sc = score_of(P, len + k, mo[u], rep);
+                    // the first eight distances (all a near candidate or a guess can have) as straight-line predicated code: the loop's
+                    // bookkeeping -- compare, mask, two branches per trip -- was twice the work of the offers themselves, 9 % of the kernel
+                    const int32_t base = score_of(P, len, mo[u], rep); // the score is linear in the length: + lit_cost per byte
+                    const uint32_t lim = back < idx ? back : idx;
+#pragma unroll
+                    for (uint32_t k = 1; k <= (uint32_t)F_BACK_CAP; k++) {
+                        const int32_t sc = base + LIT_COST * (int32_t)k;
+                        if (k <= lim && sc > 0) atomicMax(&L.ex[idx - k], ((uint32_t)sc << 6) | (63u - k));
+                    }
+                    for (uint32_t k = (uint32_t)F_BACK_CAP + 1; k <= lim; k++) { // far candidates reach further back
+                        const int32_t sc = base + LIT_COST * (int32_t)k;
                         if (sc > 0) atomicMax(&L.ex[idx - k], ((uint32_t)sc << 6) | (63u - k));
                     }
                 }
             }
+            ZGE_PROF(12); // (diagnostics: the backward offers; stage 4 below is then the wait for the requests and for the slowest wave)
             if (NFAR) zd::wait_vmem(); // the next tile's entries are in registers before any wave sends this tile's inserts
+            ZGE_PROF(13);
             zd::lds_barrier(); // own matches (a0) and offers (ex) are complete
             ZGE_PROF(4);
             if (NFAR) {
@@ -1016,7 +1027,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG, NEAR16> &L, con
         zd::lds_barrier();
     }
     } // next frame from the queue
-    if ((dbg & 1024) && tid < 12) atomicAdd((unsigned long long *)(queue + 2) + tid, L.prof[tid]);
+    if ((dbg & 1024) && tid < 14) atomicAdd((unsigned long long *)(queue + 2) + tid, L.prof[tid]);
 }
 #undef score_of
 
