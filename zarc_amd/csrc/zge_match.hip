@@ -959,21 +959,25 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG, NEAR16> &L, con
                     // visited (uniform loop on the scalar unit, one v_readlane per match)
                     const uint64_t tk = zd::ballot(take[u]);
                     const uint32_t span = cend > cbase ? cend - cbase : 0u; // positions of this chunk inside the tile
+                    // The scalar loop only collects the selected matches (find the next take flag at or after the cursor, jump to its
+                    // successor): five or six scalar instructions and a v_readlane per match.  The literals are what is left: a position
+                    // at or after the chunk's entry that is no selected match and does not lie inside the nearest selected match below
+                    // it -- one ds_bpermute for the whole chunk instead of two 64-bit masks built per match.
                     uint64_t sel = 0, lits = 0;
+                    const uint32_t entry = cur; // where the path enters this chunk (>= cend: it does not)
                     if (!(dbg & 2)) {
                         while (cur < cend) {
-                            const uint32_t rel = cur - cbase;
-                            const uint64_t ahead = tk >> rel;              // take flags at or after the cursor
-                            if (ahead == 0) {                              // only literals up to the end of the chunk
-                                lits |= ((span >= 64 ? ~0ull : ((1ull << span) - 1)) >> rel) << rel;
-                                cur = cend;
-                                break;
-                            }
-                            const uint32_t q = rel + (uint32_t)zd::ctz64(ahead);
-                            lits |= (((1ull << q) - 1) >> rel) << rel;     // literals [rel, q)
+                            const uint64_t ahead = tk & (~0ull << (cur - cbase)); // take flags at or after the cursor
+                            if (ahead == 0) { cur = cend; break; }                // only literals up to the end of the chunk
+                            const uint32_t q = (uint32_t)zd::ctz64(ahead);
                             sel |= 1ull << q;
                             cur = zd::readlane(nx[u], q);
                         }
+                        const uint64_t below = sel & lt;                          // selected matches below this lane
+                        const uint32_t qs = below ? 63u - (uint32_t)__clzll((long long)below) : 0u;
+                        const uint32_t over = zd::shfl(nx[u], (int)qs);           // where the nearest one below ends
+                        const uint32_t me = cbase + (uint32_t)lane;
+                        lits = zd::ballot(me >= entry && (uint32_t)lane < span && !((sel >> lane) & 1) && (!below || over <= me));
                     }
                     msel[u] = sel;
                     mlit[u] = lits;
