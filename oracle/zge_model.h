@@ -48,6 +48,9 @@ typedef struct {
                          occurrences of a repeat sample the same relative positions, so a repeat is found if it contains one sample */
     int far_min_frame; /* frames of at most this many bytes do without the far table (the 16-bit near table reaches 64 KiB): the engine
                           then has no 256 KiB slab to clear per frame -- what a batch of small entries spent most of its time on */
+    /* Round 3, the level >= 9 finder: */
+    int rep_pass;     /* rounds of the live recent-offset pass per tile (zstd_enc_model.c: matchfind_block), 0 = none */
+    int lazy2_delta;  /* > 0: a selected match also steps aside for one two bytes ahead that scores more than this much higher */
 } zge_params;
 
 typedef struct { uint32_t ll, ml, off, ofv; } zge_seq;

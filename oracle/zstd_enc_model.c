@@ -736,6 +736,7 @@ static uint32_t matchfind_block(mf_ctx *c, size_t bs, size_t be, zge_seq *seq, u
     for (tile = bs; tile < be; tile += (size_t)P->tile) {
         size_t tend = tile + (size_t)P->tile < be ? tile + (size_t)P->tile : be, p, sub;
         uint32_t tcount = (uint32_t)(tend - tile), t;
+        int tile_any = 0;
         /* Table entries hold (position inside the current 2^seg_log segment + 1) << tag_bits | tag; the frame loop
          * clears the tables at every segment boundary. */
         if (pos >= tend) continue; /* whole tile already covered by a match: skip it (nothing is inserted) */
@@ -874,12 +875,16 @@ static uint32_t matchfind_block(mf_ctx *c, size_t bs, size_t be, zge_seq *seq, u
         {
             int any = 0;
             for (t = 0; t < tcount; t++) any |= c->M[t].len != 0;
+            tile_any = any;
             if (any) c->cold = 0;
             else {
                 c->cold++;
                 if (c->cold >= 2) c->skip_left = c->cold >= 4 ? 7u : (1u << (c->cold - 1)) - 1;
             }
         }
+        {
+        uint32_t it;
+        for (it = 0; ; it++) {
         /* S4: backward propagation -- position t may start the match of t+k, k bytes earlier */
         for (t = 0; t < tcount; t++) {
             cand best = c->M[t];
@@ -903,6 +908,10 @@ static uint32_t matchfind_block(mf_ctx *c, size_t bs, size_t be, zge_seq *seq, u
                 const cand *m2 = &c->M2[t + 1];
                 if (score_of(P, m2->len, m2->off, m2->is_rep) > score_of(P, m->len, m->off, m->is_rep) + P->lazy_delta) tk = 0;
             }
+            if (tk && P->lazy2_delta && t + 2 < tcount && c->M2[t + 2].len) { /* two bytes ahead (libzstd's lazy2) */
+                const cand *m3 = &c->M2[t + 2];
+                if (score_of(P, m3->len, m3->off, m3->is_rep) > score_of(P, m->len, m->off, m->is_rep) + P->lazy2_delta) tk = 0;
+            }
             c->take[t] = (uint8_t)tk;
             c->next[t] = tk ? t + m->len : t + 1;
             c->mark[t] = 0;
@@ -910,6 +919,43 @@ static uint32_t matchfind_block(mf_ctx *c, size_t bs, size_t be, zge_seq *seq, u
         /* S6: the parse path from the entry cursor (pointer doubling in the kernel) */
         t = (uint32_t)((pos > tile ? pos : tile) - tile);
         while (t < tcount) { c->mark[t] = 1; t = c->next[t]; }
+        if (it >= (uint32_t)P->rep_pass || !tile_any) break;
+        /* Live recent offsets (rep_pass > 0, the level >= 9 finder): libzstd's lazy parsers try the offsets of the matches they took
+         * last at every position; the guesses above are the offsets the PREVIOUS tile ended with.  With a parse of the tile in hand,
+         * every position tries the last two different offsets of the selected matches on the path in front of it (before the tile's
+         * first ones: the entry guesses) as two more candidates at recent-offset cost, and the tile is propagated and parsed again;
+         * rep_pass rounds.  Same rules as a table candidate: 8 bytes in front of the source, at most back_cap bytes of backward
+         * extension; of two candidates with the same score the more recent offset stays.  Only positions ON the path (literals and
+         * selected matches) and the position after one (same 64-position chunk) are tried: the positions inside a selected match
+         * would compare the rest of that very match at its own offset -- most of the work for none of the gain (model: elf slices
+         * +0.1 %). */
+        {
+            uint32_t live = erep0, live1 = erep1, lv;
+            for (t = 0; t < tcount; t++) {
+                size_t p = tile + t;
+                for (lv = 0; lv < 2; lv++) {
+                uint32_t lo = lv ? live1 : live;
+                if (lv && live1 == live) continue;
+                if (lo && lo + 8 <= p && lo <= c->window && (c->mark[t] || ((t & 63) != 0 && c->mark[t - 1]))) {
+                    cand *m = &c->M[t];
+                    uint32_t limit = (uint32_t)(be - p), cap = limit < (uint32_t)P->cap ? limit : (uint32_t)P->cap;
+                    uint32_t len = match_len(src, p, p - lo, cap);
+                    if (len >= (uint32_t)P->min_rep) {
+                        int32_t sc = score_of(P, len, lo, 1), cur = m->len ? score_of(P, m->len, m->off, m->is_rep) : 0;
+                        if (sc > cur) {
+                            uint32_t back = 0;
+                            m->len = len; m->off = lo; m->is_rep = 1;
+                            while (back < (uint32_t)P->back_cap && p - back > bs && p - back > lo && src[p - back - 1] == src[p - back - 1 - lo]) back++;
+                            m->back = (uint8_t)back;
+                        }
+                    }
+                }
+                }
+                if (c->mark[t] && c->take[t] && c->M2[t].off != live) { live1 = live; live = c->M2[t].off; }
+            }
+        }
+        }
+        }
         pos = tile + t;
         /* S7: emission in position order (prefix sums in the kernel) */
         {
@@ -961,9 +1007,12 @@ void zge_default_params(zge_params *P, int level)
     P->far_min_frame = 65536;
     P->near16 = 1; P->short_log = 15; P->far_cdc_log = 4; /* round 3: one 16-bit near table of 2^15 entries, content-defined far sampling */
     if (level >= 9) { /* the engine's deep finder (engine.hip: derive_params) */
-        P->near16 = 0; P->far_cdc_log = 0; P->far_back = 8; P->far_min_frame = 0;
+        P->near16 = 0; P->far_cdc_log = 0; P->far_min_frame = 0;
         P->long_log = 14; P->short_log = 14; P->short_bytes = 4; P->min_match = 4; P->match_cost = 10; P->window_log = 22;
-        P->far_log = 16; P->far_ways = 2; P->far_step_log = 1; P->far_res_log = 0; P->far_short = 1; P->far_skip = 0; P->far_back = 8;
+        P->far_log = 16; P->far_ways = 2; P->far_step_log = 1; P->far_res_log = 0; P->far_short = 1; P->far_skip = 0; P->far_back = 32;
+        /* round 3: the parse -- live recent offsets (two rounds), a second lazy step, literals priced at 6; near tables of 2^13 entries
+         * (the far tables hold what they forget: no ratio lost on any item of tests/support/realdata.py, and two workgroups fit a CU) */
+        P->rep_pass = 2; P->lazy2_delta = 5; P->lit_cost = 6; P->long_log = 13; P->short_log = 13;
     }
 }
 

@@ -101,6 +101,7 @@ static inline hipError_t hipStreamCreate(hipStream_t *s) { *s = 0; return hipSuc
 static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 enum { hipStreamDefault = 0 };
 static inline hipError_t hipDeviceGetStreamPriorityRange(int *least, int *greatest) { *least = 0; *greatest = 0; return hipSuccess; }
+template <typename K> static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int *n, K, int, size_t) { *n = 2; return hipSuccess; }
 static inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { *s = 0; return hipSuccess; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned = 0) { return hipSuccess; } // launches are synchronous here
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }

@@ -100,7 +100,9 @@ def test_emu_unpack_in_sub_batches(emu_engine, oracle, corpus, golden_frames):
 
 
 def test_emu_level9_deep_finder_matches_model(emu_lib_path, oracle, corpus):
-    """Level >= 9 launches the deep match finder (2^14-entry tables, one workgroup per CU): frames bit-identical to the model."""
+    """Level >= 9 launches the deep match finder (two-way far tables on both hashes, live recent-offset rounds, second lazy step): frames
+    bit-identical to the model -- on the corpus and on record-like data, whose parse is chains of short repeat-offset matches."""
+    import realdata
     from zarc_amd import Engine, _lib
     e9 = Engine(0, lib_path=emu_lib_path)
     try:
@@ -108,6 +110,7 @@ def test_emu_level9_deep_finder_matches_model(emu_lib_path, oracle, corpus):
         e9.set_parameter(_lib.P_COMPRESSION_LEVEL, 9)
         raws = [corpus.entry(9100 + i, n, i & 3) for i, n in enumerate((0, 70000, 200000, 300001))]
         raws += [bytes(range(200)) * 700, corpus.entry(27, 60000, 0) + corpus.entry(28, 90000, 1) + corpus.entry(27, 60000, 0)]  # joined pieces, far tables (4 ways)
+        raws += [realdata.reloc_like(150000), realdata.loglike(140000)]
         for raw, (frame, dig) in zip(raws, e9.pack(raws)):
             assert frame == oracle.zge_encode(raw, oracle.params(level=9))
             assert dig == oracle.blake3(raw)

@@ -10,6 +10,8 @@ items = {k: v for k, v in realdata.items().items() if v}
 c = harness.Corpus()
 for k in range(3):
     items["corpus_k%d_1m" % k] = c.entry(k, 1 << 20, k)
+if os.environ.get("ITEMS"):   # ITEMS=elf_mid_4m,pyc_2m: only these
+    items = {k: v for k, v in items.items() if k in os.environ["ITEMS"].split(",")}
 variants = eval(sys.argv[1]) if len(sys.argv) > 1 else [dict()]
 levels = eval(sys.argv[2]) if len(sys.argv) > 2 else [3, 9]
 o = harness.Oracle()

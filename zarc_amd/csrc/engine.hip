@@ -71,6 +71,7 @@ struct zarc_gpu {
     DevBuf d_slot_prefix, d_zblocks, d_nseq, d_fast, d_seqidx, d_seqs, d_ztables, d_litidx, d_lits; // decoder fast path (sequences decoded ahead)
     DevBuf d_queue; // frame queues of the persistent kernels (one u32 each)
     int num_cus = 1;
+    int deep_per_cu = 0; // workgroups of zarc_zge_match_deep a CU holds (0: not asked yet)
     uint64_t blake3_total_chunks = 0;
     hipEvent_t ev_b3[2] = {}; // digest kernels on the side stream (pack)
     // staging arenas for the host-pointer entry points
@@ -127,17 +128,18 @@ ZgeParams derive_params(const zarc_gpu_params &p)
     z.window_log = p.window_log ? p.window_log : (level >= 9 ? 22 : 21);
     if (z.window_log < 10) z.window_log = 10;
     if (z.window_log > 27) z.window_log = 27;
-    // level >= 9 selects the deep finder (zarc_zge_match_deep): tables of 2^14 entries, a 4-byte short hash, 4-byte matches and a
-    // lower match cost -- within 5 % of libzstd -9 on the corpus, at about half the speed of the level-3 finder
+    // level >= 9 selects the deep finder (zarc_zge_match_deep): two tagged near tables, a 4-byte short hash, 4-byte matches, a lower
+    // match cost, two-way far tables on both hashes, and a parse that tries the live recent offsets (two rounds per tile) with a second
+    // lazy step -- within 6 % of libzstd -9 on every real-data item of the test set but one
     const bool deep = level >= 9;
     // levels below 9 (round 3): ONE near table of 2^15 16-bit entries on the 5-byte hash (candidates 1 .. 65536 bytes back), no long table
     z.near16 = deep ? 0 : 1;
-    z.long_log = deep ? 14 : 13; z.short_log = deep ? 14 : 15; z.short_bytes = deep ? 4 : 5; z.tag_bits = 10; z.seg_log = 21; z.rep_back = 256;
+    z.long_log = 13; z.short_log = deep ? 13 : 15; z.short_bytes = deep ? 4 : 5; z.tag_bits = 10; z.seg_log = 21; z.rep_back = 256;
     z.tile = 1024; z.sub = 64; z.cap = diag_env("ZARC_GPU_CAP", 256);
     z.min_match = p.min_match >= 4 && p.min_match <= 7 ? p.min_match : (deep ? 4 : 5);
     z.min_rep = 3; z.rep_search = 2; z.back_cap = 8;
-    z.lazy = level >= 2 ? 1 : 0; z.lazy_delta = 5;
-    z.lit_cost = 5; z.match_cost = deep ? 10 : 12; z.rep_cost = 9;
+    z.lazy = level >= 2 ? 1 : 0; z.lazy_delta = 5; z.lazy2_delta = deep ? 5 : 0; z.rep_pass = deep ? 2 : 0;
+    z.lit_cost = deep ? 6 : 5; z.match_cost = deep ? 10 : 12; z.rep_cost = 9;
     z.short_window_log = 30;
     // far tables in HBM (zge_match.hip).  Level 3: 2^16 buckets, one way on the 12-byte hash, content-defined sampling: the positions
     // whose hash has four given bits zero (one in 16) are inserted and looked up; level >= 9: 2^16 buckets, two ways on both hashes,
@@ -145,7 +147,7 @@ ZgeParams derive_params(const zarc_gpu_params &p)
     z.far_log = 16; z.far_ways = deep ? 2 : 1; z.far_step_log = deep ? 1 : 5; z.far_res_log = deep ? 0 : 2; z.far_short = deep ? 1 : 0;
     z.far_cdc_log = deep ? 0 : 4;
     z.far_min_frame = deep ? 0 : 65536; // smaller frames do without the far table: the near table reaches 64 KiB
-    z.far_back = deep ? 8 : 48; z.far_skip = deep ? 0 : 64;
+    z.far_back = deep ? 32 : 48; z.far_skip = deep ? 0 : 64;
     z.dbg = diag_env("ZARC_GPU_DBG", 0); // timing-only ablations (outputs invalid when set): diagnostic build only
     return z;
 }
@@ -510,11 +512,12 @@ int pack_device_impl(zarc_gpu_t *h, size_t n, const void *d_src_base, const uint
 #define HOST_PHASE(i) do { } while (0)
 #endif
     // the match finder has these compiled in (zge_match.hip: F_*)
+    const bool dp = P.level >= 9; // the deep finder (zarc_zge_match_deep)
     if (P.rep_back != 256 || P.back_cap != 8 || P.lazy_delta != 5 || P.min_rep != 3 || P.rep_search != 2 || P.seg_log != 21 || P.short_window_log < 30 ||
-        P.lit_cost != 5 || P.rep_cost != 9 || P.tag_bits != 10 || P.far_log != 16 || P.match_cost != (P.long_log == 14 ? 10 : 12) || P.far_ways != (P.long_log == 14 ? 2 : 1) ||
-        P.far_step_log != (P.long_log == 14 ? 1 : 5) || P.far_res_log != (P.long_log == 14 ? 0 : 2) || (P.far_short != 0) != (P.long_log == 14) ||
-        P.near16 != (P.long_log == 14 ? 0 : 1) || P.short_log != (P.long_log == 14 ? 14 : 15) || P.far_cdc_log != (P.long_log == 14 ? 0 : 4) ||
-        P.far_back != (P.long_log == 14 ? 8 : 48) || P.far_skip != (P.long_log == 14 ? 0 : 64)) { set_error(h, "internal: encoder parameters differ from the compiled-in ones"); return ZARC_GPU_E_PARAM; }
+        P.lit_cost != (dp ? 6 : 5) || P.rep_cost != 9 || P.tag_bits != 10 || P.far_log != 16 || P.match_cost != (dp ? 10 : 12) || P.far_ways != (dp ? 2 : 1) ||
+        P.far_step_log != (dp ? 1 : 5) || P.far_res_log != (dp ? 0 : 2) || (P.far_short != 0) != dp || P.long_log != 13 ||
+        P.near16 != (dp ? 0 : 1) || P.short_log != (dp ? 13 : 15) || P.far_cdc_log != (dp ? 0 : 4) || P.lazy2_delta != (dp ? 5 : 0) || (P.rep_pass != 0) != dp || P.rep_pass > 4 ||
+        P.far_back != (dp ? 32 : 48) || P.far_skip != (dp ? 0 : 64)) { set_error(h, "internal: encoder parameters differ from the compiled-in ones"); return ZARC_GPU_E_PARAM; }
     uint64_t need = 0;
     for (size_t i = 0; i < n; i++) {
         if (src_off[i] % ZARC_GPU_ALIGN) { set_error(h, "entry offset not 16-byte aligned"); return ZARC_GPU_E_PARAM; }
@@ -613,7 +616,7 @@ int pack_device_impl(zarc_gpu_t *h, size_t n, const void *d_src_base, const uint
         int a, b, c, d;
         ZHIP(t.mark(&a));
         ZHIP(hipMemsetAsync(h->d_queue.p, 0, 256, h->stream));
-        const bool deep = P.long_log == 14;
+        const bool deep = P.level >= 9;
         // the match finder's units of work: the 2^seg_log segments (16 blocks) of every frame, largest frames first
         std::vector<uint32_t> units;
         {
@@ -645,17 +648,24 @@ int pack_device_impl(zarc_gpu_t *h, size_t n, const void *d_src_base, const uint
         const size_t n_units = units.size() / 2;
         if ((rc = upload_u32(h, h->d_units, units.data(), units.size()))) return rc;
         HOST_PHASE(2); // sub-batch lists + uploads
-        const size_t match_grid = std::min<size_t>(n_units, (size_t)h->num_cus * (deep ? 1 : 2)); // two 80 KiB workgroups fit a CU, one of 145 KiB
+        auto match_kernel = deep ? zarc_zge_match_deep : zarc_zge_match;
+#ifdef ZARC_GPU_DIAG
+        if (P.dbg) match_kernel = deep ? zarc_zge_match_deep_diag : zarc_zge_match_diag;
+#endif
+        // persistent workgroups: as many as the chip holds at once -- two of 80 KiB of LDS and 128 registers per thread on a CU; the
+        // deep finder's register count decides whether it is one or two (asked once)
+        if (deep && h->deep_per_cu == 0) {
+            int per_cu = 0;
+            ZHIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, match_kernel, 512, 0));
+            h->deep_per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);
+        }
+        const size_t match_grid = std::min<size_t>(n_units, (size_t)h->num_cus * (size_t)(deep ? h->deep_per_cu : 2));
         ZHIP(h->d_far.reserve(match_grid * zge_far_words(P) * 4 + 16)); // one far-table slab per resident workgroup (cleared by the kernel per frame)
         // The digest kernels (low-priority stream, queued behind the FIRST sub-batch's match launch) must be off the chip before another
         // match launch: measured on the configs[4] shape, a second launch that found the last 4 ms of them still running took 326 ms
         // instead of 209 (kernel trace in gpurun_out/trace_dpp.txt) -- the persistent workgroups keep whatever uneven placement the
         // launch moment gave them.
         if (digest_queued && !have_digests) ZHIP(hipStreamWaitEvent(h->stream, h->ev_join3, 0));
-        auto match_kernel = deep ? zarc_zge_match_deep : zarc_zge_match;
-#ifdef ZARC_GPU_DIAG
-        if (!deep && P.dbg) match_kernel = zarc_zge_match_diag;
-#endif
         hipLaunchKernelGGL(match_kernel, dim3((unsigned)match_grid), dim3(512), 0, h->stream, P, base, d_off, d_len, h->d_order.as<uint32_t>(), h->d_units.as<uint32_t>(), (uint32_t)n_units,
                            h->d_block_prefix.as<uint64_t>(), h->d_blocks.as<ZgeBlock>(), h->d_seq.as<uint64_t>(), h->d_lit.as<uint8_t>(),
                            h->d_queue.as<uint32_t>(), h->d_far.as<uint32_t>());
@@ -685,12 +695,12 @@ int pack_device_impl(zarc_gpu_t *h, size_t n, const void *d_src_base, const uint
         ZHIP(hipStreamSynchronize(h->stream)); // the scratch is reused by the next sub-batch; also bounds the event pool
         HOST_PHASE(4); // waiting for the kernels
         if (P.dbg & 1024) { // stage timing of the match finder (diagnostics)
-            unsigned long long prof[14];
+            unsigned long long prof[15];
             ZHIP(hipMemcpy(prof, (const char *)h->d_queue.p + 8, sizeof prof, hipMemcpyDeviceToHost));
             unsigned long long tot = 0;
-            for (int i = 0; i < 14; i++) tot += prof[i];
+            for (int i = 0; i < 15; i++) tot += prof[i];
             fprintf(stderr, "zge_match stage ticks (%% of %llu):", tot);
-            for (int i = 0; i < 14; i++) fprintf(stderr, " %d:%.1f", i, tot ? 100.0 * (double)prof[i] / (double)tot : 0.0);
+            for (int i = 0; i < 15; i++) fprintf(stderr, " %d:%.1f", i, tot ? 100.0 * (double)prof[i] / (double)tot : 0.0);
             fprintf(stderr, "\n");
             ZHIP(hipMemcpy(prof, (const char *)h->d_queue.p + 128, 6 * 8, hipMemcpyDeviceToHost));
             tot = 0;

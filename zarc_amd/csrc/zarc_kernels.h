@@ -16,7 +16,7 @@ constexpr uint32_t ZARC_MAX_SEQ = ZARC_BLOCK / 3 + 8; // sequences per block (ev
 struct ZgeParams {
     int level, checksum, window_log, long_log, short_log, short_bytes, tile, sub, cap, min_match, min_rep, rep_search,
         back_cap, lazy, lazy_delta, lit_cost, match_cost, rep_cost, short_window_log, rep_back, tag_bits, seg_log,
-        far_log, far_ways, far_step_log, far_res_log, far_short, far_skip, far_back, near16, far_cdc_log, far_min_frame, slot_bytes, dbg;
+        far_log, far_ways, far_step_log, far_res_log, far_short, far_skip, far_back, near16, far_cdc_log, far_min_frame, rep_pass, lazy2_delta, slot_bytes, dbg;
 };
 // Encoder scratch of one block slot (sequences, literals, coded block): sized by the largest block of the SUB-BATCH (slot_bytes <=
 // ZARC_BLOCK, a multiple of 16) -- a batch of a million 1 KiB entries must not reserve 600 KiB per entry.
@@ -120,14 +120,19 @@ __global__ void zarc_corpus_fill(uint8_t *base, const uint64_t *off, const uint6
 __global__ void zarc_zge_match(ZgeParams P, const uint8_t *src_base, const uint64_t *src_off, const uint64_t *src_len,
                                const uint32_t *order, const uint32_t *units /* (queue slot, first block) per 2 MiB segment */, uint32_t n_units, const uint64_t *block_prefix, ZgeBlock *blocks,
                                uint64_t *seq_scratch, uint8_t *lit_scratch, uint32_t *queue, uint32_t *far_scratch);
-// the deep finder (level >= 9): same arguments, 2^14-entry tables (one workgroup per CU), 4-byte short hash
+// the same with the ZARC_GPU_DBG switches (diagnostic build only)
 __global__ void zarc_zge_match_diag(ZgeParams P, const uint8_t *src_base, const uint64_t *src_off, const uint64_t *src_len,
                                const uint32_t *order, const uint32_t *units /* (queue slot, first block) per 2 MiB segment */, uint32_t n_units, const uint64_t *block_prefix, ZgeBlock *blocks,
                                uint64_t *seq_scratch, uint8_t *lit_scratch, uint32_t *queue, uint32_t *far_scratch);
-// the deep finder (level >= 9): same arguments, 2^14-entry tables (one workgroup per CU), 4-byte short hash
+// the deep finder (level >= 9): same arguments; two tagged tables, 4-byte short hash, two-way far tables, live recent-offset rounds
 __global__ void zarc_zge_match_deep(ZgeParams P, const uint8_t *src_base, const uint64_t *src_off, const uint64_t *src_len,
                                     const uint32_t *order, const uint32_t *units /* (queue slot, first block) per 2 MiB segment */, uint32_t n_units, const uint64_t *block_prefix, ZgeBlock *blocks,
                                     uint64_t *seq_scratch, uint8_t *lit_scratch, uint32_t *queue, uint32_t *far_scratch);
+#ifdef ZARC_GPU_DIAG
+__global__ void zarc_zge_match_deep_diag(ZgeParams P, const uint8_t *src_base, const uint64_t *src_off, const uint64_t *src_len,
+                                    const uint32_t *order, const uint32_t *units /* (queue slot, first block) per 2 MiB segment */, uint32_t n_units, const uint64_t *block_prefix, ZgeBlock *blocks,
+                                    uint64_t *seq_scratch, uint8_t *lit_scratch, uint32_t *queue, uint32_t *far_scratch);
+#endif
 __global__ void zarc_zge_entropy(uint32_t n_blocks, uint32_t slot_bytes, ZgeBlock *blocks, uint64_t *seq_scratch, const uint8_t *lit_scratch,
                                  uint8_t *out_scratch, unsigned long long *prof);
 __global__ void zarc_zge_assemble(ZgeParams P, const uint8_t *src_base, const uint64_t *src_off, const uint64_t *src_len,

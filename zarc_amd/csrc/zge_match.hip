@@ -72,10 +72,11 @@ template <int TAB_LOG, bool NEAR16> struct MatchLds {
     uint32_t ex[TILE];            // S4: best backward offer per position; S6: first position outside its chunk reached from each position
     uint32_t tb[2][(TB_BYTES + 3) / 4]; // the window of a tile lives in buffer (tile / TILE) & 1: the current tile's and the next one's
     uint32_t wcnt[CHUNKS];       // S6: selected matches << 16 | literals of each chunk
+    uint32_t wrep[2 * CHUNKS];   // S6 (level >= 9): offset of each chunk's last selected match, and of the last one different from it
     uint32_t ctrl[16];
-    unsigned long long prof[14]; // ZARC_GPU_DBG & 1024: shader-clock ticks per stage, workgroup view from thread 0
+    unsigned long long prof[15]; // ZARC_GPU_DBG & 1024: shader-clock ticks per stage, workgroup view from thread 0
 };
-enum { K_POS = 0, K_REP0 = 1, K_REP1 = 2, K_FLAG = 3, K_SLOT = 4, K_ANY = 5 };
+enum { K_POS = 0, K_REP0 = 1, K_REP1 = 2, K_FLAG = 3, K_SLOT = 4, K_ANY = 5, K_CHG = 6 /* .. 9: a round of the live recent-offset pass changed a match */ };
 
 // Hashes from 32-bit multiplies only (a 64-bit multiply is four quarter-rate VALU ops on gfx950).
 // The near and the far tables index with different numbers of top bits of the SAME 32-bit product.
@@ -97,16 +98,17 @@ __device__ __forceinline__ uint32_t hash_short32(uint64_t v, int nbytes)
 
 // Bit-cost model (lit_cost 5, match_cost 12 (level >= 9: 10), rep_cost 9: the engine's fixed defaults, so the literal cost is a
 // shift-add instead of a quarter-rate multiply; engine.hip: derive_params() sets exactly these, they are not tunable).
-constexpr int LIT_COST = 5, REP_COST = 9;
+constexpr int REP_COST = 9; // (lit_cost: template parameter LITC, 5 below level 9, 6 from there)
 // Parameters of the model that the engine never varies (engine.hip: derive_params sets exactly these and checks them before a
 // launch): as constants they cost no scalar registers -- the kernel keeps about a hundred uniform values alive and spills them.
 constexpr int F_REP_BACK = 256, F_BACK_CAP = 8, F_LAZY_DELTA = 5, F_MIN_REP = 3, F_SEG_LOG = 21; // rep_search 2, short window unlimited
-template <int MATCH_COST> __device__ __forceinline__ int32_t score_mc(uint32_t len, uint32_t off, bool is_rep)
+template <int MATCH_COST, int LITC> __device__ __forceinline__ int32_t score_mc(uint32_t len, uint32_t off, bool is_rep)
 {
-    const int32_t lits = (int32_t)((len << 2) + len);
+    static_assert(LITC == 5 || LITC == 6, "literal cost");
+    const int32_t lits = (int32_t)((len << 2) + (LITC == 6 ? len << 1 : len));
     return is_rep ? lits - REP_COST : lits - MATCH_COST - zd::hb32(off);
 }
-#define score_of(P_, len_, off_, rep_) score_mc<MATCH_COST>((len_), (off_), (rep_))
+#define score_of(P_, len_, off_, rep_) score_mc<MATCH_COST, LITC>((len_), (off_), (rep_))
 
 struct U128 { uint64_t lo, hi; };
 
@@ -160,7 +162,7 @@ __device__ __forceinline__ uint32_t tile_end(uint32_t tile, uint32_t n)
 // relative positions, so a repeat is found when it contains one sample: 64 lookups + 64 inserts per 1024-position tile at FAR_CDC 4
 // instead of 256 + 128, and every thread asks for its OWN positions (no hand-over between lanes).
 template <int TAB_LOG, int SHORT_BYTES, int MATCH_COST, int F_FAR_LOG, int FAR_WAYS, bool FAR_SHORT, int FAR_STEP_LOG, int FAR_RES_LOG, int FAR_SKIP, int FAR_BACK, bool DIAG,
-          bool NEAR16, int FAR_CDC>
+          bool NEAR16, int FAR_CDC, int LITC, int LAZY2, bool REP_PASS>
 __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG, NEAR16> &L, const ZgeParams &P, const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off,
                                                const uint64_t *__restrict__ src_len, const uint32_t *__restrict__ order, const uint32_t *__restrict__ units, uint32_t n_units,
                                                const uint64_t *__restrict__ block_prefix, ZgeBlock *__restrict__ blocks,
@@ -187,7 +189,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG, NEAR16> &L, con
     const uint32_t seg_mask = (1u << F_SEG_LOG) - 1;
     const uint32_t cap_max = (uint32_t)(P.cap < CAP_MAX ? P.cap : CAP_MAX);
     unsigned long long tprev = ZGE_CLOCK();
-    if (tid < 14) L.prof[tid] = 0;
+    if (tid < 15) L.prof[tid] = 0;
 
     // Persistent workgroups: the grid is what the chip holds at once (two per CU); every workgroup takes the next UNIT from a queue
     // (largest frames first), so slow and fast frames balance across XCDs whatever their order in the batch.  A unit is one 2^seg_log
@@ -321,6 +323,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG, NEAR16> &L, con
             }
             const uint32_t erep0 = L.ctrl[K_REP0], erep1 = L.ctrl[K_REP1];
             if (tid == 0) L.ctrl[K_ANY] = 0; // set by any position of this tile that finds a match
+            if (REP_PASS && tid < 4) L.ctrl[K_CHG + tid] = 0;
 
             // ---- S0: tile bytes (8 before .. cap+16 after) -> LDS ----
             // frame position `pos` of the staged window [lo, hi) lives at LDS byte tbb[pos + wofs] (u32 arithmetic)
@@ -806,189 +809,101 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG, NEAR16> &L, con
 #pragma unroll
             for (int u = 0; u < PER; u++) L.a0[ZGE_IDX(u)] = match_pack(mo[u], mw[u] & 0xFFFF, (mw[u] >> 24) & 1);
             if (mo[0] | mo[1]) L.ctrl[K_ANY] = 1; // benign race: every writer stores 1
-            // ---- S4: backward propagation.  A position whose match extends b bytes backwards offers it to the b
-            // positions before it (ds_max of score << 6 | 63-k: best score wins, then the nearest source); every position
-            // then adopts the best offer if it beats its own match.  Same result as scanning the 8 following positions.
+            uint32_t fo[PER], fw[PER]; // final match of each position: its own, or the one it adopted from a position behind it
+            uint64_t msel[PER], mlit[PER];
+            // S4 - S6 (zge_parse_round.h): once per tile; with REP_PASS once more after every round of the live recent-offset pass
+            {
+#define ZGE_FIRST 1
+#include "zge_parse_round.h"
+#undef ZGE_FIRST
+            }
+            if (REP_PASS) for (uint32_t it = 0; it < (uint32_t)P.rep_pass; it++) {
+            // ---- live recent offsets (level >= 9; model: matchfind_block, rep_pass).  libzstd's lazy parsers try the offsets of the
+            // matches they took last at every position; the guesses of S3 are the offsets the PREVIOUS tile ended with.  With a parse
+            // of the tile in hand, every position tries the last two different offsets of the selected matches in front of it as two
+            // more candidates at recent-offset cost; then the tile is propagated and parsed again.  The walk left, per chunk, the
+            // offset of its last selected match and the last one different from it: the state (live, live1) at a chunk's entry is a
+            // scalar chain over the chunks before it, inside the chunk one scalar step per selected match. ----
+            {
+                const uint32_t wr = L.wrep[lane & 31];
+                uint32_t sl = erep0, sl1 = erep1; // uniform
+                for (int c = 0; c < wave * PER; c++) {
+                    const uint32_t cl = zd::readlane(wr, (uint32_t)(2 * c)), cd = zd::readlane(wr, (uint32_t)(2 * c + 1));
+                    if (cl) { if (cd) { sl1 = cd; sl = cl; } else if (cl != sl) { sl1 = sl; sl = cl; } }
+                }
+                uint32_t lv[PER], lv1[PER];
 #pragma unroll
-            for (int u = 0; u < PER; u++) {
-                const uint32_t idx = ZGE_IDX(u);
-                const uint32_t len = mw[u] & 0xFFFF, back = (mw[u] >> 16) & 0xFF;
-                if (len && back && !(dbg & 8)) {
-                    const bool rep = (mw[u] >> 24) & 1;
-                    // the first eight distances (all a near candidate or a guess can have) as straight-line predicated code: the loop's
-                    // bookkeeping -- compare, mask, two branches per trip -- was twice the work of the offers themselves, 9 % of the kernel
-                    const int32_t base = score_of(P, len, mo[u], rep); // the score is linear in the length: + lit_cost per byte
-                    const uint32_t lim = back < idx ? back : idx;
-#pragma unroll
-                    for (uint32_t k = 1; k <= (uint32_t)F_BACK_CAP; k++) {
-                        const int32_t sc = base + LIT_COST * (int32_t)k;
-                        if (k <= lim && sc > 0) atomicMax(&L.ex[idx - k], ((uint32_t)sc << 6) | (63u - k));
-                    }
-                    for (uint32_t k = (uint32_t)F_BACK_CAP + 1; k <= lim; k++) { // far candidates reach further back
-                        const int32_t sc = base + LIT_COST * (int32_t)k;
-                        if (sc > 0) atomicMax(&L.ex[idx - k], ((uint32_t)sc << 6) | (63u - k));
+                for (int u = 0; u < PER; u++) {
+                    lv[u] = sl; lv1[u] = sl1;
+                    uint64_t rem = msel[u];
+                    while (rem) { // the selected matches of this chunk in order: lanes above one see its offset
+                        const uint32_t q = (uint32_t)zd::ctz64(rem);
+                        rem &= rem - 1;
+                        const uint32_t o = zd::readlane(fo[u], q);
+                        if (o != sl) { sl1 = sl; sl = o; }
+                        if ((uint32_t)lane > q) { lv[u] = sl; lv1[u] = sl1; }
                     }
                 }
-            }
-            ZGE_PROF(12); // (diagnostics: the backward offers; stage 4 below is then the wait for the requests and for the slowest wave)
-            if (NFAR) zd::wait_vmem(); // the next tile's entries are in registers before any wave sends this tile's inserts
-            ZGE_PROF(13);
-            zd::lds_barrier(); // own matches (a0) and offers (ex) are complete
-            ZGE_PROF(4);
-            if (NFAR) {
-                // far inserts of this tile: every wave has used its lookups (they fed S3), so none of them can see these.  Every
-                // 2^far_step_log-th position, into the way of this tile; atomic max = the highest position wins, whatever the order.
-                const uint32_t way = (tile / TILE) & (uint32_t)(FAR_WAYS - 1);
+                // only positions on the path (literals, selected matches) and the position after one are tried: a position inside a selected
+                // match would compare the rest of that very match at its own offset
+                uint64_t onpath[PER];
+#pragma unroll
+                for (int u = 0; u < PER; u++) { const uint64_t mk = msel[u] | mlit[u]; onpath[u] = mk | (mk << 1); }
+                U128 qa[PER][2];
+                bool ok[PER][2];
+                bool changed = false;
 #pragma unroll
                 for (int u = 0; u < PER; u++) {
                     const uint32_t idx = ZGE_IDX(u);
                     const uint32_t p = tile + idx;
-                    if (FAR_CDC) { // the far positions of this tile: bucket | check bits known since S1
-                        const uint32_t hfc = L.a1[idx];
-                        if (hfc != 0xFFFFFFFFu && !(dbg & (64 | 8192)))
-                            zd::atomic_max_l2(far_l + (size_t)(hfc >> TAG_BITS), ((((uint32_t)(tile - segbase) + idx + 1) << TAG_BITS)) | (hfc & TAG_MASK));
-                    } else
-                    if (idx < tcount && p < far_end && (p & far_smask) <= far_rmask && !(dbg & (64 | 8192))) {
-                        const uint32_t code = ((uint32_t)(tile - segbase) + idx + 1) << TAG_BITS;
-                        const uint32_t hf = hash_far32(p8[u], zd::load_u32(tbb + (uint32_t)(p + 8 + wofs))) >> far_shift;
-                        zd::atomic_max_l2(far_l + ((size_t)(hf >> TAG_BITS) * FAR_WAYS + way), code | (hf & TAG_MASK));
-                        if (FAR_SHORT) {
-                            const uint32_t hg = hash_short32(p8[u], SHORT_BYTES) >> far_shift;
-                            zd::atomic_max_l2(far_s + ((size_t)(hg >> TAG_BITS) * FAR_WAYS + way), code | (hg & TAG_MASK));
-                        }
+#pragma unroll
+                    for (int k = 0; k < 2; k++) {
+                        const uint32_t lo = k ? lv1[u] : lv[u];
+                        ok[u][k] = idx < tcount && lo != 0 && lo + 8 <= p && lo <= window && !(k && lv1[u] == lv[u]) && ((onpath[u] >> lane) & 1);
+                        qa[u][k] = U128{0, 0};
+                        if (ok[u][k]) __builtin_memcpy(&qa[u][k], src + (p - lo - 8), 16);
                     }
                 }
-            }
-            if (L.ctrl[K_ANY] == 0) {
-                // no match anywhere in the tile (incompressible data): the path is all literals, nothing to parse
-                const uint32_t start = (uint32_t)((pos > tile ? pos : tile) - tile);
 #pragma unroll
                 for (int u = 0; u < PER; u++) {
                     const uint32_t idx = ZGE_IDX(u);
-                    if (idx >= start && idx < tcount && !(dbg & 32)) lit_out[lp + (idx - start)] = (uint8_t)p8[u];
-                }
-                lp += tcount - start;
-                if (tid == 0) L.ctrl[K_POS] = (uint32_t)(tend - bs);
-                cold++;
-                if (cold >= 2) skip_left = cold >= 4 ? 7u : (1u << (cold - 1)) - 1;
-                if (NFAR) zd::wait_vmem(); // the far inserts above are in L2 before the next tile's lookups (rare path: a searched tile without any match)
-                continue;
-            }
-            cold = 0;
+                    const uint32_t p = tile + idx;
+                    const uint32_t limit = idx < tcount ? (uint32_t)(be - p) : 0u, cap = limit < cap_max ? limit : cap_max;
+                    uint32_t olen = mw[u] & 0xFFFF;
+                    int32_t cur = olen ? score_of(P, olen, mo[u], (mw[u] >> 24) & 1) : 0;
 #pragma unroll
-            for (int u = 0; u < PER; u++) {
-                const uint32_t idx = ZGE_IDX(u);
-                const uint32_t offer = L.ex[idx];
-                uint32_t blen_ = mw[u] & 0xFFFF, boff = mo[u];
-                bool brep = (mw[u] >> 24) & 1;
-                if (offer) {
-                    const int32_t own = blen_ ? score_of(P, blen_, boff, brep) : 0;
-                    if ((int32_t)(offer >> 6) > own) {
-                        const uint32_t k = 63u - (offer & 63u);
-                        const uint32_t nm = L.a0[idx + k];
-                        boff = match_off(nm);
-                        blen_ = match_len(nm) + k;
-                        brep = match_rep(nm);
-                    }
-                }
-                mo[u] = boff;
-                mw[u] = blen_ | ((brep ? 1u : 0u) << 24);
-                L.a1[idx] = match_pack(boff, blen_, brep); // final match (a1 held this thread's short candidate until S3)
-            }
-            zd::lds_barrier();
-            ZGE_PROF(5);
-            // ---- S5: take flag (one-byte lazy lookahead inside the tile) and successor ----
-            bool take[PER];
-            uint32_t nx[PER]; // true successor in tile coordinates (may leave the tile)
-#pragma unroll
-            for (int u = 0; u < PER; u++) {
-                const uint32_t idx = ZGE_IDX(u);
-                const uint32_t my_len = mw[u] & 0xFFFF;
-                take[u] = idx < tcount && my_len != 0;
-                if (take[u] && P.lazy && idx + 1 < tcount) {
-                    const uint32_t m2 = L.a1[idx + 1];
-                    const uint32_t l2 = match_len(m2);
-                    if (l2 && score_of(P, l2, match_off(m2), match_rep(m2)) > score_of(P, my_len, mo[u], (mw[u] >> 24) & 1) + F_LAZY_DELTA) take[u] = false;
-                }
-                nx[u] = take[u] ? idx + my_len : idx + 1;
-            }
-            // ---- S6a: per chunk, the first position outside the chunk reached from every position; for the first chunk of the
-            // wave's pair this is carried on through the second chunk (one more shuffle), so ex[] of a pair's first half holds
-            // the exit of the whole pair ----
-            {
-                uint32_t val[PER];
-#pragma unroll
-                for (int u = 0; u < PER; u++) {
-                    const uint32_t cbase = (uint32_t)(wave * PER + u) * 64;
-                    const uint32_t cend = cbase + 64 < tcount ? cbase + 64 : tcount;
-                    val[u] = nx[u];
-#pragma unroll
-                    for (int r = 0; r < 6; r++) {
-                        const uint32_t v2 = zd::shfl(val[u], (int)((val[u] - cbase) & 63));
-                        if (val[u] < cend) val[u] = v2;
-                    }
-                }
-                {
-                    const uint32_t obase = (uint32_t)(wave * PER + 1) * 64, oend = obase + 64 < tcount ? obase + 64 : tcount;
-                    const uint32_t through = zd::shfl(val[1], (int)((val[0] - obase) & 63));
-                    if (val[0] >= obase && val[0] < oend) val[0] = through;
-                }
-#pragma unroll
-                for (int u = 0; u < PER; u++) L.ex[ZGE_IDX(u)] = val[u];
-            }
-            zd::lds_barrier();
-            ZGE_PROF(6);
-            // ---- S6b/c + S7: chunk entries by a chain through ex[], path marks per chunk, emission ----
-            uint64_t msel[PER], mlit[PER];
-            {
-                zd::wave_priority<2>(); // a serial chain (LDS hops, then a scalar walk): latency matters here, not throughput
-                uint32_t cur = (uint32_t)((pos > tile ? pos : tile) - tile);
-                int c = 0;
-#pragma unroll
-                for (; c < wave; c++) { // pairs of chunks before mine: hop over them (an entry in either half leaves through ex[])
-                    const uint32_t pend = (uint32_t)(c * 128 + 128) < tcount ? (uint32_t)(c * 128 + 128) : tcount;
-                    if (cur < pend) cur = L.ex[cur];
-                }
-                cur = zd::uniform(cur);
-#pragma unroll
-                for (int u = 0; u < PER; u++) {
-                    const int mychunk = wave * PER + u; // the walk of the first chunk ends at the entry of the second
-                    const uint32_t cbase = (uint32_t)mychunk * 64;
-                    const uint32_t cend = cbase + 64 < tcount ? cbase + 64 : tcount;
-                    // walk the path inside my chunk: literal nodes step by one, so only the selected matches are
-                    // visited (uniform loop on the scalar unit, one v_readlane per match)
-                    const uint64_t tk = zd::ballot(take[u]);
-                    const uint32_t span = cend > cbase ? cend - cbase : 0u; // positions of this chunk inside the tile
-                    // The scalar loop only collects the selected matches (find the next take flag at or after the cursor, jump to its
-                    // successor): five or six scalar instructions and a v_readlane per match.  The literals are what is left: a position
-                    // at or after the chunk's entry that is no selected match and does not lie inside the nearest selected match below
-                    // it -- one ds_bpermute for the whole chunk instead of two 64-bit masks built per match.
-                    uint64_t sel = 0, lits = 0;
-                    const uint32_t entry = cur; // where the path enters this chunk (>= cend: it does not)
-                    if (!(dbg & 2)) {
-                        while (cur < cend) {
-                            const uint64_t ahead = tk & (~0ull << (cur - cbase)); // take flags at or after the cursor
-                            if (ahead == 0) { cur = cend; break; }                // only literals up to the end of the chunk
-                            const uint32_t q = (uint32_t)zd::ctz64(ahead);
-                            sel |= 1ull << q;
-                            cur = zd::readlane(nx[u], q);
+                    for (int k = 0; k < 2; k++) {
+                        if (!ok[u][k]) continue;
+                        const uint32_t lo = k ? lv1[u] : lv[u];
+                        const uint32_t len = prefix_len(p, p8[u], cap, lo, qa[u][k].hi);
+                        if (len < (uint32_t)F_MIN_REP) continue;
+                        const int32_t sc = score_of(P, len, lo, true);
+                        if (sc > cur) {
+                            cur = sc;
+                            uint32_t maxb = (uint32_t)F_BACK_CAP;
+                            if (p - bs < maxb) maxb = (uint32_t)(p - bs);
+                            const uint64_t x = zd::load_u64(tbb + (uint32_t)(p - 8 + wofs)) ^ qa[u][k].lo;
+                            uint32_t back = x ? (uint32_t)(__clzll((long long)x) >> 3) : 8u;
+                            if (back > maxb) back = maxb;
+                            mo[u] = lo;
+                            mw[u] = len | (back << 16) | (1u << 24);
+                            changed = true;
                         }
-                        const uint64_t below = sel & lt;                          // selected matches below this lane
-                        const uint32_t qs = below ? 63u - (uint32_t)__clzll((long long)below) : 0u;
-                        const uint32_t over = zd::shfl(nx[u], (int)qs);           // where the nearest one below ends
-                        const uint32_t me = cbase + (uint32_t)lane;
-                        lits = zd::ballot(me >= entry && (uint32_t)lane < span && !((sel >> lane) & 1) && (!below || over <= me));
                     }
-                    msel[u] = sel;
-                    mlit[u] = lits;
-                    if (lane == 0) L.wcnt[mychunk] = ((uint32_t)__popcll(msel[u]) << 16) | (uint32_t)__popcll(mlit[u]);
+                    L.a0[idx] = match_pack(mo[u], mw[u] & 0xFFFF, (mw[u] >> 24) & 1);
+                    L.ex[idx] = 0;
                 }
-                // the wave that owns the last chunk knows where the path leaves the tile
-                if (wave == WAVES - 1 && lane == 0) L.ctrl[K_POS] = (uint32_t)(tile - bs) + cur;
-                zd::wave_priority<0>();
+                if (changed) L.ctrl[K_CHG + it] = 1; // benign race: every writer stores 1
             }
-            zd::lds_barrier();
-            ZGE_PROF(7);
+            zd::lds_barrier(); // own matches are in a0, the offers start empty
+            ZGE_PROF(14); // (diagnostics: the live recent-offset pass)
+            if (L.ctrl[K_CHG + it] == 0) break; // no position took a live offset: another parse (and every further round) would repeat the last one
+            {
+#define ZGE_FIRST 0
+#include "zge_parse_round.h"
+#undef ZGE_FIRST
+            }
+            }
             // The far inserts of this tile (issued after S3, a third of a tile ago) must be in L2 before the next tile's lookups: every wave
             // waits for its own here -- ahead of the stores below, which nobody waits for -- and the barrier at the top of the next tile
             // does the rest.
@@ -1015,11 +930,11 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG, NEAR16> &L, con
                 if (dbg & 32) continue;
                 if ((msel[u] >> lane) & 1) {
                     // the literal position stands in for the literal length (difference of neighbours, taken in stage 2)
-                    seq_out[nseq + my_sel_idx] = zge_pack_seq(lp + my_lit_idx, mw[u] & 0xFFFF, mo[u]);
+                    seq_out[nseq + my_sel_idx] = zge_pack_seq(lp + my_lit_idx, fw[u] & 0xFFFF, fo[u]);
                     // offset guesses for the next tile: the offsets of the last two matches selected so far (every thread
                     // took its copy of the old ones at the top of the tile, so they can be replaced in place)
-                    if (my_sel_idx + 1 == sel_total) { L.ctrl[K_REP0] = mo[u]; if (sel_total == 1) L.ctrl[K_REP1] = erep0; }
-                    if (my_sel_idx + 2 == sel_total) L.ctrl[K_REP1] = mo[u];
+                    if (my_sel_idx + 1 == sel_total) { L.ctrl[K_REP0] = fo[u]; if (sel_total == 1) L.ctrl[K_REP1] = erep0; }
+                    if (my_sel_idx + 2 == sel_total) L.ctrl[K_REP1] = fo[u];
                 }
                 if ((mlit[u] >> lane) & 1) lit_out[lp + my_lit_idx] = (uint8_t)p8[u];
             }
@@ -1031,7 +946,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG, NEAR16> &L, con
         zd::lds_barrier();
     }
     } // next frame from the queue
-    if ((dbg & 1024) && tid < 14) atomicAdd((unsigned long long *)(queue + 2) + tid, L.prof[tid]);
+    if ((dbg & 1024) && tid < 15) atomicAdd((unsigned long long *)(queue + 2) + tid, L.prof[tid]);
 }
 #undef score_of
 
@@ -1042,7 +957,7 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                                                       uint32_t *__restrict__ far_scratch)
 {
     __shared__ MatchLds<15, true> L;
-    zge_match_body<15, 5, 12, 16, 1, false, 5, 2, 64, 48, false, true, 4>(L, P, src_base, src_off, src_len, order, units, n_units, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
+    zge_match_body<15, 5, 12, 16, 1, false, 5, 2, 64, 48, false, true, 4, 5, 0, false>(L, P, src_base, src_off, src_len, order, units, n_units, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
 }
 
 #ifdef ZARC_GPU_DIAG
@@ -1055,7 +970,7 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match_diag(ZgeParams P, const
                                                            uint32_t *__restrict__ far_scratch)
 {
     __shared__ MatchLds<15, true> L;
-    zge_match_body<15, 5, 12, 16, 1, false, 5, 2, 64, 48, true, true, 4>(L, P, src_base, src_off, src_len, order, units, n_units, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
+    zge_match_body<15, 5, 12, 16, 1, false, 5, 2, 64, 48, true, true, 4, 5, 0, false>(L, P, src_base, src_off, src_len, order, units, n_units, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
 }
 #endif
 
@@ -1065,6 +980,18 @@ __global__ void __launch_bounds__(512, 2) zarc_zge_match_deep(ZgeParams P, const
                                                            uint64_t *__restrict__ seq_scratch, uint8_t *__restrict__ lit_scratch, uint32_t *__restrict__ queue,
                                                            uint32_t *__restrict__ far_scratch)
 {
-    __shared__ MatchLds<14, false> L;
-    zge_match_body<14, 4, 10, 16, 2, true, 1, 0, 0, 8, false, false, 0>(L, P, src_base, src_off, src_len, order, units, n_units, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
+    __shared__ MatchLds<13, false> L;
+    zge_match_body<13, 4, 10, 16, 2, true, 1, 0, 0, 32, false, false, 0, 6, 5, true>(L, P, src_base, src_off, src_len, order, units, n_units, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
 }
+
+#ifdef ZARC_GPU_DIAG
+__global__ void __launch_bounds__(512, 2) zarc_zge_match_deep_diag(ZgeParams P, const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off,
+                                                           const uint64_t *__restrict__ src_len, const uint32_t *__restrict__ order, const uint32_t *__restrict__ units, uint32_t n_units,
+                                                           const uint64_t *__restrict__ block_prefix, ZgeBlock *__restrict__ blocks,
+                                                           uint64_t *__restrict__ seq_scratch, uint8_t *__restrict__ lit_scratch, uint32_t *__restrict__ queue,
+                                                           uint32_t *__restrict__ far_scratch)
+{
+    __shared__ MatchLds<13, false> L;
+    zge_match_body<13, 4, 10, 16, 2, true, 1, 0, 0, 32, true, false, 0, 6, 5, true>(L, P, src_base, src_off, src_len, order, units, n_units, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
+}
+#endif
