@@ -97,8 +97,9 @@ enum {
 /* What the engine does with the libzstd ids (pack.rs:86-217 forwards them all):
  *   CompressionLevel  -131072..22 accepted.  Levels <= 8 run the level-3 finder (one LDS table of 2^15 16-bit entries on a 5-byte
  *                     hash, candidates up to 64 KiB back; a 2^16-bucket far table in HBM on a 12-byte hash, content-sampled one
- *                     position in 16; one-byte lazy evaluation from level 2 on); levels >= 9 run the deep finder (2^14-entry LDS
- *                     tables, 4-byte short hash, 2-way far tables on both hashes).  Levels 10..22 are NOT stronger than 9 and
+ *                     position in 16; one-byte lazy evaluation from level 2 on); levels >= 9 run the deep finder (two tagged LDS
+ *                     tables, 4-byte short hash, 2-way far tables on both hashes, a parse that tries the live repeat offsets in
+ *                     two more rounds per tile and looks two bytes ahead).  Levels 10..22 are NOT stronger than 9 and
  *                     negative levels are NOT faster than 1: there are exactly these two finders.
  *   WindowLog         honoured for the frame header / the farthest offset (10..27; default 21, level >= 9: 22).
  *   MinMatch          4..7 honoured (3 is raised to 4); default 5, level >= 9: 4.

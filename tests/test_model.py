@@ -46,7 +46,7 @@ def test_model_ratio_within_5_percent_of_libzstd_level3(oracle, corpus, libzstds
 
 
 def test_model_level9_within_5_percent_of_libzstd_level9(oracle, corpus, libzstds):
-    """BASELINE configs[3] is level 9: the deep finder (2^14-entry tables, 4-byte short hash) against libzstd -9."""
+    """BASELINE configs[3] is level 9: the deep finder (4-byte short hash, two-way far tables, live recent-offset rounds) against libzstd -9."""
     z = next((z for z in libzstds if z.version.startswith("1.5")), None) or (libzstds[0] if libzstds else None)
     if z is None:
         pytest.skip("no libzstd on this box")

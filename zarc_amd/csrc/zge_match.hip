@@ -4,10 +4,9 @@
 // (called per entry from Encoder::add_data_frame, crates/zarc/src/encode/content_frame.rs:41).
 //
 // Persistent 512-thread workgroups, TWO per CU (their waits overlap), take frames from a queue (largest first).  The
-// two position hash tables of a frame (8-byte "long" hash and 5-byte "short" hash, 2^13 u32 entries each = 64 KiB)
-// stay in LDS for the whole frame, so matches reach back across all earlier blocks (up to the 2 MiB table segment).
-// Each entry packs (position+1) << 10 | 10 hash check bits: a lookup rejects most false candidates without touching
-// memory.  The kernel is bound by VALU issue and by barrier / L2 waits, not by HBM.
+// near hash table(s) of a frame -- level 3: one table of 2^15 16-bit entries on the 5-byte hash; level >= 9: an 8-byte "long" and a
+// 4-byte "short" hash table of 2^13 u32 entries each, an entry packing (position+1) << 10 | 10 hash check bits -- are 64 KiB of LDS
+// and stay there for the whole frame, so matches reach back across all earlier blocks (64 KiB / the 2 MiB table segment).  The kernel is bound by VALU issue and by barrier / L2 waits, not by HBM.
 // A block (<= 128 KiB) is swept in tiles of 1024 positions, two positions per thread (t and t+512):
 //   S0/S1 the tile's window (recent-offset range before it, compare overrun after it) goes to LDS -- the dword of the
 //         NEXT tile is requested now and parked in a register; every position is hashed (32-bit multiplies)
@@ -149,8 +148,10 @@ __device__ __forceinline__ uint32_t tile_end(uint32_t tile, uint32_t n)
 
 } // namespace
 
-// The body is compiled twice: the level-3 finder (2^13-entry tables, 5-byte short hash, two workgroups per CU) and the deep
-// one for level >= 9 (2^14-entry tables = 128 KiB of LDS, one workgroup per CU; 4-byte short hash, cheaper matches).
+// The body is compiled twice: the level-3 finder (one 2^15-entry 16-bit table on the 5-byte hash, content-sampled far table, two
+// workgroups per CU) and the deep one for level >= 9 (two tagged 2^13-entry tables, 4-byte short hash, cheaper matches, two-way far
+// tables on both hashes, literals priced at LITC 6, a second lazy step LAZY2, and REP_PASS: rounds of the live recent-offset pass;
+// 219 registers per thread, so one workgroup per CU).
 // DIAG: the timing-only switches of ZARC_GPU_DBG are compiled into a separate instantiation, so the product kernels carry none of
 // their scalar tests
 // F_FAR_LOG / FAR_WAYS / FAR_SHORT / FAR_STEP_LOG / FAR_RES_LOG / FAR_SKIP / FAR_BACK: the far tables (0 ways = none); the engine checks that
