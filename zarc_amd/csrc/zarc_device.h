@@ -110,6 +110,15 @@ __device__ __forceinline__ uint32_t load_l2_u32(const uint32_t *p)
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
 }
+// two adjacent entries (8-byte aligned) in one request
+__device__ __forceinline__ uint64_t load_l2_u64(const uint32_t *p)
+{
+#ifdef ZARC_HIPEMU
+    return (uint64_t)p[0] | ((uint64_t)p[1] << 32);
+#else
+    return __hip_atomic_load((const uint64_t *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
 __device__ __forceinline__ void atomic_max_l2(uint32_t *p, uint32_t v)
 {
 #ifdef ZARC_HIPEMU

@@ -426,10 +426,16 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG, NEAR16> &L, con
                             ftag[u][0] = hf & TAG_MASK;
                             if (FAR_SHORT) ftag[u][1] = hg & TAG_MASK;
                             if (!far_ahead) {
+                                if (FAR_WAYS == 2) { // both ways of a bucket in one 8-byte request
+                                    const uint64_t el = zd::load_l2_u64(far_l + (size_t)(hf >> TAG_BITS) * 2);
+                                    fe[u][0] = (uint32_t)el; fe[u][1] = (uint32_t)(el >> 32);
+                                    if (FAR_SHORT) { const uint64_t es = zd::load_l2_u64(far_s + (size_t)(hg >> TAG_BITS) * 2); fe[u][2] = (uint32_t)es; fe[u][3] = (uint32_t)(es >> 32); }
+                                } else {
 #pragma unroll
                                 for (int w = 0; w < FAR_WAYS; w++) {
                                     fe[u][w] = zd::load_l2_u32(far_l + ((size_t)(hf >> TAG_BITS) * FAR_WAYS + w));
                                     if (FAR_SHORT) fe[u][FAR_WAYS + w] = zd::load_l2_u32(far_s + ((size_t)(hg >> TAG_BITS) * FAR_WAYS + w));
+                                }
                                 }
                             } else {
 #pragma unroll
@@ -575,10 +581,16 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG, NEAR16> &L, con
                     if (mine && pn < far_end && !(pn & far_rmask) && !(dbg & 2048)) {
                         const uint64_t v = zd::load_u64(tbn + (uint32_t)(pn + wofs_n));
                         const uint32_t hf = hash_far32(v, zd::load_u32(tbn + (uint32_t)(pn + 8 + wofs_n))) >> far_shift, hg = hash_short32(v, SHORT_BYTES) >> far_shift;
+                        if (FAR_WAYS == 2) { // both ways of a bucket in one 8-byte request
+                            const uint64_t el = zd::load_l2_u64(far_l + (size_t)(hf >> TAG_BITS) * 2);
+                            fnext[u][0] = (uint32_t)el; fnext[u][1] = (uint32_t)(el >> 32);
+                            if (FAR_SHORT) { const uint64_t es = zd::load_l2_u64(far_s + (size_t)(hg >> TAG_BITS) * 2); fnext[u][2] = (uint32_t)es; fnext[u][3] = (uint32_t)(es >> 32); }
+                        } else {
 #pragma unroll
                         for (int w = 0; w < FAR_WAYS; w++) {
                             fnext[u][w] = zd::load_l2_u32(far_l + ((size_t)(hf >> TAG_BITS) * FAR_WAYS + w));
                             if (FAR_SHORT) fnext[u][FAR_WAYS + w] = zd::load_l2_u32(far_s + ((size_t)(hg >> TAG_BITS) * FAR_WAYS + w));
+                        }
                         }
                     } else {
 #pragma unroll
