@@ -51,6 +51,9 @@ typedef struct {
     /* Round 3, the level >= 9 finder: */
     int rep_pass;     /* rounds of the live recent-offset pass per tile (zstd_enc_model.c: matchfind_block), 0 = none */
     int lazy2_delta;  /* > 0: a selected match also steps aside for one two bytes ahead that scores more than this much higher */
+    /* Round 3, long matches: */
+    int far_cap;      /* > cap: far candidates are compared over this many bytes (a match word holds lengths below 1024: 960 + far_back) */
+    int cont_cap;     /* > 0: continuation guess over this many bytes at the parse cursor of a tile (zstd_enc_model.c: matchfind_block) */
 } zge_params;
 
 typedef struct { uint32_t ll, ml, off, ofv; } zge_seq;

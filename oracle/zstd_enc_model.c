@@ -730,6 +730,7 @@ static uint32_t matchfind_block(mf_ctx *c, size_t bs, size_t be, zge_seq *seq, u
     const uint8_t *src = c->src;
     size_t pos = bs, tile, lp = 0, prev_lp = 0;
     uint32_t nseq = 0, erep0 = c->erep0, erep1 = c->erep1, i;
+    size_t cont_pos = 0, cont_end = 0; uint32_t cont_off = 0;
     /* positions with fewer than 8 readable bytes are never hashed */
     size_t hash_end = c->n >= 8 ? c->n - 7 : 0; /* p < hash_end is hashable */
     size_t far_end = c->n >= 12 ? c->n - 11 : 0; /* the far tables' long hash reads 12 bytes */
@@ -857,6 +858,24 @@ static uint32_t matchfind_block(mf_ctx *c, size_t bs, size_t be, zge_seq *seq, u
                 sc = score_of(P, len, off, is_rep);
                 if (sc > best_score) { best_score = sc; best_len = len; best_off = off; best_rep = is_rep; best_far = k >= 1 && k < ntab; best_fol = k == 0 && fol; }
             }
+            /* A far candidate that WON with all `cap` bytes equal is compared on, up to far_cap bytes (the kernel: the whole wave, one
+             * trip): a long repeat MiB back is found at one sampled position, and every piece boundary would have to find it again. */
+            if (P->far_cap > P->cap && best_far && best_len == (uint32_t)P->cap && limit > (uint32_t)P->cap) {
+                best_len = match_len(src, p, p - best_off, limit < (uint32_t)P->far_cap ? limit : (uint32_t)P->far_cap);
+                best_score = score_of(P, best_len, best_off, best_rep);
+            }
+            /* Continuation guess (cont_cap > 0): when the last selected match of the previous searched tile ends exactly at the parse
+             * cursor, the position at the cursor tries that match's offset once more, over cont_cap bytes -- a match cut at `cap` (or
+             * far_cap) goes on at the same offset however far back its source lies (the recent-offset guesses above only look inside the
+             * staged window); the entropy stage joins the pieces into one sequence.  Ranks last, no backward extension (the bytes in front
+             * of it are the previous piece). */
+            if (P->cont_cap > 0 && cont_off && cont_pos == p && cont_off <= p && cont_off <= c->window) {
+                uint32_t ccap = limit < (uint32_t)P->cont_cap ? limit : (uint32_t)P->cont_cap, len = match_len(src, p, p - cont_off, ccap);
+                if (len >= (uint32_t)P->min_rep) {
+                    int32_t sc = score_of(P, len, cont_off, 1);
+                    if (sc > best_score) { best_score = sc; best_len = len; best_off = cont_off; best_rep = 1; best_far = 0; best_fol = 1; }
+                }
+            }
             if (best_len && best_score > 0) {
                 uint32_t back = 0, back_cap = best_far ? (uint32_t)P->far_back : (uint32_t)P->back_cap;
                 m->len = best_len; m->off = best_off; m->is_rep = (uint8_t)best_rep;
@@ -966,12 +985,13 @@ static uint32_t matchfind_block(mf_ctx *c, size_t bs, size_t be, zge_seq *seq, u
                     seq[nseq].ll = (uint32_t)(lp - prev_lp); seq[nseq].ml = c->M2[t].len; seq[nseq].off = c->M2[t].off; seq[nseq].ofv = 0;
                     prev_lp = lp;
                     nseq++;
-                    last1 = last0; last0 = c->M2[t].off; nsel++;
+                    last1 = last0; last0 = c->M2[t].off; nsel++; cont_end = tile + t + c->M2[t].len;
                 } else {
                     lit[lp++] = src[tile + t];
                 }
             }
             /* offset guesses for the next tile: offsets of the last two matches selected so far */
+            cont_off = (nsel && cont_end == pos) ? last0 : 0; cont_pos = pos;
             if (nsel >= 2) { erep0 = last0; erep1 = last1; }
             else if (nsel == 1) { erep1 = erep0; erep0 = last0; }
         }
@@ -1013,6 +1033,7 @@ void zge_default_params(zge_params *P, int level)
         /* round 3: the parse -- live recent offsets (two rounds), a second lazy step, literals priced at 6; near tables of 2^13 entries
          * (the far tables hold what they forget: no ratio lost on any item of tests/support/realdata.py, and two workgroups fit a CU) */
         P->rep_pass = 2; P->lazy2_delta = 5; P->lit_cost = 6; P->long_log = 13; P->short_log = 13;
+        P->cont_cap = 960; /* a match cut at `cap` goes on at the tile's cursor (the level-3 kernel has no register to spare for it: DESIGN.md 4.1) */
     }
 }
 

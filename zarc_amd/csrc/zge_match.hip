@@ -57,6 +57,7 @@ static_assert(PER == 2, "the kernel is written for two positions per thread");
 constexpr int CHUNKS = TILE / 64;
 constexpr int TAG_BITS = 10;
 constexpr uint32_t TAG_MASK = (1u << TAG_BITS) - 1;
+struct U128 { uint64_t lo, hi; };
 constexpr int CAP_MAX = 256;
 constexpr int REP_BACK_MAX = 256;
 constexpr int TB_BYTES = 12 + REP_BACK_MAX + TILE + CAP_MAX + 24; // rep window + 8 bytes before the tile, compare overrun after it
@@ -75,7 +76,9 @@ template <int TAB_LOG, bool NEAR16> struct MatchLds {
     uint32_t ctrl[16];
     unsigned long long prof[15]; // ZARC_GPU_DBG & 1024: shader-clock ticks per stage, workgroup view from thread 0
 };
-enum { K_POS = 0, K_REP0 = 1, K_REP1 = 2, K_FLAG = 3, K_SLOT = 4, K_ANY = 5, K_CHG = 6 /* .. 9: a round of the live recent-offset pass changed a match */ };
+enum { K_POS = 0, K_REP0 = 1, K_REP1 = 2, K_FLAG = 3, K_SLOT = 4, K_ANY = 5, K_CHG = 6 /* .. 9: a round of the live recent-offset pass changed a match */,
+       K_CEND = 10 /* block position behind the last selected match of the last searched tile (0xFFFFFFFF: none) */,
+       K_CLEN = 11 /* length of the continuation guess at the tile's cursor */ };
 
 // Hashes from 32-bit multiplies only (a 64-bit multiply is four quarter-rate VALU ops on gfx950).
 // The near and the far tables index with different numbers of top bits of the SAME 32-bit product.
@@ -109,13 +112,37 @@ template <int MATCH_COST, int LITC> __device__ __forceinline__ int32_t score_mc(
 }
 #define score_of(P_, len_, off_, rep_) score_mc<MATCH_COST, LITC>((len_), (off_), (rep_))
 
-struct U128 { uint64_t lo, hi; };
-
-// a match in one LDS word: offset (21 bits) | length (9 bits) << 21 | recent-offset flag << 30
-__device__ __forceinline__ uint32_t match_pack(uint32_t off, uint32_t len, bool rep) { return off | (len << 21) | ((rep ? 1u : 0u) << 30); }
+// a match in one LDS word: offset (21 bits) | length (9 bits; WIDE, the finder with the continuation guess: 10 bits) << 21 | recent-offset flag << 30 (WIDE: 31)
+template <bool WIDE> __device__ __forceinline__ uint32_t match_pack_w(uint32_t off, uint32_t len, bool rep) { return off | (len << 21) | ((rep ? 1u : 0u) << (WIDE ? 31 : 30)); }
 __device__ __forceinline__ uint32_t match_off(uint32_t m) { return m & 0x1FFFFFu; }
-__device__ __forceinline__ uint32_t match_len(uint32_t m) { return (m >> 21) & 0x1FFu; }
-__device__ __forceinline__ bool match_rep(uint32_t m) { return (m >> 30) & 1u; }
+template <bool WIDE> __device__ __forceinline__ uint32_t match_len_w(uint32_t m) { return (m >> 21) & (WIDE ? 0x3FFu : 0x1FFu); }
+template <bool WIDE> __device__ __forceinline__ bool match_rep_w(uint32_t m) { return WIDE ? (m >> 31) != 0 : ((m >> 30) & 1u) != 0; }
+#define match_pack(o_, l_, r_) match_pack_w<(CONT_CAP > 0)>((o_), (l_), (r_))
+#define match_len(m_) match_len_w<(CONT_CAP > 0)>(m_)
+#define match_rep(m_) match_rep_w<(CONT_CAP > 0)>(m_)
+constexpr int LONG_CAP = 960; // cont_cap: a length stays below 2^10
+
+// Common prefix of frame positions p and p - off from byte `from` on, at most `maxlen` bytes in all, by ONE wave in one round trip:
+// lane j compares bytes [from + 16 j, from + 16 j + 16) of both sides out of global memory (1 KiB per trip; the per-lane compare
+// loops of S3 advance 16 bytes per trip).  Every argument is the same in all lanes.  Loads stay below maxlen + 16 <= block end + 16.
+__device__ __forceinline__ uint32_t wave_match_ext(const uint8_t *src, uint32_t p, uint32_t off, uint32_t from, uint32_t maxlen, int lane)
+{
+    static_assert(LONG_CAP <= 1024, "one trip of 64 x 16 bytes");
+    const uint32_t at = from + 16u * (uint32_t)lane;
+    const bool act = at < maxlen;
+    U128 a{0, 0}, b{0, 0};
+    if (act) { __builtin_memcpy(&a, src + (p + at), 16); __builtin_memcpy(&b, src + (p - off + at), 16); }
+    const uint64_t xl = a.lo ^ b.lo, xh = a.hi ^ b.hi;
+    const uint32_t mis = xl ? (uint32_t)(zd::ctz64(xl) >> 3) : (xh ? 8u + (uint32_t)(zd::ctz64(xh) >> 3) : 16u);
+    const uint64_t bad = zd::ballot(act && mis < 16u);
+    uint32_t len = maxlen;
+    if (bad) {
+        const uint32_t first = (uint32_t)zd::ctz64(bad);
+        len = from + 16u * first + zd::readlane(mis, first);
+        if (len > maxlen) len = maxlen;
+    }
+    return len;
+}
 
 // The window of a tile staged in LDS: frame bytes [lo, hi) = rep_back + 8 bytes before the tile .. cap + 16 after it,
 // fetched as whole dwords starting at the aligned address `w` (one dword per thread: TB_BYTES / 4 <= THREADS).
@@ -163,7 +190,7 @@ __device__ __forceinline__ uint32_t tile_end(uint32_t tile, uint32_t n)
 // relative positions, so a repeat is found when it contains one sample: 64 lookups + 64 inserts per 1024-position tile at FAR_CDC 4
 // instead of 256 + 128, and every thread asks for its OWN positions (no hand-over between lanes).
 template <int TAB_LOG, int SHORT_BYTES, int MATCH_COST, int F_FAR_LOG, int FAR_WAYS, bool FAR_SHORT, int FAR_STEP_LOG, int FAR_RES_LOG, int FAR_SKIP, int FAR_BACK, bool DIAG,
-          bool NEAR16, int FAR_CDC, int LITC, int LAZY2, bool REP_PASS>
+          bool NEAR16, int FAR_CDC, int LITC, int LAZY2, bool REP_PASS, int CONT_CAP>
 __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG, NEAR16> &L, const ZgeParams &P, const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off,
                                                const uint64_t *__restrict__ src_len, const uint32_t *__restrict__ order, const uint32_t *__restrict__ units, uint32_t n_units,
                                                const uint64_t *__restrict__ block_prefix, ZgeBlock *__restrict__ blocks,
@@ -273,7 +300,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG, NEAR16> &L, con
         // ---- RLE block detection: every byte equals the first one (8 bytes per load; blocks start 16-byte aligned).  Nearly
         // every block is cleared by a look at its first KiB; only a block that passes that look is read in full here, so the
         // input is not fetched twice ----
-        if (tid == 0) { L.ctrl[K_FLAG] = 0; L.ctrl[K_POS] = 0; }
+        if (tid == 0) { L.ctrl[K_FLAG] = 0; L.ctrl[K_POS] = 0; if (CONT_CAP) L.ctrl[K_CEND] = 0xFFFFFFFFu; }
         zd::lds_barrier();
         const uint8_t first = blen ? src[bs] : 0;
         const uint64_t pat = 0x0101010101010101ull * first;
@@ -304,7 +331,9 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG, NEAR16> &L, con
             zd::lds_barrier(); // K_POS / K_REP* of the previous tile are final; LDS work arrays are free again
             ZGE_PROF(0);
             const uint32_t pos = bs + L.ctrl[K_POS];
-            if (pos >= tend) continue; // whole tile already covered by a match: skip it (nothing is inserted)
+            // continuation guess: the last selected match of the last searched tile ends exactly at the cursor
+            const bool cont = CONT_CAP && L.ctrl[K_CEND] == L.ctrl[K_POS] && pos >= tile;
+            if (pos >= tend) { if (NFAR) zd::wait_vmem(); continue; } // whole tile already covered by a match: skip it (nothing is inserted; the next searched tile asks for its far entries in S1: the last inserts are waited for here)
             if (skip_left) { // cold stretch: the tile is not searched -- its bytes go straight from HBM to the literals
                 skip_left--;
                 const uint32_t start = (uint32_t)((pos > tile ? pos : tile) - tile);
@@ -318,11 +347,23 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG, NEAR16> &L, con
                     }
                 }
                 lp += tcount - start;
+                if (NFAR) zd::wait_vmem(); // as above: the next searched tile looks its far entries up in S1
                 zd::lds_barrier(); // every thread has read K_POS
                 if (tid == 0) L.ctrl[K_POS] = (uint32_t)(tend - bs);
                 continue;
             }
             const uint32_t erep0 = L.ctrl[K_REP0], erep1 = L.ctrl[K_REP1];
+            if (CONT_CAP && cont) { // uniform, rare.  Continuation guess (model: cont_cap): a match cut at its cap goes on at the same offset, however
+                // far back its source lies: the wave that owns the cursor's position compares up to CONT_CAP bytes in one trip, here, where
+                // few registers are live; the length waits in LDS for S3 (barriers in between), where it ranks behind every other candidate.
+                const uint32_t idx_c = pos - tile; // < tcount: a tile the cursor has passed is not searched
+                if (wave == (int)(idx_c >> 7)) {
+                    const uint32_t limit = (uint32_t)(be - pos);
+                    uint32_t clen = 0;
+                    if (erep0 != 0 && erep0 <= pos && erep0 <= window) clen = wave_match_ext(src, pos, erep0, 0, limit < (uint32_t)CONT_CAP ? limit : (uint32_t)CONT_CAP, lane);
+                    if (lane == 0) L.ctrl[K_CLEN] = clen;
+                }
+            }
             if (tid == 0) L.ctrl[K_ANY] = 0; // set by any position of this tile that finds a match
             if (REP_PASS && tid < 4) L.ctrl[K_CHG + tid] = 0;
 
@@ -529,6 +570,9 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG, NEAR16> &L, con
                     hc[k * 64 + lane] = e[k] ^ (h[k] & TAG_MASK);
                 zd::wave_priority<0>();
             }
+            // far inserts of the PREVIOUS searched tile (and everything else this wave has in flight: this tile's far sources, needed next)
+            // are complete before any wave asks for the next tile's far entries in S3
+            if (NFAR) zd::wait_vmem();
             zd::lds_barrier();
             ZGE_PROF(3);
             // ---- S3: own candidates {long, short, 2 recent offsets}.  The kernel is bound by VALU issue, so the loads carry no
@@ -779,6 +823,17 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG, NEAR16> &L, con
                     }
                 }
             }
+            if (CONT_CAP && cont) { // uniform.  The continuation guess (model: cont_cap; compared at the top of the tile): ranks last, recent-offset cost, no backward extension
+                const uint32_t idx_c = pos - tile;
+                if (wave == (int)(idx_c >> 7) && (uint32_t)lane == (idx_c & 63u)) {
+                    const uint32_t clen = L.ctrl[K_CLEN];
+                    if (clen >= (uint32_t)F_MIN_REP) {
+                        const int32_t sc = score_of(P, clen, erep0, true);
+                        if (idx_c & 64u) { if (sc > b_score[1]) { b_score[1] = sc; b_len[1] = clen; b_off[1] = erep0; b_flags[1] = 1u | 4u; } }
+                        else { if (sc > b_score[0]) { b_score[0] = sc; b_len[0] = clen; b_off[0] = erep0; b_flags[0] = 1u | 4u; } }
+                    }
+                }
+            }
 #pragma unroll
             for (int u = 0; u < PER; u++) {
                 const uint32_t idx = ZGE_IDX(u);
@@ -818,7 +873,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG, NEAR16> &L, con
             ZGE_PROF(11);
             // own match -> a0 (each thread overwrites only the candidate slots it has just read itself: no barrier).  A match
             // fits one word: offsets stay below 2^21 (table positions restart every 2^seg_log <= 2^21 bytes, recent-offset
-            // guesses are shorter still) and lengths below 2^9 (cap 256 + 8 bytes of backward extension).
+            // guesses are shorter still) and lengths below 2^10 (the continuation guess: LONG_CAP 960; every other candidate cap 256 + FAR_BACK).
 #pragma unroll
             for (int u = 0; u < PER; u++) L.a0[ZGE_IDX(u)] = match_pack(mo[u], mw[u] & 0xFFFF, (mw[u] >> 24) & 1);
             if (mo[0] | mo[1]) L.ctrl[K_ANY] = 1; // benign race: every writer stores 1
@@ -917,10 +972,9 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG, NEAR16> &L, con
 #undef ZGE_FIRST
             }
             }
-            // The far inserts of this tile (issued after S3, a third of a tile ago) must be in L2 before the next tile's lookups: every wave
-            // waits for its own here -- ahead of the stores below, which nobody waits for -- and the barrier at the top of the next tile
-            // does the rest.
-            if (NFAR) zd::wait_vmem();
+            // (The far inserts of this tile, issued after S3, must be in L2 before the next lookups go out -- those of the tile after the
+            // next, in the next tile's S3.  Every wave waits for its own just before the barrier in front of that S3, i.e. while the table
+            // wave is in S2: two thirds of a tile later instead of a third, and in time the other waves spend at that barrier anyway.)
             // counts of the chunks before mine: a 16-lane scan of the packed per-chunk counts (every wave repeats it)
             uint32_t sel_total, lit_total, sel_before[PER], lit_before[PER];
             {
@@ -946,7 +1000,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG, NEAR16> &L, con
                     seq_out[nseq + my_sel_idx] = zge_pack_seq(lp + my_lit_idx, fw[u] & 0xFFFF, fo[u]);
                     // offset guesses for the next tile: the offsets of the last two matches selected so far (every thread
                     // took its copy of the old ones at the top of the tile, so they can be replaced in place)
-                    if (my_sel_idx + 1 == sel_total) { L.ctrl[K_REP0] = fo[u]; if (sel_total == 1) L.ctrl[K_REP1] = erep0; }
+                    if (my_sel_idx + 1 == sel_total) { L.ctrl[K_REP0] = fo[u]; if (sel_total == 1) L.ctrl[K_REP1] = erep0; if (CONT_CAP) L.ctrl[K_CEND] = (uint32_t)(tile - bs) + ZGE_IDX(u) + (fw[u] & 0xFFFF); }
                     if (my_sel_idx + 2 == sel_total) L.ctrl[K_REP1] = fo[u];
                 }
                 if ((mlit[u] >> lane) & 1) lit_out[lp + my_lit_idx] = (uint8_t)p8[u];
@@ -956,12 +1010,16 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG, NEAR16> &L, con
             ZGE_PROF(8);
         }
         if (tid == 0) { rec->nseq = nseq; rec->nlit = lp; }
+        if (NFAR) zd::wait_vmem(); // the block's last far inserts: the slab may be cleared next (new segment, next frame)
         zd::lds_barrier();
     }
     } // next frame from the queue
     if ((dbg & 1024) && tid < 15) atomicAdd((unsigned long long *)(queue + 2) + tid, L.prof[tid]);
 }
 #undef score_of
+#undef match_pack
+#undef match_len
+#undef match_rep
 
 __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off,
                                                       const uint64_t *__restrict__ src_len, const uint32_t *__restrict__ order, const uint32_t *__restrict__ units, uint32_t n_units,
@@ -970,7 +1028,7 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                                                       uint32_t *__restrict__ far_scratch)
 {
     __shared__ MatchLds<15, true> L;
-    zge_match_body<15, 5, 12, 16, 1, false, 5, 2, 64, 48, false, true, 4, 5, 0, false>(L, P, src_base, src_off, src_len, order, units, n_units, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
+    zge_match_body<15, 5, 12, 16, 1, false, 5, 2, 64, 48, false, true, 4, 5, 0, false, 0>(L, P, src_base, src_off, src_len, order, units, n_units, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
 }
 
 #ifdef ZARC_GPU_DIAG
@@ -983,7 +1041,7 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match_diag(ZgeParams P, const
                                                            uint32_t *__restrict__ far_scratch)
 {
     __shared__ MatchLds<15, true> L;
-    zge_match_body<15, 5, 12, 16, 1, false, 5, 2, 64, 48, true, true, 4, 5, 0, false>(L, P, src_base, src_off, src_len, order, units, n_units, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
+    zge_match_body<15, 5, 12, 16, 1, false, 5, 2, 64, 48, true, true, 4, 5, 0, false, 0>(L, P, src_base, src_off, src_len, order, units, n_units, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
 }
 #endif
 
@@ -994,7 +1052,7 @@ __global__ void __launch_bounds__(512, 2) zarc_zge_match_deep(ZgeParams P, const
                                                            uint32_t *__restrict__ far_scratch)
 {
     __shared__ MatchLds<13, false> L;
-    zge_match_body<13, 4, 10, 16, 2, true, 1, 0, 0, 32, false, false, 0, 6, 5, true>(L, P, src_base, src_off, src_len, order, units, n_units, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
+    zge_match_body<13, 4, 10, 16, 2, true, 1, 0, 0, 32, false, false, 0, 6, 5, true, LONG_CAP>(L, P, src_base, src_off, src_len, order, units, n_units, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
 }
 
 #ifdef ZARC_GPU_DIAG
@@ -1005,6 +1063,6 @@ __global__ void __launch_bounds__(512, 2) zarc_zge_match_deep_diag(ZgeParams P, 
                                                            uint32_t *__restrict__ far_scratch)
 {
     __shared__ MatchLds<13, false> L;
-    zge_match_body<13, 4, 10, 16, 2, true, 1, 0, 0, 32, true, false, 0, 6, 5, true>(L, P, src_base, src_off, src_len, order, units, n_units, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
+    zge_match_body<13, 4, 10, 16, 2, true, 1, 0, 0, 32, true, false, 0, 6, 5, true, LONG_CAP>(L, P, src_base, src_off, src_len, order, units, n_units, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
 }
 #endif

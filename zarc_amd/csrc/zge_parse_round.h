@@ -69,7 +69,7 @@
                     if (idx >= start && idx < tcount && !(dbg & 32)) lit_out[lp + (idx - start)] = (uint8_t)p8[u];
                 }
                 lp += tcount - start;
-                if (tid == 0) L.ctrl[K_POS] = (uint32_t)(tend - bs);
+                if (tid == 0) { L.ctrl[K_POS] = (uint32_t)(tend - bs); if (CONT_CAP) L.ctrl[K_CEND] = 0xFFFFFFFFu; }
                 cold++;
                 if (cold >= 2) skip_left = cold >= 4 ? 7u : (1u << (cold - 1)) - 1;
                 if (NFAR) zd::wait_vmem(); // the far inserts above are in L2 before the next tile's lookups (rare path: a searched tile without any match)
