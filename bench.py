@@ -213,9 +213,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", choices=["c2", "c4", "c5", "small"], default="c2", help="c2: BASELINE configs[1]/[2] (the headline); c4 / c5: configs[3] / [4] shapes; small: log-normal sizes with median 822 B (use --entries 1000000)")
+    ap.add_argument("--config", choices=["c2", "c4", "c5", "small"], default="c2", help="c2: BASELINE configs[1]/[2] (the headline); c4 / c5: configs[3] / [4] shapes; small: a million entries of log-normal sizes, median 822 B")
     ap.add_argument("--gib", type=float, default=32.0, help="c4 / c5: uncompressed GiB per GPU")
-    ap.add_argument("--entries", type=int, default=10000, help="entries per GPU (BASELINE configs[1]: 10000)")
+    ap.add_argument("--entries", type=int, default=None, help="entries per GPU (default: BASELINE configs[1]'s 10000; --config small: 1000000)")
     ap.add_argument("--size", type=int, default=1 << 20, help="bytes per entry (BASELINE configs[1]: 1 MiB)")
     ap.add_argument("--cpu-sample", type=int, default=1024, help="entries timed on one host thread for cpu_baseline (rank 0, N=1)")
     ap.add_argument("--host-entries", type=int, default=8192, help="entries (of the resident batch) sent through the host-pointer entry points")
@@ -224,6 +224,8 @@ def main():
     ap.add_argument("--dec-groups", type=int, default=0, help="diagnostics: ZARC_GPU_PX_DEC_GROUPS (0 = the engine decides by the batch's shape)")
     ap.add_argument("--kind", type=int, default=-1, help="diagnostics: use one corpus kind for every entry (default: round-robin)")
     args = ap.parse_args()
+    if args.entries is None:
+        args.entries = 1000000 if args.config == "small" else 10000
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
