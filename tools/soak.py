@@ -7,7 +7,7 @@ import os, random, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "support"))
 from zarc_amd import Engine, _lib
-import harness
+import harness, realdata
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
@@ -26,8 +26,10 @@ while time.time() < t_end:
     for _ in range(n):
         size = rnd.choice([0, 1, rnd.randrange(2, 400), rnd.randrange(400, 70000), rnd.randrange(70000, 600000), rnd.randrange(600000, 3 << 20),
                            rnd.randrange(3 << 20, 20 << 20) if rnd.randrange(5) == 0 else rnd.randrange(100000, 200000)])
-        kind = rnd.randrange(4)
-        raw = corpus.entry(rnd.randrange(1 << 30), size, kind)
+        kind = rnd.randrange(6)
+        if kind == 4: raw = realdata.reloc_like(size, seed=rnd.randrange(1 << 30))   # record tables: chains of short repeat-offset matches (the level-9 rounds)
+        elif kind == 5: raw = realdata.loglike(min(size, 2 << 20), seed=rnd.randrange(1 << 30))
+        else: raw = corpus.entry(rnd.randrange(1 << 30), size, kind)
         if rnd.randrange(6) == 0 and size > 64:      # long runs / repeated halves: RLE blocks, overlapping matches, long matches
             raw = raw[:size // 3] + bytes([raw[0]]) * (size // 3) + raw[:size - 2 * (size // 3)]
         if rnd.randrange(5) == 0 and ents and len(ents[-1]) > 1000:   # far repeats: a mutated copy of the previous entry behind other data (far tables)
@@ -35,6 +37,9 @@ while time.time() < t_end:
             for _ in range(rnd.randrange(0, 30)):
                 prev[rnd.randrange(len(prev))] = rnd.randrange(256)
             raw = raw[:len(raw) // 2] + bytes(prev) + ents[-1][:rnd.randrange(0, 100000)]
+        if rnd.randrange(8) == 0 and len(raw) > 4096:   # a long exact repeat far back: pieces cut at the compare cap, the continuation guess
+            k = rnd.randrange(1000, min(len(raw) // 2, 200000))
+            raw = raw + corpus.entry(rnd.randrange(1 << 30), rnd.randrange(70000, 300000), 3) + raw[:k]
         ents.append(raw)
     packed = eng.pack(ents)
     for raw, (frame, dig) in zip(ents, packed):
