@@ -1,11 +1,11 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence for one round (run on the GPU box via gpurun):
 #   kernel trace + stats of the bench command, then FETCH_SIZE and WRITE_SIZE in their own passes.
-# Usage: tools/profile.sh <round-tag> [entries]
+# Usage: tools/profile.sh <round-tag> [entries]      (BENCH_ARGS="--config c4 --gib 8": another workload instead of --entries N)
 TAG=${1:-r01}; N=${2:-2048}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$TAG; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $R/bench.py --entries $N --steps 2 --warmup 1 --no-cpu-baseline --no-host-path"
+CMD="python3 $R/bench.py ${BENCH_ARGS:---entries $N} --steps 2 --warmup 1 --no-cpu-baseline --no-host-path"
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- $CMD > $O/trace.log 2>&1; echo "trace rc=$?"
 timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- $CMD > $O/fetch.log 2>&1; echo "fetch rc=$?"
 timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- $CMD > $O/write.log 2>&1; echo "write rc=$?"
@@ -28,6 +28,7 @@ for name in ("fetch", "write"):
     out[name] = {k: {"dispatches": v[0], "sum": v[1], "per_dispatch": v[1] / max(v[0], 1)} for k, v in agg.items()}
 out["entries"] = $N
 out["entry_bytes"] = 1 << 20
+out["bench_args"] = "${BENCH_ARGS:-}"   # non-empty: another workload than entries x 1 MiB (bench.py quotes roofline.traffic for the default workload only)
 import hashlib
 out["lib_sha16"] = hashlib.sha256(open("$R/zarc_amd/libzarc_gpu.so", "rb").read()).hexdigest()[:16]
 import sys
