@@ -97,3 +97,22 @@ def test_model_joins_the_pieces_of_long_matches(oracle):
     raw = bytes(range(200)) * 20000
     frame, st = oracle.zge_encode(raw, stats=True)
     assert st.seqs == st.blk_comp == 31 and len(frame) < 700
+
+
+def test_model_long_far_repeats_with_far_cap_and_continuation_guess(oracle, corpus, libzstds):
+    """DESIGN.md 4.1, "The cap": a long repeat MiB back is found at one sampled far position and cut after `cap` = 256 bytes; with
+    `far_cap` / `cont_cap` (model parameters: 0 at level 3, where the kernel has no register for them; the level >= 9 kernel has the
+    continuation guess) the pieces go on at the same offset.  The frames stay valid and get smaller; the defaults are what the kernels run."""
+    piece = corpus.entry(4242, 300000, 0)
+    raw = piece + corpus.entry(4243, 2 << 20, 3) + piece[1000:250000] + corpus.entry(4244, 200000, 1) + piece[5000:200000]
+    sizes = {}
+    for name, kw in (("default", {}), ("cont", dict(cont_cap=960)), ("both", dict(far_cap=960, cont_cap=960))):
+        frame = oracle.zge_encode(raw, oracle.params(level=3, **kw))
+        rc, out, used = oracle.zstd_decode(frame, len(raw))
+        assert rc == 0 and out == raw and used == len(frame), name
+        for z in libzstds:
+            assert z.decompress(frame, len(raw))[0] == raw, (name, z.version)
+        sizes[name] = len(frame)
+    assert sizes["both"] <= sizes["cont"] <= sizes["default"], sizes
+    p3, p9 = oracle.params(level=3), oracle.params(level=9)
+    assert (p3.far_cap, p3.cont_cap, p9.far_cap, p9.cont_cap) == (0, 0, 0, 960)   # engine.hip: derive_params sets exactly these
