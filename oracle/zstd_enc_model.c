@@ -970,6 +970,14 @@ static uint32_t matchfind_block(mf_ctx *c, size_t bs, size_t be, zge_seq *seq, u
                     }
                 }
                 }
+                /* a SELECTED match that was cut at the cap goes on at its offset (cont_cap bytes at most): the pieces of a long repeat stay
+                 * one match even where the next piece's position would not have found the offset again (the kernel: one trip of the
+                 * whole wave per such match) */
+                if (P->cont_cap > 0 && c->mark[t] && c->take[t] && c->M2[t].len >= (uint32_t)P->cap) {
+                    uint32_t limit = (uint32_t)(be - p), xcap = limit < (uint32_t)P->cont_cap ? limit : (uint32_t)P->cont_cap;
+                    uint32_t xl = xcap > c->M2[t].len ? match_len(src, p, p - c->M2[t].off, xcap) : 0;
+                    if (xl > c->M2[t].len) { cand *m = &c->M[t]; m->len = xl; m->off = c->M2[t].off; m->is_rep = c->M2[t].is_rep; m->back = 0; }
+                }
                 if (c->mark[t] && c->take[t] && c->M2[t].off != live) { live1 = live; live = c->M2[t].off; }
             }
         }

@@ -958,6 +958,23 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG, NEAR16> &L, con
                             changed = true;
                         }
                     }
+                    if (CONT_CAP) {
+                        // a SELECTED match that was cut at the cap goes on at its offset, CONT_CAP bytes at most (model: the live pass): the pieces
+                        // of a long repeat stay one match even where the next piece's position would not have found the offset again.  One trip of
+                        // the whole wave per such match; none on most data.
+                        const uint32_t flen = fw[u] & 0xFFFFu;
+                        uint64_t ext = msel[u] & zd::ballot(flen >= cap_max);
+                        while (ext) { // uniform
+                            const uint32_t who = (uint32_t)zd::ctz64(ext);
+                            ext &= ext - 1;
+                            const uint32_t p_w = zd::readlane(p, who), len_w = zd::readlane(flen, who), off_w = zd::readlane(fo[u], who);
+                            const uint32_t lim_w = (uint32_t)(be - p_w), maxl = lim_w < (uint32_t)CONT_CAP ? lim_w : (uint32_t)CONT_CAP;
+                            if (maxl > len_w) {
+                                const uint32_t e = wave_match_ext(src, p_w, off_w, len_w, maxl, lane);
+                                if ((uint32_t)lane == who && e > len_w) { mo[u] = fo[u]; mw[u] = e | (fw[u] & (1u << 24)); changed = true; }
+                            }
+                        }
+                    }
                     L.a0[idx] = match_pack(mo[u], mw[u] & 0xFFFF, (mw[u] >> 24) & 1);
                     L.ex[idx] = 0;
                 }
