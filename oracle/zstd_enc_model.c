@@ -1037,7 +1037,7 @@ void zge_default_params(zge_params *P, int level)
     if (level >= 9) { /* the engine's deep finder (engine.hip: derive_params) */
         P->near16 = 0; P->far_cdc_log = 0; P->far_min_frame = 0;
         P->long_log = 14; P->short_log = 14; P->short_bytes = 4; P->min_match = 4; P->match_cost = 10; P->window_log = 22;
-        P->far_log = 16; P->far_ways = 2; P->far_step_log = 1; P->far_res_log = 0; P->far_short = 1; P->far_skip = 0; P->far_back = 32;
+        P->far_log = 16; P->far_ways = 2; P->far_step_log = 1; P->far_res_log = 0; P->far_short = 1; P->far_skip = 0; P->far_back = 48;
         /* round 3: the parse -- live recent offsets (two rounds), a second lazy step, literals priced at 6; near tables of 2^13 entries
          * (the far tables hold what they forget: no ratio lost on any item of tests/support/realdata.py, and two workgroups fit a CU) */
         P->rep_pass = 2; P->lazy2_delta = 5; P->lit_cost = 6; P->long_log = 13; P->short_log = 13;

@@ -116,10 +116,11 @@ CONTRACT = 1.05
 EXCEPTIONS = {
     (3, "hsaco_2m"): (1.22, "GPU code objects (thousands of near-identical kernels, 70x compressible): repeats of 10 - 40 bytes at MiB "
                             "distances; libzstd's 2^17-entry long table holds every position, the sampled far table one in 16"),
-    (9, "elf_mid_4m"): (1.06, "level 9 (libzstd: lazy2, 16 candidates per position): relocation / symbol tables, chains of short repeat-offset "
-                              "matches; the live recent-offset rounds of the tile parse (DESIGN.md 4.1) brought it from 1.18 to 1.052"),
-    (9, "json_node_2m"): (1.06, "level 9: hundreds of tiny files; from 1.09 to 1.051"),
-    (9, "hsaco_2m"): (1.28, "as level 3; level 9 has the continuation guess and goes on with selected matches that were cut at the cap: from 1.54 to 1.26"),
+    (9, "elf_mid_4m"): (1.055, "level 9 (libzstd: lazy2, 16 candidates per position): relocation / symbol tables, chains of short repeat-offset "
+                               "matches; measured 1.049 -- inside the contract by a hair since the live recent-offset rounds (from 1.18), listed so that a "
+                               "box whose copy of the library differs by a few hundred bytes does not fail the gate"),
+    (9, "json_node_2m"): (1.055, "level 9: hundreds of tiny files; measured 1.0497 (from 1.09), listed for the same reason"),
+    (9, "hsaco_2m"): (1.27, "as level 3; level 9 has the continuation guess and goes on with selected matches that were cut at the cap: from 1.54 to 1.245"),
 }
 
 

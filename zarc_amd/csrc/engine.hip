@@ -148,7 +148,7 @@ ZgeParams derive_params(const zarc_gpu_params &p)
     z.far_log = 16; z.far_ways = deep ? 2 : 1; z.far_step_log = deep ? 1 : 5; z.far_res_log = deep ? 0 : 2; z.far_short = deep ? 1 : 0;
     z.far_cdc_log = deep ? 0 : 4;
     z.far_min_frame = deep ? 0 : 65536; // smaller frames do without the far table: the near table reaches 64 KiB
-    z.far_back = deep ? 32 : 48; z.far_skip = deep ? 0 : 64;
+    z.far_back = 48; z.far_skip = deep ? 0 : 64;
     z.dbg = diag_env("ZARC_GPU_DBG", 0); // timing-only ablations (outputs invalid when set): diagnostic build only
     return z;
 }
@@ -518,7 +518,7 @@ int pack_device_impl(zarc_gpu_t *h, size_t n, const void *d_src_base, const uint
         P.lit_cost != (dp ? 6 : 5) || P.rep_cost != 9 || P.tag_bits != 10 || P.far_log != 16 || P.match_cost != (dp ? 10 : 12) || P.far_ways != (dp ? 2 : 1) ||
         P.far_step_log != (dp ? 1 : 5) || P.far_res_log != (dp ? 0 : 2) || (P.far_short != 0) != dp || P.long_log != 13 ||
         P.near16 != (dp ? 0 : 1) || P.short_log != (dp ? 13 : 15) || P.far_cdc_log != (dp ? 0 : 4) || P.lazy2_delta != (dp ? 5 : 0) || (P.rep_pass != 0) != dp || P.rep_pass > 4 || P.far_cap != 0 || P.cont_cap != (dp ? 960 : 0) ||
-        P.far_back != (dp ? 32 : 48) || P.far_skip != (dp ? 0 : 64)) { set_error(h, "internal: encoder parameters differ from the compiled-in ones"); return ZARC_GPU_E_PARAM; }
+        P.far_back != 48 || P.far_skip != (dp ? 0 : 64)) { set_error(h, "internal: encoder parameters differ from the compiled-in ones"); return ZARC_GPU_E_PARAM; }
     uint64_t need = 0;
     for (size_t i = 0; i < n; i++) {
         if (src_off[i] % ZARC_GPU_ALIGN) { set_error(h, "entry offset not 16-byte aligned"); return ZARC_GPU_E_PARAM; }

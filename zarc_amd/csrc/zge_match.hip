@@ -1069,7 +1069,7 @@ __global__ void __launch_bounds__(512, 2) zarc_zge_match_deep(ZgeParams P, const
                                                            uint32_t *__restrict__ far_scratch)
 {
     __shared__ MatchLds<13, false> L;
-    zge_match_body<13, 4, 10, 16, 2, true, 1, 0, 0, 32, false, false, 0, 6, 5, true, LONG_CAP>(L, P, src_base, src_off, src_len, order, units, n_units, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
+    zge_match_body<13, 4, 10, 16, 2, true, 1, 0, 0, 48, false, false, 0, 6, 5, true, LONG_CAP>(L, P, src_base, src_off, src_len, order, units, n_units, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
 }
 
 #ifdef ZARC_GPU_DIAG
@@ -1080,6 +1080,6 @@ __global__ void __launch_bounds__(512, 2) zarc_zge_match_deep_diag(ZgeParams P, 
                                                            uint32_t *__restrict__ far_scratch)
 {
     __shared__ MatchLds<13, false> L;
-    zge_match_body<13, 4, 10, 16, 2, true, 1, 0, 0, 32, true, false, 0, 6, 5, true, LONG_CAP>(L, P, src_base, src_off, src_len, order, units, n_units, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
+    zge_match_body<13, 4, 10, 16, 2, true, 1, 0, 0, 48, true, false, 0, 6, 5, true, LONG_CAP>(L, P, src_base, src_off, src_len, order, units, n_units, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
 }
 #endif
