@@ -54,6 +54,8 @@ typedef struct {
     /* Round 3, long matches: */
     int far_cap;      /* > cap: far candidates are compared over this many bytes (a match word holds lengths below 1024: 960 + far_back) */
     int cont_cap;     /* > 0: continuation guess over this many bytes at the parse cursor of a tile (zstd_enc_model.c: matchfind_block) */
+    int ext_cap;      /* > 0: in a round of rep_pass, a SELECTED match of `cap` bytes or more goes on at its offset, up to this many bytes */
+    int live_reps;    /* 1 = the rounds of rep_pass try the live recent offsets (level >= 9); 0 = they only continue long matches */
 } zge_params;
 
 typedef struct { uint32_t ll, ml, off, ofv; } zge_seq;

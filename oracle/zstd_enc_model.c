@@ -955,7 +955,7 @@ static uint32_t matchfind_block(mf_ctx *c, size_t bs, size_t be, zge_seq *seq, u
                 for (lv = 0; lv < 2; lv++) {
                 uint32_t lo = lv ? live1 : live;
                 if (lv && live1 == live) continue;
-                if (lo && lo + 8 <= p && lo <= c->window && (c->mark[t] || ((t & 63) != 0 && c->mark[t - 1]))) {
+                if (P->live_reps && lo && lo + 8 <= p && lo <= c->window && (c->mark[t] || ((t & 63) != 0 && c->mark[t - 1]))) {
                     cand *m = &c->M[t];
                     uint32_t limit = (uint32_t)(be - p), cap = limit < (uint32_t)P->cap ? limit : (uint32_t)P->cap;
                     uint32_t len = match_len(src, p, p - lo, cap);
@@ -970,11 +970,11 @@ static uint32_t matchfind_block(mf_ctx *c, size_t bs, size_t be, zge_seq *seq, u
                     }
                 }
                 }
-                /* a SELECTED match that was cut at the cap goes on at its offset (cont_cap bytes at most): the pieces of a long repeat stay
+                /* a SELECTED match that was cut at the cap goes on at its offset (ext_cap bytes at most): the pieces of a long repeat stay
                  * one match even where the next piece's position would not have found the offset again (the kernel: one trip of the
                  * whole wave per such match) */
-                if (P->cont_cap > 0 && c->mark[t] && c->take[t] && c->M2[t].len >= (uint32_t)P->cap) {
-                    uint32_t limit = (uint32_t)(be - p), xcap = limit < (uint32_t)P->cont_cap ? limit : (uint32_t)P->cont_cap;
+                if (P->ext_cap > 0 && c->mark[t] && c->take[t] && c->M2[t].len >= (uint32_t)P->cap) {
+                    uint32_t limit = (uint32_t)(be - p), xcap = limit < (uint32_t)P->ext_cap ? limit : (uint32_t)P->ext_cap;
                     uint32_t xl = xcap > c->M2[t].len ? match_len(src, p, p - c->M2[t].off, xcap) : 0;
                     if (xl > c->M2[t].len) { cand *m = &c->M[t]; m->len = xl; m->off = c->M2[t].off; m->is_rep = c->M2[t].is_rep; m->back = 0; }
                 }
@@ -1033,6 +1033,9 @@ void zge_default_params(zge_params *P, int level)
     P->window_log = 21; P->short_window_log = 30;
     P->far_log = 16; P->far_ways = 1; P->far_step_log = 5; P->far_res_log = 2; P->far_short = 0; P->far_skip = 64; P->far_back = 48;
     P->far_min_frame = 65536;
+    /* long matches: one more parse round per tile in which selected matches that were cut at `cap` go on at their offset (no live
+     * recent offsets below level 9); the kernel runs the round only in tiles that have such a match */
+    P->rep_pass = 1; P->live_reps = 0; P->ext_cap = 960;
     P->near16 = 1; P->short_log = 15; P->far_cdc_log = 4; /* round 3: one 16-bit near table of 2^15 entries, content-defined far sampling */
     if (level >= 9) { /* the engine's deep finder (engine.hip: derive_params) */
         P->near16 = 0; P->far_cdc_log = 0; P->far_min_frame = 0;
@@ -1040,7 +1043,7 @@ void zge_default_params(zge_params *P, int level)
         P->far_log = 16; P->far_ways = 2; P->far_step_log = 1; P->far_res_log = 0; P->far_short = 1; P->far_skip = 0; P->far_back = 48;
         /* round 3: the parse -- live recent offsets (two rounds), a second lazy step, literals priced at 6; near tables of 2^13 entries
          * (the far tables hold what they forget: no ratio lost on any item of tests/support/realdata.py, and two workgroups fit a CU) */
-        P->rep_pass = 2; P->lazy2_delta = 5; P->lit_cost = 6; P->long_log = 13; P->short_log = 13;
+        P->rep_pass = 2; P->live_reps = 1; P->lazy2_delta = 5; P->lit_cost = 6; P->long_log = 13; P->short_log = 13;
         P->cont_cap = 960; /* a match cut at `cap` goes on at the tile's cursor (the level-3 kernel has no register to spare for it: DESIGN.md 4.1) */
     }
 }

@@ -110,12 +110,13 @@ def reloc_like(n, seed=3):
 
 
 # The ratio contract (BASELINE.json north_star): ours / libzstd at the same level <= 1.05.  EXCEPTIONS is the ONE table of items that
-# are outside it: (level, item) -> (bound the tests still enforce = measured value + slack so that a regression shows, why).  The gate
+# are outside it, or inside by so little that another box's copy of the files could tip them over (level 3: nothing is outside since the
+# extension round of round 3 -- the GPU code objects, 1.21 before it, measure 1.045): (level, item) -> (bound the tests still enforce = measured value + slack so that a regression shows, why).  The gate
 # prints every item with its ratio, so the table below is always next to the numbers it excuses.
 CONTRACT = 1.05
 EXCEPTIONS = {
-    (3, "hsaco_2m"): (1.22, "GPU code objects (thousands of near-identical kernels, 70x compressible): repeats of 10 - 40 bytes at MiB "
-                            "distances; libzstd's 2^17-entry long table holds every position, the sampled far table one in 16"),
+    (3, "hsaco_2m"): (1.07, "GPU code objects (thousands of near-identical kernels, 70x compressible): measured 1.045 -- inside the contract since "
+                            "selected matches cut at the compare cap go on in an extension round (from 1.21); listed for the margin only"),
     (9, "elf_mid_4m"): (1.055, "level 9 (libzstd: lazy2, 16 candidates per position): relocation / symbol tables, chains of short repeat-offset "
                                "matches; measured 1.049 -- inside the contract by a hair since the live recent-offset rounds (from 1.18), listed so that a "
                                "box whose copy of the library differs by a few hundred bytes does not fail the gate"),

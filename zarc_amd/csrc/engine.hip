@@ -138,7 +138,10 @@ ZgeParams derive_params(const zarc_gpu_params &p)
     z.tile = 1024; z.sub = 64; z.cap = diag_env("ZARC_GPU_CAP", 256);
     z.min_match = p.min_match >= 4 && p.min_match <= 7 ? p.min_match : (deep ? 4 : 5);
     z.min_rep = 3; z.rep_search = 2; z.back_cap = 8;
-    z.lazy = level >= 2 ? 1 : 0; z.lazy_delta = 5; z.lazy2_delta = deep ? 5 : 0; z.rep_pass = deep ? 2 : 0;
+    z.lazy = level >= 2 ? 1 : 0; z.lazy_delta = 5; z.lazy2_delta = deep ? 5 : 0;
+    // rounds after a tile's first parse: level >= 9 two, with the live recent offsets; below, one that only continues selected matches cut at
+    // the cap (ext_cap) and that the kernel runs in tiles that have such a match
+    z.rep_pass = deep ? 2 : 1; z.live_reps = deep ? 1 : 0; z.ext_cap = 960;
     z.far_cap = 0; z.cont_cap = deep ? 960 : 0; // level >= 9: continuation guess at a tile's cursor (zge_match.hip: LONG_CAP); far_cap is the model's only
     z.lit_cost = deep ? 6 : 5; z.match_cost = deep ? 10 : 12; z.rep_cost = 9;
     z.short_window_log = 30;
@@ -517,7 +520,7 @@ int pack_device_impl(zarc_gpu_t *h, size_t n, const void *d_src_base, const uint
     if (P.rep_back != 256 || P.back_cap != 8 || P.lazy_delta != 5 || P.min_rep != 3 || P.rep_search != 2 || P.seg_log != 21 || P.short_window_log < 30 ||
         P.lit_cost != (dp ? 6 : 5) || P.rep_cost != 9 || P.tag_bits != 10 || P.far_log != 16 || P.match_cost != (dp ? 10 : 12) || P.far_ways != (dp ? 2 : 1) ||
         P.far_step_log != (dp ? 1 : 5) || P.far_res_log != (dp ? 0 : 2) || (P.far_short != 0) != dp || P.long_log != 13 ||
-        P.near16 != (dp ? 0 : 1) || P.short_log != (dp ? 13 : 15) || P.far_cdc_log != (dp ? 0 : 4) || P.lazy2_delta != (dp ? 5 : 0) || (P.rep_pass != 0) != dp || P.rep_pass > 4 || P.far_cap != 0 || P.cont_cap != (dp ? 960 : 0) ||
+        P.near16 != (dp ? 0 : 1) || P.short_log != (dp ? 13 : 15) || P.far_cdc_log != (dp ? 0 : 4) || P.lazy2_delta != (dp ? 5 : 0) || P.rep_pass != (dp ? 2 : 1) || P.live_reps != (dp ? 1 : 0) || P.ext_cap != 960 || P.far_cap != 0 || P.cont_cap != (dp ? 960 : 0) ||
         P.far_back != 48 || P.far_skip != (dp ? 0 : 64)) { set_error(h, "internal: encoder parameters differ from the compiled-in ones"); return ZARC_GPU_E_PARAM; }
     uint64_t need = 0;
     for (size_t i = 0; i < n; i++) {

@@ -16,7 +16,7 @@ constexpr uint32_t ZARC_MAX_SEQ = ZARC_BLOCK / 3 + 8; // sequences per block (ev
 struct ZgeParams {
     int level, checksum, window_log, long_log, short_log, short_bytes, tile, sub, cap, min_match, min_rep, rep_search,
         back_cap, lazy, lazy_delta, lit_cost, match_cost, rep_cost, short_window_log, rep_back, tag_bits, seg_log,
-        far_log, far_ways, far_step_log, far_res_log, far_short, far_skip, far_back, near16, far_cdc_log, far_min_frame, rep_pass, lazy2_delta, far_cap, cont_cap, slot_bytes, dbg;
+        far_log, far_ways, far_step_log, far_res_log, far_short, far_skip, far_back, near16, far_cdc_log, far_min_frame, rep_pass, lazy2_delta, far_cap, cont_cap, ext_cap, live_reps, slot_bytes, dbg;
 };
 // Encoder scratch of one block slot (sequences, literals, coded block): sized by the largest block of the SUB-BATCH (slot_bytes <=
 // ZARC_BLOCK, a multiple of 16) -- a batch of a million 1 KiB entries must not reserve 600 KiB per entry.

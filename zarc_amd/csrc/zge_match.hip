@@ -78,7 +78,8 @@ template <int TAB_LOG, bool NEAR16> struct MatchLds {
 };
 enum { K_POS = 0, K_REP0 = 1, K_REP1 = 2, K_FLAG = 3, K_SLOT = 4, K_ANY = 5, K_CHG = 6 /* .. 9: a round of the live recent-offset pass changed a match */,
        K_CEND = 10 /* block position behind the last selected match of the last searched tile (0xFFFFFFFF: none) */,
-       K_CLEN = 11 /* length of the continuation guess at the tile's cursor */ };
+       K_CLEN = 11 /* length of the continuation guess at the tile's cursor */,
+       K_LONG = 12 /* EXT_ROUND: a selected match of this tile was cut at the cap */ };
 
 // Hashes from 32-bit multiplies only (a 64-bit multiply is four quarter-rate VALU ops on gfx950).
 // The near and the far tables index with different numbers of top bits of the SAME 32-bit product.
@@ -117,9 +118,9 @@ template <bool WIDE> __device__ __forceinline__ uint32_t match_pack_w(uint32_t o
 __device__ __forceinline__ uint32_t match_off(uint32_t m) { return m & 0x1FFFFFu; }
 template <bool WIDE> __device__ __forceinline__ uint32_t match_len_w(uint32_t m) { return (m >> 21) & (WIDE ? 0x3FFu : 0x1FFu); }
 template <bool WIDE> __device__ __forceinline__ bool match_rep_w(uint32_t m) { return WIDE ? (m >> 31) != 0 : ((m >> 30) & 1u) != 0; }
-#define match_pack(o_, l_, r_) match_pack_w<(CONT_CAP > 0)>((o_), (l_), (r_))
-#define match_len(m_) match_len_w<(CONT_CAP > 0)>(m_)
-#define match_rep(m_) match_rep_w<(CONT_CAP > 0)>(m_)
+#define match_pack(o_, l_, r_) match_pack_w<(CONT_CAP > 0 || EXT_ROUND)>((o_), (l_), (r_))
+#define match_len(m_) match_len_w<(CONT_CAP > 0 || EXT_ROUND)>(m_)
+#define match_rep(m_) match_rep_w<(CONT_CAP > 0 || EXT_ROUND)>(m_)
 constexpr int LONG_CAP = 960; // cont_cap: a length stays below 2^10
 
 // Common prefix of frame positions p and p - off from byte `from` on, at most `maxlen` bytes in all, by ONE wave in one round trip:
@@ -190,7 +191,7 @@ __device__ __forceinline__ uint32_t tile_end(uint32_t tile, uint32_t n)
 // relative positions, so a repeat is found when it contains one sample: 64 lookups + 64 inserts per 1024-position tile at FAR_CDC 4
 // instead of 256 + 128, and every thread asks for its OWN positions (no hand-over between lanes).
 template <int TAB_LOG, int SHORT_BYTES, int MATCH_COST, int F_FAR_LOG, int FAR_WAYS, bool FAR_SHORT, int FAR_STEP_LOG, int FAR_RES_LOG, int FAR_SKIP, int FAR_BACK, bool DIAG,
-          bool NEAR16, int FAR_CDC, int LITC, int LAZY2, bool REP_PASS, int CONT_CAP>
+          bool NEAR16, int FAR_CDC, int LITC, int LAZY2, bool REP_PASS, int CONT_CAP, bool EXT_ROUND>
 __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG, NEAR16> &L, const ZgeParams &P, const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off,
                                                const uint64_t *__restrict__ src_len, const uint32_t *__restrict__ order, const uint32_t *__restrict__ units, uint32_t n_units,
                                                const uint64_t *__restrict__ block_prefix, ZgeBlock *__restrict__ blocks,
@@ -366,6 +367,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG, NEAR16> &L, con
             }
             if (tid == 0) L.ctrl[K_ANY] = 0; // set by any position of this tile that finds a match
             if (REP_PASS && tid < 4) L.ctrl[K_CHG + tid] = 0;
+            if (EXT_ROUND && tid == 0) L.ctrl[K_LONG] = 0;
 
             // ---- S0: tile bytes (8 before .. cap+16 after) -> LDS ----
             // frame position `pos` of the staged window [lo, hi) lives at LDS byte tbb[pos + wofs] (u32 arithmetic)
@@ -885,6 +887,36 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG, NEAR16> &L, con
 #include "zge_parse_round.h"
 #undef ZGE_FIRST
             }
+            if (EXT_ROUND && L.ctrl[K_LONG]) { // uniform, rare (model: rep_pass 1 with ext_cap, live_reps 0).  A SELECTED match that was cut at the cap goes on at
+                // its offset, LONG_CAP bytes at most -- one trip of the whole wave per such match -- and the tile is propagated and parsed
+                // once more: a long repeat MiB back, found at one sampled far position, stays one match instead of pieces that each have
+                // to be found again (the GPU code objects: 1.21 -> 1.045 of libzstd -3).  Tiles without such a match never come here.
+#pragma unroll
+                for (int u = 0; u < PER; u++) {
+                    const uint32_t idx = ZGE_IDX(u);
+                    const uint32_t p = tile + idx;
+                    const uint32_t flen = fw[u] & 0xFFFFu;
+                    uint64_t ext = msel[u] & zd::ballot(flen >= cap_max);
+                    while (ext) { // uniform
+                        const uint32_t who = (uint32_t)zd::ctz64(ext);
+                        ext &= ext - 1;
+                        const uint32_t p_w = zd::readlane(p, who), len_w = zd::readlane(flen, who), off_w = zd::readlane(fo[u], who);
+                        const uint32_t lim_w = (uint32_t)(be - p_w), maxl = lim_w < (uint32_t)LONG_CAP ? lim_w : (uint32_t)LONG_CAP;
+                        if (maxl > len_w) {
+                            const uint32_t e = wave_match_ext(src, p_w, off_w, len_w, maxl, lane);
+                            if ((uint32_t)lane == who && e > len_w) { mo[u] = fo[u]; mw[u] = e | (fw[u] & (1u << 24)); }
+                        }
+                    }
+                    L.a0[idx] = match_pack(mo[u], mw[u] & 0xFFFF, (mw[u] >> 24) & 1);
+                    L.ex[idx] = 0;
+                }
+                zd::lds_barrier(); // own matches are in a0, the offers start empty
+                {
+#define ZGE_FIRST 0
+#include "zge_parse_round.h"
+#undef ZGE_FIRST
+                }
+            }
             if (REP_PASS) for (uint32_t it = 0; it < (uint32_t)P.rep_pass; it++) {
             // ---- live recent offsets (level >= 9; model: matchfind_block, rep_pass).  libzstd's lazy parsers try the offsets of the
             // matches they took last at every position; the guesses of S3 are the offsets the PREVIOUS tile ended with.  With a parse
@@ -1045,7 +1077,7 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                                                       uint32_t *__restrict__ far_scratch)
 {
     __shared__ MatchLds<15, true> L;
-    zge_match_body<15, 5, 12, 16, 1, false, 5, 2, 64, 48, false, true, 4, 5, 0, false, 0>(L, P, src_base, src_off, src_len, order, units, n_units, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
+    zge_match_body<15, 5, 12, 16, 1, false, 5, 2, 64, 48, false, true, 4, 5, 0, false, 0, true>(L, P, src_base, src_off, src_len, order, units, n_units, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
 }
 
 #ifdef ZARC_GPU_DIAG
@@ -1058,7 +1090,7 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match_diag(ZgeParams P, const
                                                            uint32_t *__restrict__ far_scratch)
 {
     __shared__ MatchLds<15, true> L;
-    zge_match_body<15, 5, 12, 16, 1, false, 5, 2, 64, 48, true, true, 4, 5, 0, false, 0>(L, P, src_base, src_off, src_len, order, units, n_units, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
+    zge_match_body<15, 5, 12, 16, 1, false, 5, 2, 64, 48, true, true, 4, 5, 0, false, 0, true>(L, P, src_base, src_off, src_len, order, units, n_units, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
 }
 #endif
 
@@ -1069,7 +1101,7 @@ __global__ void __launch_bounds__(512, 2) zarc_zge_match_deep(ZgeParams P, const
                                                            uint32_t *__restrict__ far_scratch)
 {
     __shared__ MatchLds<13, false> L;
-    zge_match_body<13, 4, 10, 16, 2, true, 1, 0, 0, 48, false, false, 0, 6, 5, true, LONG_CAP>(L, P, src_base, src_off, src_len, order, units, n_units, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
+    zge_match_body<13, 4, 10, 16, 2, true, 1, 0, 0, 48, false, false, 0, 6, 5, true, LONG_CAP, false>(L, P, src_base, src_off, src_len, order, units, n_units, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
 }
 
 #ifdef ZARC_GPU_DIAG
@@ -1080,6 +1112,6 @@ __global__ void __launch_bounds__(512, 2) zarc_zge_match_deep_diag(ZgeParams P, 
                                                            uint32_t *__restrict__ far_scratch)
 {
     __shared__ MatchLds<13, false> L;
-    zge_match_body<13, 4, 10, 16, 2, true, 1, 0, 0, 48, true, false, 0, 6, 5, true, LONG_CAP>(L, P, src_base, src_off, src_len, order, units, n_units, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
+    zge_match_body<13, 4, 10, 16, 2, true, 1, 0, 0, 48, true, false, 0, 6, 5, true, LONG_CAP, false>(L, P, src_base, src_off, src_len, order, units, n_units, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
 }
 #endif
