@@ -79,7 +79,7 @@ template <int TAB_LOG, bool NEAR16> struct MatchLds {
 enum { K_POS = 0, K_REP0 = 1, K_REP1 = 2, K_FLAG = 3, K_SLOT = 4, K_ANY = 5, K_CHG = 6 /* .. 9: a round of the live recent-offset pass changed a match */,
        K_CEND = 10 /* block position behind the last selected match of the last searched tile (0xFFFFFFFF: none) */,
        K_CLEN = 11 /* length of the continuation guess at the tile's cursor */,
-       K_LONG = 12 /* EXT_ROUND: a selected match of this tile was cut at the cap */ };
+       K_LONG = 12 /* EXT_ROUND: a candidate of this tile reaches the cap */, K_LONG2 = 13 /* ... and a selected match was cut at it */ };
 
 // Hashes from 32-bit multiplies only (a 64-bit multiply is four quarter-rate VALU ops on gfx950).
 // The near and the far tables index with different numbers of top bits of the SAME 32-bit product.
@@ -367,7 +367,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG, NEAR16> &L, con
             }
             if (tid == 0) L.ctrl[K_ANY] = 0; // set by any position of this tile that finds a match
             if (REP_PASS && tid < 4) L.ctrl[K_CHG + tid] = 0;
-            if (EXT_ROUND && tid == 0) L.ctrl[K_LONG] = 0;
+            if (EXT_ROUND && tid == 0) { L.ctrl[K_LONG] = 0; L.ctrl[K_LONG2] = 0; }
 
             // ---- S0: tile bytes (8 before .. cap+16 after) -> LDS ----
             // frame position `pos` of the staged window [lo, hi) lives at LDS byte tbb[pos + wofs] (u32 arithmetic)
@@ -879,6 +879,10 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG, NEAR16> &L, con
 #pragma unroll
             for (int u = 0; u < PER; u++) L.a0[ZGE_IDX(u)] = match_pack(mo[u], mw[u] & 0xFFFF, (mw[u] >> 24) & 1);
             if (mo[0] | mo[1]) L.ctrl[K_ANY] = 1; // benign race: every writer stores 1
+            if (EXT_ROUND) { // a candidate that may reach the cap once adopted (length + backward extension): the tile looks at its selected matches after the parse
+                const uint32_t r0 = (mw[0] & 0xFFFFu) + ((mw[0] >> 16) & 0xFFu), r1 = (mw[1] & 0xFFFFu) + ((mw[1] >> 16) & 0xFFu);
+                if ((r0 > r1 ? r0 : r1) >= cap_max) L.ctrl[K_LONG] = 1;
+            }
             uint32_t fo[PER], fw[PER]; // final match of each position: its own, or the one it adopted from a position behind it
             uint64_t msel[PER], mlit[PER];
             // S4 - S6 (zge_parse_round.h): once per tile; with REP_PASS once more after every round of the live recent-offset pass
@@ -890,13 +894,26 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG, NEAR16> &L, con
             if (EXT_ROUND && L.ctrl[K_LONG]) { // uniform, rare (model: rep_pass 1 with ext_cap, live_reps 0).  A SELECTED match that was cut at the cap goes on at
                 // its offset, LONG_CAP bytes at most -- one trip of the whole wave per such match -- and the tile is propagated and parsed
                 // once more: a long repeat MiB back, found at one sampled far position, stays one match instead of pieces that each have
-                // to be found again (the GPU code objects: 1.21 -> 1.045 of libzstd -3).  Tiles without such a match never come here.
+                // to be found again (the GPU code objects: 1.21 -> 1.045 of libzstd -3).  Tiles without a candidate of cap length never come
+                // here; of those that do, the ones without such a SELECTED match leave after one barrier.
+                uint64_t extm[PER];
+                bool any = false;
+#pragma unroll
+                for (int u = 0; u < PER; u++) {
+                    const uint32_t idx = ZGE_IDX(u);
+                    const uint32_t flen = fw[u] & 0xFFFFu, lim = idx < tcount ? (uint32_t)(be - tile) - idx : 0u;
+                    extm[u] = msel[u] & zd::ballot(flen >= cap_max && lim > flen);
+                    any |= extm[u] != 0;
+                }
+                if (any && lane == 0) L.ctrl[K_LONG2] = 1;
+                zd::lds_barrier();
+                if (L.ctrl[K_LONG2]) {
 #pragma unroll
                 for (int u = 0; u < PER; u++) {
                     const uint32_t idx = ZGE_IDX(u);
                     const uint32_t p = tile + idx;
                     const uint32_t flen = fw[u] & 0xFFFFu;
-                    uint64_t ext = msel[u] & zd::ballot(flen >= cap_max);
+                    uint64_t ext = extm[u];
                     while (ext) { // uniform
                         const uint32_t who = (uint32_t)zd::ctz64(ext);
                         ext &= ext - 1;
@@ -915,6 +932,7 @@ __device__ __forceinline__ void zge_match_body(MatchLds<TAB_LOG, NEAR16> &L, con
 #define ZGE_FIRST 0
 #include "zge_parse_round.h"
 #undef ZGE_FIRST
+                }
                 }
             }
             if (REP_PASS) for (uint32_t it = 0; it < (uint32_t)P.rep_pass; it++) {

@@ -190,10 +190,6 @@
                     msel[u] = sel;
                     mlit[u] = lits;
                     if (lane == 0) L.wcnt[mychunk] = ((uint32_t)__popcll(msel[u]) << 16) | (uint32_t)__popcll(mlit[u]);
-                    if (EXT_ROUND && ZGE_FIRST) { // a selected match that was cut at the cap and has bytes left in the block: the tile gets its extension round
-                        const uint32_t flen = fw[u] & 0xFFFFu, at = cbase + (uint32_t)lane;
-                        if ((sel & zd::ballot(flen >= cap_max && at < tcount && (uint32_t)(be - tile) - at > flen)) && lane == 0) L.ctrl[K_LONG] = 1;
-                    }
                     if (REP_PASS && lane == 0) { L.wrep[2 * mychunk] = o_last; L.wrep[2 * mychunk + 1] = o_diff; }
                 }
                 // the wave that owns the last chunk knows where the path leaves the tile
