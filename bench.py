@@ -67,7 +67,8 @@ def cpu_baseline(sample, size, first_index, level, kind=-1):
     z15 = next((z for z in zs if z.version.startswith("1.5")), zbest)
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     one = harness.cpu_baseline(zbest.path, level, 1, sample, size, first_index, kind)
-    many = harness.cpu_baseline(zbest.path, level, cores, min(4 * sample, 4096), size, first_index, kind) if cores > 1 else None
+    # every thread gets 64 entries (at most 8192 in all: 8 GiB of 1 MiB entries + their frame buffers, allocated before the clock starts)
+    many = harness.cpu_baseline(zbest.path, level, cores, max(min(64 * cores, 8192), cores), size, first_index, kind) if cores > 1 else None
     ref = harness.cpu_baseline(z15.path, level, cores, min(sample, 256), size, first_index, kind)  # ratio yardstick: the 1.5.x build
     one15 = harness.cpu_baseline(z15.path, level, 1, max(sample // 4, 16), size, first_index, kind) if z15.path != zbest.path else one
     out = {"value": one["bytes"] / one["pack_seconds"] / GIB, "unit": "GiB/s", "cores": 1, "kind": "port",

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define ZARC_GPU_ABI_VERSION 1
+#define ZARC_GPU_ABI_VERSION 2 /* 2: round 3's entry points (device_count, *_dedup, FRAME_DUPLICATE, PX_ZERO_COPY) + round 4's (warnings, levels) */
 #define ZARC_GPU_DIGEST_LEN 32  /* DigestType::digest_len(), crates/zarc/src/integrity.rs:100-104 */
 #define ZARC_GPU_ALIGN 16       /* device-resident entries / outputs must start 16-byte aligned   */
 #define ZARC_GPU_PAD 64         /* readable slack required after the last byte of a device arena   */

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol(product_lib):
     for name in _declared():
         assert hasattr(lib, name), name
     lib.zarc_gpu_abi_version.restype = ctypes.c_int
-    assert lib.zarc_gpu_abi_version() == 1
+    assert lib.zarc_gpu_abi_version() == 2
 
 
 def test_bound_and_error_names(product_lib):

@@ -10,6 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "libzarc_gpu.so")
 
+ABI_VERSION = 2  # include/zarc_gpu.h: ZARC_GPU_ABI_VERSION
 DIGEST_LEN = 32
 ALIGN = 16
 PAD = 64
@@ -61,6 +62,9 @@ def load(path=None):
     vp, sz, u64p, u8p, ip = c.c_void_p, c.c_size_t, c.POINTER(c.c_uint64), c.POINTER(c.c_uint8), c.POINTER(c.c_int)
     szp, vpp = c.POINTER(c.c_size_t), c.POINTER(c.c_void_p)
     lib.zarc_gpu_abi_version.restype = c.c_int
+    got = lib.zarc_gpu_abi_version()
+    if got != ABI_VERSION:  # checked BEFORE the newer symbols are resolved: a stale library fails here, by version, not at a symbol lookup
+        raise OSError("%s has ABI version %d, this binding needs %d -- rebuild it (make -C zarc_amd/csrc)" % (path, got, ABI_VERSION))
     lib.zarc_gpu_device_count.restype = c.c_int
     lib.zarc_gpu_create.argtypes = [c.POINTER(vp), c.c_int]
     lib.zarc_gpu_destroy.argtypes = [vp]

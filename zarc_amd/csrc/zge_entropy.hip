@@ -172,10 +172,11 @@ __device__ void fse_build_ctab(FseCtab &t, const int16_t *norm, int nsym, int al
 //   spread      the j-th visited position is (j * step) mod T, positions above `high` (the less-than-one symbols' cells at the top) are
 //               skipped: every lane takes T/64 consecutive j, a wave scan of the valid counts gives each valid j its occupant rank,
 //               a binary search over the starts the rank's symbol -- instead of T dependent steps on one lane
-//   state table every cell takes the next slot of its symbol: 64 cells per ds_add_rtn; same-address LDS atomics of one instruction
-//               execute in lane order (measured: tools/micro/lds_write_order.hip, 1 280 000 lanes; pinned on every GPU box by
-//               tests/test_gpu_parity.py::test_gpu_lds_same_address_stores_keep_the_highest_lane), so cells in rising order get rising
-//               slots, as the serial loop gives them
+//   state table every cell takes the next slot of its symbol, 64 cells per round: a cell's slot is its symbol's running slot plus the
+//               number of lower lanes of the round that hold the same symbol (six ballots give every lane the mask of its symbol's
+//               lanes), so cells in rising order get rising slots, as the serial loop gives them -- computed, not left to the order in
+//               which the LDS executes same-address atomics of one instruction (round 3 used ds_add_rtn here; a different order would
+//               have produced frames that decode to wrong bytes)
 //   per symbol  dnb / dfs, one lane per symbol
 __device__ void fse_build_ctab_wave(FseCtab &t, const int16_t *norm, int nsym, int al, uint8_t *cellsym, int lane)
 {
@@ -211,8 +212,22 @@ __device__ void fse_build_ctab_wave(FseCtab &t, const int16_t *norm, int nsym, i
     zd::wave_sync();
     for (int i0 = 0; i0 < T; i0 += 64) {
         const int i = i0 + lane;
-        if (i < T) { const int slot = atomicAdd(&t.dfs[cellsym[i]], 1); t.state_tab[slot] = (uint16_t)(T + i); }
-        zd::wave_lds_order(); // one instruction's 64 cells before the next one's (program order on hardware; the emulator runs lanes one after another)
+        const bool act = i < T;
+        const uint32_t sym = act ? (uint32_t)cellsym[i] : 64u; // (64: matches no symbol; T < 64 only below accuracy 6)
+        // lanes of this group that hold the same symbol: six ballots, one per bit of the symbol -- no reliance on the order in which the
+        // LDS would execute same-address atomics of one instruction
+        uint64_t same = zd::ballot(act);
+#pragma unroll
+        for (int b = 0; b < 6; b++) { const uint64_t m = zd::ballot((sym >> b) & 1u); same &= ((sym >> b) & 1u) ? m : ~m; }
+        const uint32_t below = (uint32_t)__popcll(same & ((1ull << lane) - 1)), all = (uint32_t)__popcll(same);
+        int base = 0;
+        if (act) base = t.dfs[sym];
+        zd::wave_lds_order(); // every lane has read its symbol's running slot before the group's last cell of that symbol moves it on
+        if (act) {
+            t.state_tab[base + (int)below] = (uint16_t)(T + i);
+            if (below + 1 == all) t.dfs[sym] = base + (int)all;
+        }
+        zd::wave_lds_order(); // one group's 64 cells before the next one's (program order on hardware; the emulator needs the rendezvous)
     }
     zd::wave_sync();
     if (lane < nsym) {
