@@ -56,6 +56,10 @@ typedef struct {
     int cont_cap;     /* > 0: continuation guess over this many bytes at the parse cursor of a tile (zstd_enc_model.c: matchfind_block) */
     int ext_cap;      /* > 0: in a round of rep_pass, a SELECTED match of `cap` bytes or more goes on at its offset, up to this many bytes */
     int live_reps;    /* 1 = the rounds of rep_pass try the live recent offsets (level >= 9); 0 = they only continue long matches */
+    /* Round 4: */
+    int seq_repeat;   /* 1 = groups of eight blocks share one FSE table per sequence-code type (first block describes it, the others say
+                         Repeat_Mode) when that costs at most 1/64 more bits than the blocks' own tables (zstd_enc_model.c: seq_plan_group);
+                         the engine always does */
 } zge_params;
 
 typedef struct { uint32_t ll, ml, off, ofv; } zge_seq;

@@ -476,7 +476,7 @@ static uint64_t dist_cost(const uint32_t *count, const int16_t *norm, int nsym, 
     return c;
 }
 
-typedef struct { int mode; int16_t norm[64]; int nsym; int al; uint8_t rle_sym; uint8_t desc[80]; size_t desc_len; } seq_table_choice;
+typedef struct { int mode; int16_t norm[64]; int nsym; int al; uint8_t rle_sym; uint8_t desc[80]; size_t desc_len; uint64_t cost; } seq_table_choice;
 
 static void choose_table(seq_table_choice *c, const uint32_t *count, int maxsym, uint32_t nseq,
                          const int16_t *def, int def_n, int def_al, int max_al)
@@ -484,6 +484,7 @@ static void choose_table(seq_table_choice *c, const uint32_t *count, int maxsym,
     int s, distinct = 0, last = 0, al;
     uint64_t cost_def, cost_dyn;
     for (s = 0; s <= maxsym; s++) if (count[s]) { distinct++; last = s; }
+    c->cost = 0;
     if (distinct == 1) { c->mode = 1; c->rle_sym = (uint8_t)last; c->desc_len = 0; return; }
     cost_def = last < def_n ? dist_cost(count, def, def_n, def_al) : (uint64_t)-1;
     /* dynamic table */
@@ -502,15 +503,119 @@ static void choose_table(seq_table_choice *c, const uint32_t *count, int maxsym,
         c->al = def_al;
         memcpy(c->norm, def, sizeof(int16_t) * (size_t)def_n);
         c->desc_len = 0;
+        c->cost = cost_def;
     } else {
         c->mode = 2;
+        c->cost = cost_dyn;
     }
 }
 
-static size_t encode_sequences(const zge_seq *seq, uint32_t nseq, uint8_t *dst, size_t cap, zge_stats *st)
+/* Shared sequence tables (Repeat_Mode, RFC 8878 3.1.1.3.2.1: "the table used in the previous Compressed_Block with
+ * Number_of_Sequences > 0 will be used again").  The blocks of a frame are taken in GROUPS of ZGE_TABLE_GROUP (block index / 8: the eight
+ * blocks of a 1 MiB entry are one group).  Per table type (LL, OF, ML) a group may code all its blocks with ONE table, normalised from
+ * the SUM of the blocks' code histograms: the first block describes it, the others say Repeat.  That saves seven descriptions, and --
+ * the point for the engine's decoder -- the blocks of an entry share one table set, which zstd_decode.hip keeps in LDS for the whole
+ * wave instead of one 2.5 KiB table set per block in HBM.  Taken when it costs at most 1/64 more table-coded bits than the blocks' own
+ * best choices (the sum's cost is linear in the counts: one dist_cost call).
+ * The engine decides this per group in a small kernel between two passes of the entropy stage (zge_entropy.hip: zarc_zge_plan),
+ * before any sequence is coded, so what the decoder "has" must be PROVEN from the histograms: a block hands the group's table on only
+ * if an upper bound of its coded size is below its raw size (it cannot end up a raw block); the block behind any other block
+ * describes the table again.  A block whose codes of one type are all equal keeps RLE mode for that type and breaks that type's chain
+ * the same way.  Blocks without sequences, RLE blocks and blocks whose literals failed to code take no part: they leave the decoder's
+ * tables alone. */
+#define ZGE_TABLE_GROUP 8
+typedef struct {
+    int active;                /* the block has sequences to code (and its literals section exists) */
+    uint32_t nseq;
+    uint32_t count[3][64];     /* code histograms: LL, OF, ML */
+    seq_table_choice ch[3];    /* own best choice (choose_table), then the final one */
+    uint64_t extra_bits;       /* bits of the sequences' extra-bits fields */
+    size_t lsz, blen;          /* literals section in front, raw size of the block (for the size bound) */
+    int guaranteed;
+} seq_plan;
+
+static uint32_t fse_max_bits(int n, int al) { return (n == -1 || n == 1) ? (uint32_t)al : (uint32_t)(al - hb32((uint32_t)(n - 1))); }
+static const int SEQ_MAXSYM[3] = {35, 31, 52}, SEQ_MAX_AL[3] = {9, 8, 9};
+
+static void seq_plan_block(seq_plan *pl, const zge_seq *seq, uint32_t nseq, size_t lsz, size_t blen)
+{
+    uint32_t i;
+    int s;
+    memset(pl, 0, sizeof *pl);
+    pl->nseq = nseq; pl->lsz = lsz; pl->blen = blen;
+    pl->active = nseq != 0 && lsz != 0;
+    if (!pl->active) return;
+    for (i = 0; i < nseq; i++) {
+        pl->count[0][zge_ll_code(seq[i].ll)]++;
+        pl->count[1][hb32(seq[i].ofv)]++;
+        pl->count[2][zge_ml_code(seq[i].ml)]++;
+    }
+    choose_table(&pl->ch[0], pl->count[0], 35, nseq, LL_DEFAULT, 36, 6, 9);
+    choose_table(&pl->ch[1], pl->count[1], 31, nseq, OF_DEFAULT, 29, 5, 8);
+    choose_table(&pl->ch[2], pl->count[2], 52, nseq, ML_DEFAULT, 53, 6, 9);
+    for (s = 0; s < 36; s++) pl->extra_bits += (uint64_t)pl->count[0][s] * LL_BITS[s];
+    for (s = 0; s < 32; s++) pl->extra_bits += (uint64_t)pl->count[1][s] * (uint32_t)s;
+    for (s = 0; s < 53; s++) pl->extra_bits += (uint64_t)pl->count[2][s] * ML_BITS[s];
+}
+
+/* the blocks of one group, in order */
+static void seq_plan_group(seq_plan *pl, int nb)
+{
+    int use_group[3] = {0, 0, 0}, have[3] = {0, 0, 0}, t, b, s;
+    seq_table_choice g[3];
+    for (t = 0; t < 3; t++) {
+        uint32_t sum[64], total = 0;
+        uint64_t cost_own = 0, cost_group;
+        int np = 0, distinct = 0, last = 0, al;
+        memset(sum, 0, sizeof sum);
+        memset(&g[t], 0, sizeof g[t]);
+        for (b = 0; b < nb; b++) {
+            if (!pl[b].active || pl[b].ch[t].mode == 1) continue;
+            for (s = 0; s <= SEQ_MAXSYM[t]; s++) sum[s] += pl[b].count[t][s];
+            total += pl[b].nseq; cost_own += pl[b].ch[t].cost; np++;
+        }
+        if (np < 2) continue;
+        for (s = 0; s <= SEQ_MAXSYM[t]; s++) if (sum[s]) { distinct++; last = s; }
+        al = hb32(total > 1 ? total - 1 : 1) - 2;
+        if (al > SEQ_MAX_AL[t]) al = SEQ_MAX_AL[t];
+        if (al < 5) al = 5;
+        while ((1 << al) < distinct) al++;
+        g[t].mode = 2; g[t].nsym = last + 1; g[t].al = al;
+        fse_normalize(sum, g[t].nsym, total, al, g[t].norm);
+        g[t].desc_len = fse_write_desc(g[t].desc, sizeof g[t].desc, g[t].norm, g[t].nsym, al);
+        if (!g[t].desc_len) continue;
+        cost_group = dist_cost(sum, g[t].norm, g[t].nsym, al) + (uint64_t)g[t].desc_len * 8 * 256;
+        use_group[t] = cost_group <= cost_own + (cost_own >> 6);
+    }
+    for (b = 0; b < nb; b++) {
+        uint64_t ub_bits = 1; /* the end mark */
+        size_t ub;
+        seq_plan *p = &pl[b];
+        if (!p->active) continue;
+        for (t = 0; t < 3; t++) {
+            seq_table_choice *c = &p->ch[t];
+            if (c->mode == 1 || !use_group[t]) continue;
+            { const uint8_t rle = c->rle_sym; *c = g[t]; c->rle_sym = rle; }
+            if (have[t]) { c->mode = 3; c->desc_len = 0; }
+        }
+        /* upper bound of the block's coded size: every state transition at its symbol's larger bit count */
+        for (t = 0; t < 3; t++) {
+            const seq_table_choice *c = &p->ch[t];
+            if (c->mode == 1) continue;
+            for (s = 0; s < c->nsym && s <= SEQ_MAXSYM[t]; s++) if (p->count[t][s]) ub_bits += (uint64_t)p->count[t][s] * fse_max_bits(c->norm[s], c->al);
+            ub_bits += (uint64_t)c->al;
+        }
+        ub_bits += p->extra_bits;
+        ub = p->lsz + (p->nseq < 128 ? 1 : (p->nseq < 0x7F00 ? 2 : 3)) + 1 + (size_t)((ub_bits + 7) / 8);
+        for (t = 0; t < 3; t++) ub += p->ch[t].mode == 1 ? 1 : p->ch[t].desc_len;
+        p->guaranteed = ub < p->blen;
+        for (t = 0; t < 3; t++) have[t] = (p->ch[t].mode != 1 && use_group[t]) ? p->guaranteed : 0;
+    }
+}
+
+static size_t encode_sequences(const zge_seq *seq, uint32_t nseq, uint8_t *dst, size_t cap, zge_stats *st, const seq_plan *pl)
 {
     size_t pos = 0;
-    uint32_t cl[36], co[32], cm[53], i;
     seq_table_choice tl, to, tm;
     fse_ctab ctl, cto, ctm;
     bitw b;
@@ -519,15 +624,7 @@ static size_t encode_sequences(const zge_seq *seq, uint32_t nseq, uint8_t *dst, 
     else if (nseq < 0x7F00) { dst[pos++] = (uint8_t)((nseq >> 8) + 128); dst[pos++] = (uint8_t)nseq; }
     else { dst[pos++] = 255; dst[pos++] = (uint8_t)(nseq - 0x7F00); dst[pos++] = (uint8_t)((nseq - 0x7F00) >> 8); }
     if (nseq == 0) return pos;
-    memset(cl, 0, sizeof cl); memset(co, 0, sizeof co); memset(cm, 0, sizeof cm);
-    for (i = 0; i < nseq; i++) {
-        cl[zge_ll_code(seq[i].ll)]++;
-        cm[zge_ml_code(seq[i].ml)]++;
-        co[hb32(seq[i].ofv)]++;
-    }
-    choose_table(&tl, cl, 35, nseq, LL_DEFAULT, 36, 6, 9);
-    choose_table(&to, co, 31, nseq, OF_DEFAULT, 29, 5, 8);
-    choose_table(&tm, cm, 52, nseq, ML_DEFAULT, 53, 6, 9);
+    tl = pl->ch[0]; to = pl->ch[1]; tm = pl->ch[2];
     if (st) { st->seq_mode[tl.mode]++; st->seq_mode[to.mode]++; st->seq_mode[tm.mode]++; }
     if (pos + 1 + 3 + tl.desc_len + to.desc_len + tm.desc_len > cap) return 0;
     dst[pos++] = (uint8_t)((tl.mode << 6) | (to.mode << 4) | (tm.mode << 2));
@@ -1036,6 +1133,7 @@ void zge_default_params(zge_params *P, int level)
     /* long matches: one more parse round per tile in which selected matches that were cut at `cap` go on at their offset (no live
      * recent offsets below level 9); the kernel runs the round only in tiles that have such a match */
     P->rep_pass = 1; P->live_reps = 0; P->ext_cap = 960;
+    P->seq_repeat = 1; /* round 4: the blocks of a group share their sequence tables (seq_plan_group) */
     P->near16 = 1; P->short_log = 15; P->far_cdc_log = 4; /* round 3: one 16-bit near table of 2^15 entries, content-defined far sampling */
     if (level >= 9) { /* the engine's deep finder (engine.hip: derive_params) */
         P->near16 = 0; P->far_cdc_log = 0; P->far_min_frame = 0;
@@ -1055,11 +1153,12 @@ int zge_encode_frame(const zge_params *P_in, const void *src_, size_t n, void *d
     const zge_params *P = &Pn;
     const uint8_t *src = (const uint8_t *)src_;
     uint8_t *dst = (uint8_t *)dst_;
-    size_t pos = 0, bs;
+    size_t pos = 0, bs, gs;
     mf_ctx c;
-    zge_seq *seq;
-    uint8_t *lit, *blk;
-    int wlog, single;
+    zge_seq *gseq[ZGE_TABLE_GROUP];
+    uint8_t *lit, *gblk[ZGE_TABLE_GROUP];
+    seq_plan *plans;
+    int wlog, single, bad_bound = 0, g;
     if (cap < zge_bound(n)) return -1;
     if (st) memset(st, 0, sizeof *st);
     if (n <= (size_t)Pn.far_min_frame) Pn.far_log = 0; /* small frames: no far table */
@@ -1093,14 +1192,20 @@ int zge_encode_frame(const zge_params *P_in, const void *src_, size_t n, void *d
     c.next = (uint32_t *)calloc((size_t)P->tile, 4);
     c.take = (uint8_t *)calloc((size_t)P->tile, 1);
     c.mark = (uint8_t *)calloc((size_t)P->tile, 1);
-    seq = (zge_seq *)malloc(sizeof(zge_seq) * (ZGE_BLOCK / 3 + 8));
+    for (g = 0; g < ZGE_TABLE_GROUP; g++) {
+        gseq[g] = (zge_seq *)malloc(sizeof(zge_seq) * (ZGE_BLOCK / 3 + 8));
+        gblk[g] = (uint8_t *)malloc(ZGE_BLOCK + 1024);
+    }
+    plans = (seq_plan *)calloc(ZGE_TABLE_GROUP, sizeof *plans);
     lit = (uint8_t *)malloc(ZGE_BLOCK + 64);
-    blk = (uint8_t *)malloc(ZGE_BLOCK + 1024);
     if (n == 0) { dst[pos++] = 1; dst[pos++] = 0; dst[pos++] = 0; }
-    for (bs = 0; bs < n; bs += ZGE_BLOCK) {
+    for (gs = 0; gs < n; gs += (size_t)ZGE_TABLE_GROUP * ZGE_BLOCK) {
+      /* first pass over the group's blocks: match finding, literals section, code histograms and each block's own table choices */
+      int nb = 0, rle[ZGE_TABLE_GROUP];
+      size_t nlits[ZGE_TABLE_GROUP];
+      for (bs = gs; bs < n && nb < ZGE_TABLE_GROUP; bs += ZGE_BLOCK, nb++) {
         size_t be = bs + ZGE_BLOCK < n ? bs + ZGE_BLOCK : n, blen = be - bs, nlit = 0, i;
-        int last = be == n, all_same = 1;
-        uint32_t hdr;
+        int all_same = 1;
         /* table positions are relative to 2^seg_log segments (multiples of the block size): at a boundary the
          * tables are cleared, so candidates never cross it (only frames larger than a segment notice) */
         if (bs > 0 && (bs & (((size_t)1 << P->seg_log) - 1)) == 0) {
@@ -1118,9 +1223,24 @@ int zge_encode_frame(const zge_params *P_in, const void *src_, size_t n, void *d
             if (n > ZGE_SPLIT_MIN) { c.erep0 = c.erep1 = 0; c.cold = 0; c.skip_left = 0; }
         }
         for (i = 1; i < blen; i++) if (src[bs + i] != src[bs]) { all_same = 0; break; }
-        if (all_same && blen >= 2) {
-            /* RLE block.  The match finder still has to see the block so later blocks can reference it:
-             * the engine inserts nothing for RLE blocks (cheap and deterministic). */
+        rle[nb] = all_same && blen >= 2;
+        memset(&plans[nb], 0, sizeof plans[nb]);
+        nlits[nb] = 0;
+        if (rle[nb]) continue; /* RLE block: the engine inserts nothing for it (cheap and deterministic) */
+        {
+            const uint32_t nseq = matchfind_block(&c, bs, be, gseq[nb], lit, &nlit);
+            const size_t lsz = encode_literals(lit, nlit, gblk[nb], ZGE_BLOCK + 1024, st);
+            seq_plan_block(&plans[nb], gseq[nb], nseq, lsz, blen);
+            nlits[nb] = nlit;
+        }
+      }
+      if (P->seq_repeat) seq_plan_group(plans, nb);
+      /* second pass: the sequences sections, and the blocks in order */
+      for (g = 0, bs = gs; g < nb; g++, bs += ZGE_BLOCK) {
+        const size_t be = bs + ZGE_BLOCK < n ? bs + ZGE_BLOCK : n, blen = be - bs;
+        const int last = be == n;
+        uint32_t hdr;
+        if (rle[g]) {
             hdr = (uint32_t)last | (1u << 1) | ((uint32_t)blen << 3);
             dst[pos++] = (uint8_t)hdr; dst[pos++] = (uint8_t)(hdr >> 8); dst[pos++] = (uint8_t)(hdr >> 16);
             dst[pos++] = src[bs];
@@ -1128,18 +1248,18 @@ int zge_encode_frame(const zge_params *P_in, const void *src_, size_t n, void *d
             continue;
         }
         {
-            uint32_t nseq;
-            size_t lsz, ssz = 0, csz = 0;
-            nseq = matchfind_block(&c, bs, be, seq, lit, &nlit);
-            lsz = encode_literals(lit, nlit, blk, ZGE_BLOCK + 1024, st);
-            if (lsz) ssz = encode_sequences(seq, nseq, blk + lsz, ZGE_BLOCK + 1024 - lsz, st);
+            const size_t lsz = plans[g].lsz;
+            size_t ssz = 0, csz;
+            uint8_t *blk = gblk[g];
+            if (lsz) ssz = encode_sequences(gseq[g], plans[g].nseq, blk + lsz, ZGE_BLOCK + 1024 - lsz, st, &plans[g]);
             csz = lsz && ssz ? lsz + ssz : 0;
+            if (plans[g].guaranteed && !(csz && csz < blen)) bad_bound = 1; /* the size bound that lets a successor repeat this block's tables was no bound */
             if (csz && csz < blen) {
                 hdr = (uint32_t)last | (2u << 1) | ((uint32_t)csz << 3);
                 dst[pos++] = (uint8_t)hdr; dst[pos++] = (uint8_t)(hdr >> 8); dst[pos++] = (uint8_t)(hdr >> 16);
                 memcpy(dst + pos, blk, csz);
                 pos += csz;
-                if (st) { st->blk_comp++; st->lit_bytes += nlit; st->lit_section += lsz; st->seq_section += ssz; }
+                if (st) { st->blk_comp++; st->lit_bytes += nlits[g]; st->lit_section += lsz; st->seq_section += ssz; }
             } else {
                 /* raw block: the decoder's repcode history is not advanced by it (see matchfind_block) */
                 hdr = (uint32_t)last | (0u << 1) | ((uint32_t)blen << 3);
@@ -1149,12 +1269,14 @@ int zge_encode_frame(const zge_params *P_in, const void *src_, size_t n, void *d
                 if (st) st->blk_raw++;
             }
         }
+      }
     }
     if (P->checksum) {
         uint32_t x = (uint32_t)oracle_xxh64(src, n, 0);
         dst[pos++] = (uint8_t)x; dst[pos++] = (uint8_t)(x >> 8); dst[pos++] = (uint8_t)(x >> 16); dst[pos++] = (uint8_t)(x >> 24);
     }
-    free(c.t16); free(c.fl); free(c.fs); free(c.farc); free(c.tl); free(c.ts); free(c.M); free(c.M2); free(c.next); free(c.take); free(c.mark); free(seq); free(lit); free(blk);
+    free(c.t16); free(c.fl); free(c.fs); free(c.farc); free(c.tl); free(c.ts); free(c.M); free(c.M2); free(c.next); free(c.take); free(c.mark); free(lit); free(plans);
+    for (g = 0; g < ZGE_TABLE_GROUP; g++) { free(gseq[g]); free(gblk[g]); }
     *out_len = pos;
-    return 0;
+    return bad_bound ? -3 : 0;
 }

@@ -60,7 +60,7 @@ class ZgeParams(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in (
         "level", "checksum", "window_log", "long_log", "short_log", "short_bytes", "tile", "sub", "cap",
         "min_match", "min_rep", "rep_search", "back_cap", "lazy", "lazy_delta", "lit_cost", "match_cost",
-        "rep_cost", "short_window_log", "rep_back", "tag_bits", "seg_log", "far_log", "far_ways", "far_step_log", "far_res_log", "far_short", "far_skip", "far_back", "near16", "far_cdc_log", "far_min_frame", "rep_pass", "lazy2_delta", "far_cap", "cont_cap", "ext_cap", "live_reps")]
+        "rep_cost", "short_window_log", "rep_back", "tag_bits", "seg_log", "far_log", "far_ways", "far_step_log", "far_res_log", "far_short", "far_skip", "far_back", "near16", "far_cdc_log", "far_min_frame", "rep_pass", "lazy2_delta", "far_cap", "cont_cap", "ext_cap", "live_reps", "seq_repeat")]
 
 
 class ZgeStats(ctypes.Structure):

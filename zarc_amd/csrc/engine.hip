@@ -65,10 +65,10 @@ struct zarc_gpu {
     // hashing
     DevBuf d_cvs, d_cvs_tmp, d_digests, d_xxh, d_expect;
     // encoder
-    DevBuf d_blocks, d_seq, d_lit, d_out, d_far;
+    DevBuf d_blocks, d_seq, d_lit, d_out, d_far, d_plan;
     // decoder
     DevBuf d_declit, d_status, d_stored_ck;
-    DevBuf d_slot_prefix, d_zblocks, d_nseq, d_fast, d_seqidx, d_seqs, d_ztables, d_litidx, d_lits; // decoder fast path (sequences decoded ahead)
+    DevBuf d_slot_prefix, d_zblocks, d_nseq, d_fast, d_seqidx, d_seqs, d_ztables, d_litidx, d_lits, d_seqflag; // decoder fast path (sequences decoded ahead)
     DevBuf d_queue; // frame queues of the persistent kernels (one u32 each)
     int num_cus = 1;
     int deep_per_cu = 0; // workgroups of zarc_zge_match_deep a CU holds (0: not asked yet)
@@ -579,7 +579,7 @@ int pack_device_impl(zarc_gpu_t *h, size_t n, const void *d_src_base, const uint
     HOST_PHASE(0); // checks, descriptor uploads, checksum + digest set-up
     const std::vector<uint32_t> order = order_by_size_desc(src_len, n);
     HOST_PHASE(1); // size ordering
-    auto per_block_of = [](uint32_t slot) { return (size_t)(zge_seq_stride(slot) * 8 + zge_lit_stride(slot) + zge_out_stride(slot) + sizeof(ZgeBlock)); };
+    auto per_block_of = [](uint32_t slot) { return (size_t)(zge_seq_stride(slot) * 8 + zge_lit_stride(slot) + zge_out_stride(slot) + sizeof(ZgeBlock) + sizeof(ZgePlan)); };
     size_t budget = h->scratch_budget;
     if (!budget) {
         // up to 64 GiB of scratch (BASELINE configs[1] needs 46 GiB to run as ONE launch per kernel), at most 45 % of what is free
@@ -684,9 +684,21 @@ int pack_device_impl(zarc_gpu_t *h, size_t n, const void *d_src_base, const uint
             digest_queued = true;
         }
         ZHIP(t.mark(&b));
-        hipLaunchKernelGGL(zarc_zge_entropy, dim3((unsigned)nb), dim3(64), 0, h->stream, (uint32_t)nb, slot, h->d_blocks.as<ZgeBlock>(),
-                           h->d_seq.as<uint64_t>(), h->d_lit.as<uint8_t>(), h->d_out.as<uint8_t>(),
-                           (P.dbg & 1024) ? (unsigned long long *)((char *)h->d_queue.p + 128) : (unsigned long long *)nullptr);
+        {
+            unsigned long long *const eprof = (P.dbg & 1024) ? (unsigned long long *)((char *)h->d_queue.p + 128) : (unsigned long long *)nullptr;
+            if (bp[1] - bp[0] > 1) {
+                // the sub-batch holds frames of several blocks (the largest comes first): the entropy stage runs in two passes around the
+                // table plan, which lets the blocks of a group share their sequence tables (zge_entropy.hip: zarc_zge_plan)
+                ZHIP(h->d_plan.reserve(nb * sizeof(ZgePlan)));
+                hipLaunchKernelGGL(zarc_zge_entropy_p1, dim3((unsigned)nb), dim3(64), 0, h->stream, (uint32_t)nb, slot, h->d_blocks.as<ZgeBlock>(),
+                                   h->d_seq.as<uint64_t>(), h->d_lit.as<uint8_t>(), h->d_out.as<uint8_t>(), eprof, h->d_plan.as<ZgePlan>());
+                hipLaunchKernelGGL(zarc_zge_plan, dim3((unsigned)nb), dim3(64), 0, h->stream, (uint32_t)nb, h->d_blocks.as<ZgeBlock>(), h->d_plan.as<ZgePlan>());
+                hipLaunchKernelGGL(zarc_zge_entropy_p2, dim3((unsigned)nb), dim3(64), 0, h->stream, (uint32_t)nb, slot, h->d_blocks.as<ZgeBlock>(),
+                                   h->d_seq.as<uint64_t>(), h->d_lit.as<uint8_t>(), h->d_out.as<uint8_t>(), eprof, h->d_plan.as<ZgePlan>());
+            } else
+                hipLaunchKernelGGL(zarc_zge_entropy, dim3((unsigned)nb), dim3(64), 0, h->stream, (uint32_t)nb, slot, h->d_blocks.as<ZgeBlock>(),
+                                   h->d_seq.as<uint64_t>(), h->d_lit.as<uint8_t>(), h->d_out.as<uint8_t>(), eprof);
+        }
         ZHIP(hipGetLastError());
         ZHIP(t.mark(&c));
         if (!xxh_joined) { ZHIP(hipStreamWaitEvent(h->stream, h->ev_join, 0)); xxh_joined = true; }
@@ -888,6 +900,7 @@ int unpack_device_once(zarc_gpu_t *h, size_t n, const void *d_frames_base, const
         ZHIP(h->d_seqidx.reserve(nslots * 8));
         ZHIP(h->d_litidx.reserve(nslots * 8));
         ZHIP(h->d_ztables.reserve(nslots * (size_t)ZDEC_TABLE_CELLS * 2));
+        ZHIP(h->d_seqflag.reserve((nslots / 64 + (size_t)zarc_gpu::DEC_GROUPS + 2) * 4));
         ZHIP(hipMemsetAsync(h->d_zblocks.p, 0xFF, nslots * sizeof(ZdecBlock), h->stream));
         ZHIP(hipMemsetAsync(h->d_nseq.p, 0, nslots * 8, h->stream));
         hipLaunchKernelGGL(zarc_zdec_scan, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, h->stream, (const uint8_t *)d_frames_base, h->d_frame_off.as<uint64_t>(),
@@ -969,10 +982,24 @@ int unpack_device_once(zarc_gpu_t *h, size_t n, const void *d_frames_base, const
                     ZHIP(hipGetLastError());
                     ZHIP(hipEventRecord(h->ev_join3, h->stream3));
                 }
-                if (split > s0)
+                if (split > s0) {
+                    // Waves whose 64 blocks share their tables (the engine's own frames: one table set per group of eight blocks; libzstd's
+                    // Repeat_Mode blocks) decode with the tables in LDS; the others raise their flag and are done by the second launch with a
+                    // table set per block in HBM scratch, as before.
+                    const bool shared = seq_lanes == 64 && diag_env("ZARC_GPU_SEQ_SHARED", 1) != 0;
+                    const size_t waves = (size_t)((split - s0 + 63) / 64);
+                    uint32_t *flags = nullptr;
+                    if (shared) {
+                        flags = h->d_seqflag.as<uint32_t>() + (size_t)(s0 / 64) + (size_t)g; // (a group's slots need not start at a multiple of 64)
+                        ZHIP(hipMemsetAsync(flags, 0, waves * 4, sa));
+                        hipLaunchKernelGGL(zarc_zdec_seqs_shared, dim3((unsigned)waves), dim3(64), 0, sa, (const uint8_t *)d_frames_base, h->d_frame_off.as<uint64_t>(),
+                                           split, h->d_slot_prefix.as<uint64_t>(), h->d_zblocks.as<ZdecBlock>(), h->d_seqidx.as<uint64_t>(), h->d_seqs.as<uint64_t>(),
+                                           h->d_fast.as<uint32_t>(), s0, flags);
+                    }
                     hipLaunchKernelGGL(zarc_zdec_seqs, dim3((unsigned)((split - s0 + seq_lanes - 1) / seq_lanes)), dim3(seq_lanes), 0, sa, (const uint8_t *)d_frames_base,
                                        h->d_frame_off.as<uint64_t>(), split, h->d_slot_prefix.as<uint64_t>(), h->d_zblocks.as<ZdecBlock>(), h->d_seqidx.as<uint64_t>(),
-                                       h->d_seqs.as<uint64_t>(), h->d_ztables.as<uint16_t>(), h->d_fast.as<uint32_t>(), s0);
+                                       h->d_seqs.as<uint64_t>(), h->d_ztables.as<uint16_t>(), h->d_fast.as<uint32_t>(), s0, (const uint32_t *)flags);
+                }
                 if (split < s1) ZHIP(hipStreamWaitEvent(sa, h->ev_join3, 0));
                 ZHIP(hipGetLastError());
                 ZHIP(hipEventRecord(ev[1], sa));

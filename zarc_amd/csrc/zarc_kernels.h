@@ -36,6 +36,27 @@ struct ZgeBlock {
     uint32_t out_len;    // bytes of block content (without the 3-byte header)
     uint32_t pad;
 };
+// Sequence-table plan of one block (entropy stage, multi-block frames): written by pass 1 (code histograms, the block's own best table
+// per type), settled per group of ZGE_TABLE_GROUP blocks by zarc_zge_plan (one shared table per type where that is cheap: the first
+// block describes it, the others say Repeat_Mode), read by pass 2 (model: zstd_enc_model.c, seq_plan / seq_plan_group).
+constexpr uint32_t ZGE_TABLE_GROUP = 8;
+struct ZgePlanTable {
+    int16_t norm[64];   // normalised counts of the table to code with (pass 1: the block's own choice; zarc_zge_plan: the group's)
+    uint8_t desc[80];   // its FSE description (mode 2)
+    uint32_t count[64]; // histogram of the block's codes of this type (zero beyond the largest code)
+    uint32_t cost;      // the own choice's cost in 1/256 bit, description included (modes 0 and 2)
+    uint8_t mode, al, nsym, dl, rle, pad[3]; // Symbol_Compression_Mode 0..3, accuracy log, symbols in norm[], description bytes, RLE symbol
+};
+struct ZgePlan {
+    uint32_t active;     // 1 = pass 2 codes this block's sequences section (0: RLE / raw / no sequences: the block record is final)
+    uint32_t nseq;       // sequences after joining
+    uint32_t lsz;        // bytes of the literals section in front
+    uint32_t extra_bits; // bits of all extra-bits fields (for the size bound)
+    uint32_t guaranteed; // zarc_zge_plan: an upper bound of the coded size is below the raw size
+    uint32_t pad[3];
+    ZgePlanTable t[3];   // LL, OF, ML
+};
+static_assert(sizeof(ZgePlanTable) == 476 && sizeof(ZgePlan) == 32 + 3 * 476, "plan record layout");
 // one sequence: ofv (28 bits) | ll << 28 (18 bits) | ml << 46 (18 bits)
 __host__ __device__ inline uint64_t zge_pack_seq(uint32_t ll, uint32_t ml, uint32_t ofv) { return (uint64_t)ofv | ((uint64_t)ll << 28) | ((uint64_t)ml << 46); }
 __host__ __device__ inline uint32_t zge_seq_ofv(uint64_t s) { return (uint32_t)(s & 0xFFFFFFFu); }
@@ -108,9 +129,15 @@ __global__ void zarc_zdec_literals(const uint8_t *frames_base, const uint64_t *f
 // stage 2 with the tables in LDS: one wave of ZDEC_LDS_LANES active lanes per workgroup
 __global__ void zarc_zdec_seqs_lds(const uint8_t *frames_base, const uint64_t *frame_off, uint64_t n_slots, const uint64_t *slot_prefix,
                                    ZdecBlock *zblocks, const uint64_t *seq_index, uint64_t *seqs, uint32_t *fast, uint64_t slot_base);
-// stage 2: one LANE per block slot entropy-decodes the block's sequences (FSE tables in HBM scratch) into seqs[]
+// stage 2: one LANE per block slot entropy-decodes the block's sequences (FSE tables in HBM scratch) into seqs[]; with wave_flag only the
+// 64-slot waves zarc_zdec_seqs_shared turned down
 __global__ void zarc_zdec_seqs(const uint8_t *frames_base, const uint64_t *frame_off, uint64_t n_slots, const uint64_t *slot_prefix,
-                               ZdecBlock *zblocks, const uint64_t *seq_index, uint64_t *seqs, uint16_t *tables, uint32_t *fast, uint64_t slot_base);
+                               ZdecBlock *zblocks, const uint64_t *seq_index, uint64_t *seqs, uint16_t *tables, uint32_t *fast, uint64_t slot_base,
+                               const uint32_t *wave_flag /* may be null */);
+// stage 2 with the tables shared by a wave's 64 blocks in LDS (Repeat_Mode / equal descriptions); sets wave_flag[wave] where they do not fit
+__global__ void zarc_zdec_seqs_shared(const uint8_t *frames_base, const uint64_t *frame_off, uint64_t n_slots, const uint64_t *slot_prefix,
+                                      ZdecBlock *zblocks, const uint64_t *seq_index, uint64_t *seqs, uint32_t *fast, uint64_t slot_base,
+                                      uint32_t *wave_flag);
 // status[i]: keeps decode errors; else CHECKSUM if the stored XXH64 differs; else DIGEST if expect differs
 __global__ void zarc_unpack_verdict(uint32_t n, const uint64_t *xxh, const uint32_t *stored_checksum, const uint32_t *digests,
                                     const uint32_t *expect /* may be null */, int32_t *status);
@@ -133,8 +160,15 @@ __global__ void zarc_zge_match_deep_diag(ZgeParams P, const uint8_t *src_base, c
                                     const uint32_t *order, const uint32_t *units /* (queue slot, first block) per 2 MiB segment */, uint32_t n_units, const uint64_t *block_prefix, ZgeBlock *blocks,
                                     uint64_t *seq_scratch, uint8_t *lit_scratch, uint32_t *queue, uint32_t *far_scratch);
 #endif
+// entropy stage, everything in one pass (sub-batches without a multi-block frame: every block chooses its tables alone)
 __global__ void zarc_zge_entropy(uint32_t n_blocks, uint32_t slot_bytes, ZgeBlock *blocks, uint64_t *seq_scratch, const uint8_t *lit_scratch,
                                  uint8_t *out_scratch, unsigned long long *prof);
+// ... or in two passes around the table plan: literals + sequence pre-pass + histograms + own choices -> plans[]; the plan; sequences
+__global__ void zarc_zge_entropy_p1(uint32_t n_blocks, uint32_t slot_bytes, ZgeBlock *blocks, uint64_t *seq_scratch, const uint8_t *lit_scratch,
+                                    uint8_t *out_scratch, unsigned long long *prof, ZgePlan *plans);
+__global__ void zarc_zge_plan(uint32_t n_blocks, const ZgeBlock *blocks, ZgePlan *plans);
+__global__ void zarc_zge_entropy_p2(uint32_t n_blocks, uint32_t slot_bytes, ZgeBlock *blocks, uint64_t *seq_scratch, const uint8_t *lit_scratch,
+                                    uint8_t *out_scratch, unsigned long long *prof, ZgePlan *plans);
 __global__ void zarc_zge_assemble(ZgeParams P, const uint8_t *src_base, const uint64_t *src_off, const uint64_t *src_len,
                                   const uint32_t *order, uint32_t n_frames, const uint64_t *block_prefix, const ZgeBlock *blocks, const uint8_t *out_scratch,
                                   const uint64_t *xxh, uint8_t *dst_base, const uint64_t *dst_off, uint64_t *dst_len);

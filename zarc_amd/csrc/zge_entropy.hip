@@ -74,6 +74,9 @@ __device__ __forceinline__ uint32_t ml_extra(uint32_t ml, uint32_t code, uint32_
     return (ml - 3) & ((1u << nb) - 1); // baselines - 3 = 32, 34, .. 40, 44, 48, 56, 64, 80, 96, 128, ..: multiples of 2^nb
 }
 
+__device__ __forceinline__ uint32_t ll_code_bits(uint32_t code) { return code < 16 ? 0u : (code >= 25 ? code - 19 : (uint32_t)((0x433221111ull >> (4 * (code - 16))) & 15)); }
+__device__ __forceinline__ uint32_t ml_code_bits(uint32_t code) { return code < 32 ? 0u : (code >= 43 ? code - 36 : (uint32_t)((0x54433221111ull >> (4 * (code - 32))) & 15)); }
+
 // ---- lane-serial bit writer into a byte buffer (LDS or global) ----
 struct BitW {
     uint8_t *p; uint32_t pos, cap; uint64_t acc; int nb; bool overflow;
@@ -126,7 +129,8 @@ struct EntLds {
 };
 enum { ST_LL = 0, ST_ML = 512, ST_OF = 1024 };
 enum { X_TMP = 0, X_DLEN = 1, X_MODE_L = 2, X_MODE_O = 3, X_MODE_M = 4, X_AL_L = 5, X_AL_O = 6, X_AL_M = 7, X_DL_L = 8, X_DL_O = 9,
-       X_DL_M = 10, X_RLE_L = 11, X_RLE_O = 12, X_RLE_M = 13, X_NSYM_L = 14, X_NSYM_O = 15, X_NSYM_M = 16, X_MAXBITS = 17, X_NSYM_LAST = 18 };
+       X_DL_M = 10, X_RLE_L = 11, X_RLE_O = 12, X_RLE_M = 13, X_NSYM_L = 14, X_NSYM_O = 15, X_NSYM_M = 16, X_MAXBITS = 17, X_NSYM_LAST = 18,
+       X_COST_L = 19, X_COST_O = 20, X_COST_M = 21 /* the own choice's cost in 1/256 bit, description included (< 2^27: 43 690 sequences x 9 bits x 256) */ };
 
 // ---- FSE helpers (lane-serial; same arithmetic as the model) ----
 __device__ void fse_build_ctab(FseCtab &t, const int16_t *norm, int nsym, int al, uint8_t *cellsym)
@@ -331,6 +335,7 @@ __device__ void choose_table(EntLds &L, int which, const uint32_t *count, int ma
     int distinct = 0, last = 0;
     for (int s = 0; s <= maxsym; s++) if (count[s]) { distinct++; last = s; }
     int16_t *norm = L.s.norm[which];
+    L.ctrl[X_COST_L + which] = 0;
     if (distinct == 1) { L.ctrl[X_MODE_L + which] = 1; L.ctrl[X_RLE_L + which] = last; L.ctrl[X_DL_L + which] = 0; return; }
     uint64_t cost_def = ~0ull;
     if (last < def_n) {
@@ -349,8 +354,10 @@ __device__ void choose_table(EntLds &L, int which, const uint32_t *count, int ma
     if (cost_def <= cost_dyn) {
         for (int s = 0; s < def_n; s++) norm[s] = def[s];
         L.ctrl[X_MODE_L + which] = 0; L.ctrl[X_NSYM_L + which] = def_n; L.ctrl[X_AL_L + which] = def_al; L.ctrl[X_DL_L + which] = 0;
+        L.ctrl[X_COST_L + which] = (int)(uint32_t)cost_def;
     } else {
         L.ctrl[X_MODE_L + which] = 2; L.ctrl[X_NSYM_L + which] = nsym; L.ctrl[X_AL_L + which] = al; L.ctrl[X_DL_L + which] = (int)dl;
+        L.ctrl[X_COST_L + which] = (int)(uint32_t)cost_dyn;
     }
 }
 
@@ -602,21 +609,24 @@ struct WavePacker {
     }
 };
 
-} // namespace
-
-__global__ void __launch_bounds__(64, 5) zarc_zge_entropy(uint32_t n_blocks, uint32_t slot_bytes, ZgeBlock *__restrict__ blocks, uint64_t *__restrict__ seq_scratch,
-                                                       const uint8_t *__restrict__ lit_scratch, uint8_t *__restrict__ out_scratch,
-                                                       unsigned long long *__restrict__ prof /* stage ticks (diagnostics) or null */)
+// PHASE 0: the whole stage in one pass (every block chooses its sequence tables alone).  PHASE 1 / 2: the same code cut in two where
+// the tables are chosen -- pass 1 ends with the block's code histograms and own choices in plans[bi], zarc_zge_plan settles the tables of
+// each group of blocks, pass 2 builds them and codes the sequences.  Blocks without sequences to code are finished by pass 1.
+template <int PHASE>
+__device__ __forceinline__ void zge_entropy_body(EntLds &L, uint32_t n_blocks, uint32_t slot_bytes, ZgeBlock *__restrict__ blocks, uint64_t *__restrict__ seq_scratch,
+                                                 const uint8_t *__restrict__ lit_scratch, uint8_t *__restrict__ out_scratch,
+                                                 unsigned long long *__restrict__ prof /* stage ticks (diagnostics) or null */, ZgePlan *__restrict__ plans)
 {
-    __shared__ EntLds L;
     const int lane = zd::lane_id();
     unsigned long long tprev = ZGE_CLOCK();
     const uint32_t bi = blockIdx.x;
     if (bi >= n_blocks) return;
     ZgeBlock *rec = blocks + bi;
-    if (rec->type == 1) return; // RLE block: nothing to code
+    ZgePlan *const plan = PHASE ? plans + bi : nullptr;
+    if (PHASE == 2 && !plan->active) return;
+    if (rec->type == 1) { if (PHASE == 1 && lane == 0) plan->active = 0; return; } // RLE block: nothing to code
     const uint32_t nlit = rec->nlit, src_len = rec->src_len;
-    uint32_t nseq = rec->nseq;
+    uint32_t nseq = PHASE == 2 ? plan->nseq : rec->nseq;
     uint64_t *seq = seq_scratch + (uint64_t)bi * zge_seq_stride(slot_bytes);
     const uint8_t *lit = lit_scratch + (uint64_t)bi * zge_lit_stride(slot_bytes);
     uint8_t *out = out_scratch + (uint64_t)bi * zge_out_stride(slot_bytes);
@@ -624,8 +634,8 @@ __global__ void __launch_bounds__(64, 5) zarc_zge_entropy(uint32_t n_blocks, uin
     bool fail = false;
 
     // ================= literals section =================
-    uint32_t lsz = 0;
-    {
+    uint32_t lsz = PHASE == 2 ? plan->lsz : 0u;
+    if (PHASE != 2) {
         const uint32_t n = nlit;
         const uint32_t raw_hdr = n < 32 ? 1u : (n < 4096 ? 2u : 3u);
         for (int i = lane; i < 256; i += 64) L.h.count[i] = 0;
@@ -762,7 +772,7 @@ __global__ void __launch_bounds__(64, 5) zarc_zge_entropy(uint32_t n_blocks, uin
             lsz = raw_hdr + n;
         }
     }
-    zd::wave_sync_global();
+    if (PHASE != 2) zd::wave_sync_global();
     ENT_PROF(2);
 
     // ================= sequences pre-pass =================
@@ -780,7 +790,7 @@ __global__ void __launch_bounds__(64, 5) zarc_zge_entropy(uint32_t n_blocks, uin
     // length, so match lengths reach the format's 131 074 (model: merge_sequences).  64 sequences per round, compacted in place:
     // a head's length is a difference of the round's prefix sums; the last head of a round stays pending in scalar registers
     // because its run may go on in the next round.
-    if (nseq > 1) {
+    if (PHASE != 2 && nseq > 1) {
         const uint64_t lt = (1ull << lane) - 1;
         uint32_t out = 0;                       // heads so far, including the pending one
         uint32_t pend_lp = 0, pend_ml = 0, pend_o = 0, c_lp = 0, c_o = 0; // pending head; literal position / offset of the previous round's last sequence
@@ -818,7 +828,7 @@ __global__ void __launch_bounds__(64, 5) zarc_zge_entropy(uint32_t n_blocks, uin
         nseq = out;
         zd::wave_sync_global(); // the pass below reads what other lanes wrote here
     }
-    {
+    if (PHASE != 2) {
         uint32_t r0 = 0, r1 = 0, r2 = 0, carry = 0; // wave-uniform history / literal position carried between rounds
         uint64_t s_next = (uint32_t)lane < nseq ? seq[lane] : 0;
         for (uint32_t base = 0; base < nseq; base += 64) {
@@ -875,6 +885,7 @@ __global__ void __launch_bounds__(64, 5) zarc_zge_entropy(uint32_t n_blocks, uin
         pos = nseq < 128 ? 1u : (nseq < 0x7F00 ? 2u : 3u);
         if (nseq == 0) ssz = pos;
         else {
+          if (PHASE != 2) {
             for (int i = lane; i < 36; i += 64) L.s.cl[i] = 0;
             for (int i = lane; i < 32; i += 64) L.s.co[i] = 0;
             for (int i = lane; i < 53; i += 64) L.s.cm[i] = 0;
@@ -902,6 +913,49 @@ __global__ void __launch_bounds__(64, 5) zarc_zge_entropy(uint32_t n_blocks, uin
                              which == 1 ? 5 : 6, which == 1 ? 8 : 9);
             }
             zd::wave_sync();
+          }
+          if (PHASE == 1) {
+            // the block's plan record: histograms, own choices (zarc_zge_plan may replace them by the group's table), what pass 2 needs
+#pragma unroll
+            for (int which = 0; which < 3; which++) {
+                ZgePlanTable *pt = &plan->t[which];
+                const uint32_t *cnt = which == 0 ? L.s.cl : (which == 1 ? L.s.co : L.s.cm);
+                const int nc = which == 0 ? 36 : (which == 1 ? 32 : 53);
+                pt->count[lane] = lane < nc ? cnt[lane] : 0u;
+                pt->norm[lane] = L.s.norm[which][lane];
+                pt->desc[lane] = L.s.desc[which][lane];
+                if (lane < 16) pt->desc[64 + lane] = L.s.desc[which][64 + lane];
+                if (lane == 0) {
+                    pt->cost = (uint32_t)L.ctrl[X_COST_L + which];
+                    pt->mode = (uint8_t)L.ctrl[X_MODE_L + which]; pt->al = (uint8_t)L.ctrl[X_AL_L + which]; pt->nsym = (uint8_t)L.ctrl[X_NSYM_L + which];
+                    pt->dl = (uint8_t)L.ctrl[X_DL_L + which]; pt->rle = (uint8_t)L.ctrl[X_RLE_L + which];
+                }
+            }
+            {
+                uint32_t xb = 0;
+                if (lane < 36) xb += L.s.cl[lane] * ll_code_bits((uint32_t)lane);
+                if (lane < 53) xb += L.s.cm[lane] * ml_code_bits((uint32_t)lane);
+                if (lane < 32) xb += L.s.co[lane] * (uint32_t)lane;
+                xb = zd::wave_sum(xb);
+                if (lane == 0) { plan->active = 1; plan->nseq = nseq; plan->lsz = lsz; plan->extra_bits = xb; plan->guaranteed = 0; }
+            }
+            return; // pass 2 goes on from here
+          }
+          if (PHASE == 2) {
+            // the tables the plan settled on: normalised counts, description, mode per type -> where pass 0 has them after choose_table
+#pragma unroll
+            for (int which = 0; which < 3; which++) {
+                const ZgePlanTable *pt = &plan->t[which];
+                L.s.norm[which][lane] = pt->norm[lane];
+                L.s.desc[which][lane] = pt->desc[lane];
+                if (lane < 16) L.s.desc[which][64 + lane] = pt->desc[64 + lane];
+                if (lane == 0) {
+                    L.ctrl[X_MODE_L + which] = pt->mode; L.ctrl[X_AL_L + which] = pt->al; L.ctrl[X_NSYM_L + which] = pt->nsym;
+                    L.ctrl[X_DL_L + which] = pt->dl; L.ctrl[X_RLE_L + which] = pt->rle;
+                }
+            }
+            zd::wave_sync();
+          }
             // ... and the whole wave builds them, one after the other (round 3: the serial build on three lanes was a sixth of the stage)
 #pragma unroll
             for (int which = 0; which < 3; which++) {
@@ -1035,5 +1089,137 @@ __global__ void __launch_bounds__(64, 5) zarc_zge_entropy(uint32_t n_blocks, uin
     if (lane == 0) {
         if (csz && csz < src_len) { rec->type = 2; rec->out_len = csz; }
         else { rec->type = 0; rec->out_len = src_len; }
+        if (PHASE == 1) plan->active = 0; // no sequences to code (or the literals failed): the block record is final
+    }
+}
+
+} // namespace
+
+__global__ void __launch_bounds__(64, 5) zarc_zge_entropy(uint32_t n_blocks, uint32_t slot_bytes, ZgeBlock *__restrict__ blocks, uint64_t *__restrict__ seq_scratch,
+                                                       const uint8_t *__restrict__ lit_scratch, uint8_t *__restrict__ out_scratch,
+                                                       unsigned long long *__restrict__ prof)
+{
+    __shared__ EntLds L;
+    zge_entropy_body<0>(L, n_blocks, slot_bytes, blocks, seq_scratch, lit_scratch, out_scratch, prof, nullptr);
+}
+__global__ void __launch_bounds__(64, 5) zarc_zge_entropy_p1(uint32_t n_blocks, uint32_t slot_bytes, ZgeBlock *__restrict__ blocks, uint64_t *__restrict__ seq_scratch,
+                                                          const uint8_t *__restrict__ lit_scratch, uint8_t *__restrict__ out_scratch,
+                                                          unsigned long long *__restrict__ prof, ZgePlan *__restrict__ plans)
+{
+    __shared__ EntLds L;
+    zge_entropy_body<1>(L, n_blocks, slot_bytes, blocks, seq_scratch, lit_scratch, out_scratch, prof, plans);
+}
+__global__ void __launch_bounds__(64, 5) zarc_zge_entropy_p2(uint32_t n_blocks, uint32_t slot_bytes, ZgeBlock *__restrict__ blocks, uint64_t *__restrict__ seq_scratch,
+                                                          const uint8_t *__restrict__ lit_scratch, uint8_t *__restrict__ out_scratch,
+                                                          unsigned long long *__restrict__ prof, ZgePlan *__restrict__ plans)
+{
+    __shared__ EntLds L;
+    zge_entropy_body<2>(L, n_blocks, slot_bytes, blocks, seq_scratch, lit_scratch, out_scratch, prof, plans);
+}
+
+// The table plan (model: zstd_enc_model.c, seq_plan_group).  One wave per group of ZGE_TABLE_GROUP blocks of a frame (the wave of the
+// group's first block slot; the others leave at once), one lane per symbol.  Per table type: the sum of the blocks' histograms is
+// normalised like a block's own table would be; if coding every block of the group with that one table costs at most 1/64 more bits
+// than the blocks' own choices, the first block describes it and the others say Repeat_Mode -- as long as the chain holds: a block
+// hands the table on only if an upper bound of its coded size (every state transition at its symbol's larger bit count) is below its
+// raw size, i.e. it cannot end up a raw block, whose tables the decoder never sees; the block behind any other describes the table
+// again.  Blocks that keep RLE mode for a type break that type's chain the same way.  Costs fit 32 bits: a group holds at most
+// 8 x 43 690 sequences at 9 x 256 units each.
+__global__ void __launch_bounds__(64) zarc_zge_plan(uint32_t n_blocks, const ZgeBlock *__restrict__ blocks, ZgePlan *__restrict__ plans)
+{
+    __shared__ int16_t gnorm[3][64];
+    __shared__ uint8_t gdesc[3][80];
+    __shared__ uint32_t gdl[3];
+    const int lane = zd::lane_id();
+    const uint32_t bi = blockIdx.x;
+    if (bi >= n_blocks) return;
+    const uint32_t frame = blocks[bi].frame, index0 = blocks[bi].index;
+    if (index0 % ZGE_TABLE_GROUP) return;
+    uint32_t nb = 1;
+    while (nb < ZGE_TABLE_GROUP && bi + nb < n_blocks && blocks[bi + nb].frame == frame && blocks[bi + nb].index == index0 + nb) nb++;
+    if (nb < 2) return; // a block on its own keeps its own choices
+    bool use_group[3] = {false, false, false};
+    uint32_t g_al[3] = {0, 0, 0}, g_nsym[3] = {0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+        const int max_al = t == 1 ? 8 : 9;
+        uint32_t sum = 0, total = 0, cost_own = 0, np = 0;
+        for (uint32_t b = 0; b < nb; b++) {
+            const ZgePlan *p = plans + bi + b;
+            if (!p->active || p->t[t].mode == 1) continue; // uniform
+            sum += p->t[t].count[lane];
+            total += p->nseq; cost_own += p->t[t].cost; np++;
+        }
+        if (np < 2) continue;
+        const uint64_t present = zd::ballot(sum != 0);
+        const int distinct = (int)__popcll(present), last = 63 - (int)__clzll((long long)present);
+        int al = zd::hb32(total > 1 ? total - 1 : 1) - 2;
+        if (al > max_al) al = max_al;
+        if (al < 5) al = 5;
+        while ((1 << al) < distinct) al++;
+        const uint32_t T = 1u << al;
+        // fse_normalize, a symbol per lane: round to nearest (at least 1), then the surplus / deficit goes to the largest entry (lowest
+        // symbol on ties), one wave maximum per step
+        uint32_t v = 0;
+        if (sum) { v = (sum * T + total / 2) / total; if (v < 1) v = 1; } // sum * T < 2^28
+        uint32_t vs = zd::uniform(zd::wave_sum(v));
+        while (vs != T) {
+            const uint32_t key = v ? (v << 6) | (uint32_t)(63 - lane) : 0u;
+            const uint32_t best = 63u - (zd::uniform(zd::wave_max(key)) & 63u);
+            const uint32_t bv = zd::readlane(v, best);
+            if (vs > T) {
+                uint32_t take = vs - T;
+                const uint32_t room = bv - 1;
+                if (take > room) take = room;
+                if (take == 0) break;
+                if ((uint32_t)lane == best) v -= take;
+                vs -= take;
+            } else {
+                if ((uint32_t)lane == best) v += T - vs;
+                vs = T;
+            }
+        }
+        gnorm[t][lane] = (int16_t)v; // zero beyond the last symbol
+        zd::wave_sync();
+        if (lane == 0) gdl[t] = fse_write_desc(gdesc[t], 80, gnorm[t], last + 1, al);
+        zd::wave_sync();
+        const uint32_t dl = gdl[t];
+        if (!dl) continue;
+        const uint32_t cost_group = zd::uniform(zd::wave_sum(sum ? sum * ((uint32_t)al * 256 - log2_fp8(v)) : 0u)) + dl * 8 * 256;
+        use_group[t] = cost_group <= cost_own + (cost_own >> 6);
+        g_al[t] = (uint32_t)al; g_nsym[t] = (uint32_t)(last + 1);
+    }
+    if (!use_group[0] && !use_group[1] && !use_group[2]) return; // every block keeps its own choices: nothing to write
+    bool have[3] = {false, false, false}; // the decoder is known to hold the group's table of this type
+    for (uint32_t b = 0; b < nb; b++) {
+        ZgePlan *p = plans + bi + b;
+        if (!p->active) continue; // uniform
+        uint32_t ub_bits = 1 + p->extra_bits, hdrs = 0;
+        bool grp[3];
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            ZgePlanTable *pt = &p->t[t];
+            uint32_t mode = pt->mode, al = pt->al, dl = pt->dl;
+            int n_l = pt->norm[lane];
+            grp[t] = mode != 1 && use_group[t];
+            if (grp[t]) {
+                mode = have[t] ? 3u : 2u; al = g_al[t]; dl = mode == 2 ? gdl[t] : 0u; n_l = gnorm[t][lane];
+                pt->norm[lane] = (int16_t)n_l;
+                if (mode == 2) { pt->desc[lane] = gdesc[t][lane]; if (lane < 16) pt->desc[64 + lane] = gdesc[t][64 + lane]; }
+                if (lane == 0) { pt->mode = (uint8_t)mode; pt->al = (uint8_t)al; pt->nsym = (uint8_t)g_nsym[t]; pt->dl = (uint8_t)dl; }
+            }
+            if (mode != 1) {
+                const uint32_t cnt = pt->count[lane];
+                const uint32_t mb = (n_l == -1 || n_l == 1) ? al : (n_l > 1 ? al - (uint32_t)zd::hb32((uint32_t)(n_l - 1)) : 0u);
+                ub_bits += zd::uniform(zd::wave_sum(cnt * mb)) + al;
+            }
+            hdrs += mode == 1 ? 1u : dl;
+        }
+        const uint32_t nseq = p->nseq;
+        const uint32_t ub = p->lsz + (nseq < 128 ? 1u : (nseq < 0x7F00 ? 2u : 3u)) + 1 + (ub_bits + 7) / 8 + hdrs;
+        const bool guaranteed = ub < blocks[bi + b].src_len;
+        if (lane == 0) p->guaranteed = guaranteed ? 1u : 0u;
+#pragma unroll
+        for (int t = 0; t < 3; t++) have[t] = grp[t] && guaranteed;
     }
 }

@@ -29,6 +29,12 @@
 namespace {
 
 constexpr int BLOCK_MAX = 128 * 1024;
+constexpr int ZDEC_SH_SETS = 10; // zarc_zdec_seqs_shared: tables per type a wave keeps in LDS
+#ifdef ZARC_HIPEMU
+typedef const uint16_t *ZDEC_LDS_TAB;
+#else
+typedef const uint16_t __attribute__((address_space(3))) *ZDEC_LDS_TAB; // a pointer the compiler knows to be LDS: ds_read_u16, not flat loads
+#endif
 constexpr int SEQ_BATCH = 64;
 
 __constant__ const uint32_t D_LL_BASE[36] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18,
@@ -1303,82 +1309,24 @@ __global__ void __launch_bounds__(64) zarc_zdec_scan(const uint8_t *__restrict__
     fast[f] = 1;
 }
 
-// table of type t for block slot s: from the block's own description or, in Repeat mode, from the nearest earlier block of
-// the frame that has sequences and sets this table.  Returns the accuracy or -1.
-__device__ int make_seq_table(uint16_t *tab, int t, const SeqHeader &own, const uint8_t *src, uint64_t s, uint32_t f,
-                              const uint64_t *__restrict__ slot_prefix, const ZdecBlock *__restrict__ zblocks)
+// The sequence chain of one block on one lane (stage 2): FSE states through the three decode tables `tl` / `to` / `tm` (HBM scratch or
+// LDS: the pointer's address space is the caller's), repeat offsets kept symbolic, 8 bytes per sequence streamed to outp.  Leaves the
+// block's summary in zblocks[s] or, when anything is off, clears fast[f] (the frame pass then decodes the frame inline).
+template <typename TAB>
+__device__ __forceinline__ void seq_chain(bool ok, const uint8_t *__restrict__ src, const ZdecBlock &zb, const SeqHeader &own, const uint32_t end,
+                                          TAB tl, TAB to, TAB tm, const int al_l, const int al_o, const int al_m, uint64_t *__restrict__ outp,
+                                          ZdecBlock *__restrict__ zslot, uint32_t *__restrict__ fast_f)
 {
-    uint32_t mode = own.mode[t], off = own.off[t], len = own.len[t];
-    if (mode == 3) {
-        bool found = false;
-        const uint64_t first = slot_prefix[f];
-        for (uint64_t j = s; j > first;) {
-            j--;
-            const ZdecBlock pb = zblocks[j];
-            if (pb.type != 2 || pb.nseq == 0) continue;
-            SeqHeader ph;
-            if (!scan_seq_header(src, pb.seq_hdr, pb.payload + pb.size, &ph)) break;
-            if (ph.mode[t] == 3) continue;
-            mode = ph.mode[t]; off = ph.off[t]; len = ph.len[t];
-            found = true;
-            break;
-        }
-        if (!found) return -1;
-    }
-    return build_seq_table(tab, t, mode, src + off, mode == 2 ? len : (mode == 1 ? 1u : 0u));
-}
-
-// Stage 2: one lane per block slot.
-__global__ void __launch_bounds__(64) zarc_zdec_seqs(const uint8_t *__restrict__ frames_base, const uint64_t *__restrict__ frame_off, uint64_t n_slots,
-                                                     const uint64_t *__restrict__ slot_prefix, ZdecBlock *__restrict__ zblocks,
-                                                     const uint64_t *__restrict__ seq_index, uint64_t *__restrict__ seqs, uint16_t *__restrict__ tables,
-                                                     uint32_t *__restrict__ fast, uint64_t slot_base)
-{
-    const uint64_t s = slot_base + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; // slots [slot_base, n_slots); waves may be partly filled (engine.hip)
-    if (s >= n_slots) return;
-    const ZdecBlock zb = zblocks[s];
-    if (zb.type != 2 || zb.nseq == 0) return;
-    const uint32_t f = zb.frame;
-    if (!fast[f]) return;
-    const uint8_t *src = frames_base + frame_off[f];
-    const uint32_t end = zb.payload + zb.size;
-    uint16_t *tab = tables + s * (uint64_t)ZDEC_TABLE_CELLS;
-    uint16_t *const tabs[3] = {tab, tab + 1024, tab + 512}; // LL, OF, ML
-    SeqHeader own;
-    bool ok = scan_seq_header(src, zb.seq_hdr, end, &own);
-    int al[3] = {0, 0, 0};
     // repeat-offset history, symbolic: hv = offset (hr = 0) or hv = slot | delta << 2 of the history at block start (hr = 1)
     uint32_t hv0 = 0, hv1 = 1, hv2 = 2, hr0 = 1, hr1 = 1, hr2 = 1;
     uint32_t bpos_ = 0, reach_ = 0, msum_ = 0; // output position inside the block, farthest reach in front of it, sum of the match lengths
-    for (int t = 0; t < 3 && ok; t++) {
-        uint32_t mode = own.mode[t], off = own.off[t], len = own.len[t];
-        if (mode == 3) { // Repeat: the description lives in the nearest earlier block with sequences that set this table
-            ok = false;
-            const uint64_t first = slot_prefix[f];
-            for (uint64_t j = s; j > first;) {
-                j--;
-                const ZdecBlock pb = zblocks[j];
-                if (pb.type != 2 || pb.nseq == 0) continue;
-                SeqHeader ph;
-                if (!scan_seq_header(src, pb.seq_hdr, pb.payload + pb.size, &ph)) break;
-                if (ph.mode[t] == 3) continue;
-                mode = ph.mode[t]; off = ph.off[t]; len = ph.len[t];
-                ok = true;
-                break;
-            }
-            if (!ok) break;
-        }
-        al[t] = build_seq_table(tabs[t], t, mode, src + off, mode == 2 ? len : (mode == 1 ? 1u : 0u));
-        if (al[t] < 0) ok = false;
-    }
     if (ok) {
         SeqBits b;
         ok = b.init(src + own.bits_off, end - own.bits_off);
         uint32_t sl = 0, so = 0, sm = 0;
-        if (ok) { sl = b.read(al[0]); so = b.read(al[1]); sm = b.read(al[2]); ok = b.bitpos >= 0; }
-        uint64_t *outp = seqs + seq_index[s];
+        if (ok) { sl = b.read(al_l); so = b.read(al_o); sm = b.read(al_m); ok = b.bitpos >= 0; }
         for (uint32_t i = 0; i < zb.nseq && ok; i++) {
-            const uint32_t cl = tabs[0][sl], co = tabs[1][so], cm = tabs[2][sm];
+            const uint32_t cl = tl[sl], co = to[so], cm = tm[sm];
             const uint32_t ofc = cell_sym(co), mlc = cell_sym(cm), llc = cell_sym(cl);
             if (ofc > 27 || mlc > 52 || llc > 35) { ok = false; break; } // offsets past the format's largest window: left to the frame pass
             const uint32_t ofv = (1u << ofc) + b.read((int)ofc);
@@ -1412,23 +1360,164 @@ __global__ void __launch_bounds__(64) zarc_zdec_seqs(const uint8_t *__restrict__
             bpos_ += ml; msum_ += ml;
             zd::store_streaming(outp + i, zge_pack_seq(ll | (orf ? ZDEC_LL_REF : 0u), ml, ov)); // written once, read by the frame pass: keep it out of the way of the tables
             if (i + 1 < zb.nseq) {
-                sl = cell_base(cl, al[0]) + b.read((int)cell_nbits(cl, al[0]));
-                sm = cell_base(cm, al[2]) + b.read((int)cell_nbits(cm, al[2]));
-                so = cell_base(co, al[1]) + b.read((int)cell_nbits(co, al[1]));
+                sl = cell_base(cl, al_l) + b.read((int)cell_nbits(cl, al_l));
+                sm = cell_base(cm, al_m) + b.read((int)cell_nbits(cm, al_m));
+                so = cell_base(co, al_o) + b.read((int)cell_nbits(co, al_o));
             }
             if (b.bitpos < 0) ok = false;
         }
         if (ok && b.bitpos != 0) ok = false;
     }
     if (ok) {
-        zblocks[s].rep[0] = hr0 ? (ZDEC_REP_REF | hv0) : hv0;
-        zblocks[s].rep[1] = hr1 ? (ZDEC_REP_REF | hv1) : hv1;
-        zblocks[s].rep[2] = hr2 ? (ZDEC_REP_REF | hv2) : hv2;
-        zblocks[s].pad[0] = reach_;
-        zblocks[s].pad[1] = zb.lit_len + msum_;
-        zblocks[s].state = 1;
+        zslot->rep[0] = hr0 ? (ZDEC_REP_REF | hv0) : hv0;
+        zslot->rep[1] = hr1 ? (ZDEC_REP_REF | hv1) : hv1;
+        zslot->rep[2] = hr2 ? (ZDEC_REP_REF | hv2) : hv2;
+        zslot->pad[0] = reach_;
+        zslot->pad[1] = zb.lit_len + msum_;
+        zslot->state = 1;
     }
-    else fast[f] = 0; // the frame pass decodes this frame inline and reports whatever is wrong with it
+    else *fast_f = 0; // the frame pass decodes this frame inline and reports whatever is wrong with it
+}
+
+// Where the table of type t of block slot s is described: the block's own header or, in Repeat mode, the nearest earlier block of the
+// frame that has sequences and sets this table.  *owner = the slot that describes it.
+__device__ bool seq_table_source(int t, const SeqHeader &own, const uint8_t *src, uint64_t s, uint32_t f, const uint64_t *__restrict__ slot_prefix,
+                                 const ZdecBlock *__restrict__ zblocks, uint32_t *mode, uint32_t *off, uint32_t *len, uint64_t *owner)
+{
+    *mode = own.mode[t]; *off = own.off[t]; *len = own.len[t]; *owner = s;
+    if (*mode != 3) return true;
+    const uint64_t first = slot_prefix[f];
+    for (uint64_t j = s; j > first;) {
+        j--;
+        const ZdecBlock pb = zblocks[j];
+        if (pb.type != 2 || pb.nseq == 0) continue;
+        SeqHeader ph;
+        if (!scan_seq_header(src, pb.seq_hdr, pb.payload + pb.size, &ph)) return false;
+        if (ph.mode[t] == 3) continue;
+        *mode = ph.mode[t]; *off = ph.off[t]; *len = ph.len[t]; *owner = j;
+        return true;
+    }
+    return false;
+}
+__device__ int make_seq_table(uint16_t *tab, int t, const SeqHeader &own, const uint8_t *src, uint64_t s, uint32_t f,
+                              const uint64_t *__restrict__ slot_prefix, const ZdecBlock *__restrict__ zblocks)
+{
+    uint32_t mode, off, len;
+    uint64_t owner;
+    if (!seq_table_source(t, own, src, s, f, slot_prefix, zblocks, &mode, &off, &len, &owner)) return -1;
+    return build_seq_table(tab, t, mode, src + off, mode == 2 ? len : (mode == 1 ? 1u : 0u));
+}
+
+// Stage 2: one lane per block slot, every lane with its own table set in HBM scratch.  With `wave_flag` (the launch behind
+// zarc_zdec_seqs_shared) only the waves that kernel turned down do anything.
+__global__ void __launch_bounds__(64) zarc_zdec_seqs(const uint8_t *__restrict__ frames_base, const uint64_t *__restrict__ frame_off, uint64_t n_slots,
+                                                     const uint64_t *__restrict__ slot_prefix, ZdecBlock *__restrict__ zblocks,
+                                                     const uint64_t *__restrict__ seq_index, uint64_t *__restrict__ seqs, uint16_t *__restrict__ tables,
+                                                     uint32_t *__restrict__ fast, uint64_t slot_base, const uint32_t *__restrict__ wave_flag)
+{
+    if (wave_flag && !wave_flag[blockIdx.x]) return; // (launched with 64 lanes per workgroup then: the flags are per 64 slots)
+    const uint64_t s = slot_base + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; // slots [slot_base, n_slots); waves may be partly filled (engine.hip)
+    if (s >= n_slots) return;
+    const ZdecBlock zb = zblocks[s];
+    if (zb.type != 2 || zb.nseq == 0) return;
+    const uint32_t f = zb.frame;
+    if (!fast[f]) return;
+    const uint8_t *src = frames_base + frame_off[f];
+    const uint32_t end = zb.payload + zb.size;
+    uint16_t *tab = tables + s * (uint64_t)ZDEC_TABLE_CELLS;
+    uint16_t *const tabs[3] = {tab, tab + 1024, tab + 512}; // LL, OF, ML
+    SeqHeader own;
+    bool ok = scan_seq_header(src, zb.seq_hdr, end, &own);
+    int al[3] = {0, 0, 0};
+    for (int t = 0; t < 3 && ok; t++) {
+        al[t] = make_seq_table(tabs[t], t, own, src, s, f, slot_prefix, zblocks);
+        if (al[t] < 0) ok = false;
+    }
+    seq_chain<const uint16_t *>(ok, src, zb, own, end, tabs[0], tabs[1], tabs[2], al[0], al[1], al[2], seqs + seq_index[s], zblocks + s, fast + f);
+}
+
+// Stage 2 with the tables of a wave's 64 blocks SHARED in LDS.  The engine's own frames code the eight blocks of a 1 MiB entry with
+// one table per type (zge_entropy.hip: zarc_zge_plan; libzstd repeats tables as well): blocks whose tables come from the same
+// description (their own, or the same earlier block's through Repeat_Mode; the predefined distributions; an RLE symbol) use one copy.
+// A wave's 64 consecutive block slots typically need 8 table sets instead of 64: they fit LDS (ZDEC_SH_SETS tables per type, 25 KiB per
+// wave, six waves per CU), and the three lookups per sequence stop being 64-byte lines from 80 000 tables in HBM / MALL (178 GB per
+// launch at BASELINE configs[1], 11 x the whole path's algorithmic bytes).  A wave that needs more tables of some type than fit
+// sets wave_flag[its index] and leaves: the launch of zarc_zdec_seqs behind this one does its 64 slots the old way.
+__global__ void __launch_bounds__(64) zarc_zdec_seqs_shared(const uint8_t *__restrict__ frames_base, const uint64_t *__restrict__ frame_off, uint64_t n_slots,
+                                                            const uint64_t *__restrict__ slot_prefix, ZdecBlock *__restrict__ zblocks,
+                                                            const uint64_t *__restrict__ seq_index, uint64_t *__restrict__ seqs,
+                                                            uint32_t *__restrict__ fast, uint64_t slot_base, uint32_t *__restrict__ wave_flag)
+{
+    __shared__ uint16_t T_ll[ZDEC_SH_SETS][512], T_ml[ZDEC_SH_SETS][512], T_of[ZDEC_SH_SETS][256];
+    __shared__ int32_t T_al[3][ZDEC_SH_SETS];
+    __shared__ uint32_t lead[3][ZDEC_SH_SETS];
+    const int lane = zd::lane_id();
+    const uint64_t s = slot_base + (uint64_t)blockIdx.x * 64 + (uint64_t)lane;
+    ZdecBlock zb;
+    zb.type = 0xFFFFFFFFu; zb.nseq = 0; zb.frame = 0; zb.payload = 0; zb.size = 0; zb.seq_hdr = 0; zb.lit_len = 0;
+    if (s < n_slots) zb = zblocks[s];
+    const uint32_t f = zb.type == 2 ? zb.frame : 0u;
+    const bool mine = s < n_slots && zb.type == 2 && zb.nseq != 0 && fast[f] != 0; // a lane with a block to decode
+    const uint8_t *src = frames_base + (mine ? frame_off[f] : 0);
+    const uint32_t end = zb.payload + zb.size;
+    SeqHeader own;
+    own.bits_off = 0;
+    for (int t = 0; t < 3; t++) { own.mode[t] = 0; own.off[t] = 0; own.len[t] = 0; }
+    bool ok = mine && scan_seq_header(src, zb.seq_hdr, end, &own);
+    // where each of my three tables is described, and a key that is equal for lanes whose table is the same one
+    uint32_t mode[3] = {0, 0, 0}, off[3] = {0, 0, 0}, len[3] = {0, 0, 0}, key[3] = {0, 0, 0}, idx[3] = {0, 0, 0};
+    for (int t = 0; t < 3 && ok; t++) {
+        uint64_t owner;
+        ok = seq_table_source(t, own, src, s, f, slot_prefix, zblocks, &mode[t], &off[t], &len[t], &owner);
+        // (slots of one launch lie within 2^30 of each other: engine.hip caps the table scratch at 8 GiB = 3.4 M slots)
+        if (ok) key[t] = mode[t] == 0 ? 0xC0000000u : (mode[t] == 1 ? (0x80000000u | src[off[t]]) : (uint32_t)(owner & 0x3FFFFFFFu));
+    }
+    // table indices: the lanes of one key share a table; the first lane of each key is the one whose description is read
+    uint32_t most = 0;
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+        uint64_t rem = zd::ballot(ok);
+        uint32_t n = 0;
+        while (rem) { // uniform
+            const uint32_t first = (uint32_t)zd::ctz64(rem);
+            const uint32_t k = zd::readlane(key[t], first);
+            const uint64_t m = zd::ballot(ok && key[t] == k);
+            if (ok && key[t] == k) idx[t] = n;
+            if (n < (uint32_t)ZDEC_SH_SETS && lane == 0) lead[t][n] = first;
+            n++;
+            rem &= ~m;
+        }
+        most = n > most ? n : most;
+        if (lane == 0) for (uint32_t i = n; i < (uint32_t)ZDEC_SH_SETS; i++) lead[t][i] = 0xFFFFFFFFu;
+    }
+    if (most > (uint32_t)ZDEC_SH_SETS) { if (lane == 0) wave_flag[blockIdx.x] = 1; return; } // uniform: zarc_zdec_seqs takes these 64 slots
+    zd::wave_sync();
+    // build: lane L builds table L % SETS of type L / SETS from its first user's description (3 x SETS <= 64 lanes at once)
+    {
+        static_assert(3 * ZDEC_SH_SETS <= 64, "one building lane per table");
+        const int bt = lane / ZDEC_SH_SETS, bn = lane % ZDEC_SH_SETS;
+        const uint32_t from = bt < 3 ? lead[bt][bn] : 0xFFFFFFFFu;
+        const int fl = from == 0xFFFFFFFFu ? lane : (int)from;
+        uint32_t bmode = 0, boff = 0, blen = 0;
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            const uint32_t m_ = zd::shfl(mode[t], fl), o_ = zd::shfl(off[t], fl), l_ = zd::shfl(len[t], fl);
+            if (t == bt) { bmode = m_; boff = o_; blen = l_; }
+        }
+        const uint32_t bf = zd::shfl(f, fl);
+        if (from != 0xFFFFFFFFu) {
+            uint16_t *tab = bt == 0 ? &T_ll[bn][0] : (bt == 1 ? &T_of[bn][0] : &T_ml[bn][0]);
+            const uint8_t *bsrc = frames_base + frame_off[bf];
+            T_al[bt][bn] = build_seq_table(tab, bt, bmode, bsrc + boff, bmode == 2 ? blen : (bmode == 1 ? 1u : 0u));
+        }
+    }
+    zd::wave_sync();
+    if (!mine) return;
+    int al_l = 0, al_o = 0, al_m = 0;
+    if (ok) { al_l = T_al[0][idx[0]]; al_o = T_al[1][idx[1]]; al_m = T_al[2][idx[2]]; ok = al_l >= 0 && al_o >= 0 && al_m >= 0; }
+    const uint32_t i0 = ok ? idx[0] : 0u, i1 = ok ? idx[1] : 0u, i2 = ok ? idx[2] : 0u;
+    seq_chain<ZDEC_LDS_TAB>(ok, src, zb, own, end, (ZDEC_LDS_TAB)&T_ll[i0][0], (ZDEC_LDS_TAB)&T_of[i1][0], (ZDEC_LDS_TAB)&T_ml[i2][0],
+                            al_l, al_o, al_m, seqs + seq_index[s], zblocks + s, fast + f);
 }
 
 
