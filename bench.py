@@ -140,6 +140,9 @@ def workload(args, rank, world):
         level, kind = 3, args.kind
         desc = "zarc pack %d x %d B synthetic entries per GPU, zstd level 3, checksum on (BASELINE configs[1]%s)" % (
             args.entries, args.size, "" if (args.entries, args.size) == (10000, 1 << 20) else ", scaled")
+    if args.level is not None and args.level != level:
+        desc = desc.replace("zstd level %d" % level, "zstd level %d (--level: not the configuration's %d)" % (args.level, level))
+        level = args.level
     mine = shard.assign(sizes, world)[rank]          # positions in the global list
     if args.config == "c2":
         # Weak scaling keeps every rank's share the SAME mix of kinds: list position j holds corpus entry (j mod G) * entries + j // G, so
@@ -223,6 +226,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true")
     ap.add_argument("--dec-groups", type=int, default=0, help="diagnostics: ZARC_GPU_PX_DEC_GROUPS (0 = the engine decides by the batch's shape)")
+    ap.add_argument("--level", type=int, default=None, help="compression level instead of the configuration's (c2 / c5 / small: 3, c4: 9); the metric then names it")
     ap.add_argument("--kind", type=int, default=-1, help="diagnostics: use one corpus kind for every entry (default: round-robin)")
     args = ap.parse_args()
     if args.entries is None:

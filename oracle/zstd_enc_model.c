@@ -1143,6 +1143,10 @@ void zge_default_params(zge_params *P, int level)
          * (the far tables hold what they forget: no ratio lost on any item of tests/support/realdata.py, and two workgroups fit a CU) */
         P->rep_pass = 2; P->live_reps = 1; P->lazy2_delta = 5; P->lit_cost = 6; P->long_log = 13; P->short_log = 13;
         P->cont_cap = 960; /* a match cut at `cap` goes on at the tile's cursor (the level-3 kernel has no register to spare for it: DESIGN.md 4.1) */
+        if (level >= 15) P->rep_pass = 4; /* round 4: levels 15 .. 22 run two more rounds of the live recent-offset pass */
+    }
+    if (level != 0 && level <= 1) { /* round 4: level 1 and the negative levels -- the near table only: no far table, no lazy step, no extension round */
+        P->far_log = 0; P->rep_pass = 0; P->lazy = 0;
     }
 }
 

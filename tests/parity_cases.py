@@ -102,6 +102,32 @@ def check_pack(engine, oracle, corpus, libzstds, big):
         assert len(frame) <= engine.bound(len(raw))
 
 
+def check_levels(engine, oracle, corpus, libzstds, big):
+    """The level tiers (zarc-cli/src/pack.rs:24-33 forwards --level -131072..22): level 1 and the negative levels run the fast finder (near
+    table only), 2..8 the level-3 finder, 9..14 the deep finder, 15..22 the deep finder with two more live rounds.  Every tier bit-exact
+    against the model at the same level, valid for the oracle decoder and libzstd; levels of one tier give the same bytes."""
+    cases = encode_cases(corpus, big)
+    names = [k for k in ("k0_64k", "k1_64k", "k0_200k", "far_repeat", "per3", "cold_hot", "abc", "empty") if k in cases] + (["k0_4m", "far_2m3"] if big else [])
+    frames = {}
+    try:
+        for level in (1, -1, -7, 2, 9, 15, 22):
+            engine.set_parameter(_lib.P_COMPRESSION_LEVEL, level)
+            res = engine.pack([cases[k] for k in names])
+            frames[level] = [f for f, _ in res]
+            for k, (frame, dig) in zip(names, res):
+                raw = cases[k]
+                assert frame == oracle.zge_encode(raw, oracle.params(level=level)), (k, level)
+                rc, out, used = oracle.zstd_decode(frame, len(raw))
+                assert rc == 0 and used == len(frame) and out == raw, (k, level)
+                for z in libzstds:
+                    got, err = z.decompress(frame, len(raw))
+                    assert got == raw, (k, level, z.version, err)
+        assert frames[1] == frames[-1] == frames[-7] and frames[15] == frames[22]
+        assert frames[1] != frames[2] and frames[2] != frames[9]
+    finally:
+        engine.set_parameter(_lib.P_COMPRESSION_LEVEL, 3)
+
+
 def check_unpack_golden(engine, oracle, corpus, golden_frames, limit=None):
     """Frames made by real libzstd builds decode bit-exactly; digest + checksum verified."""
     d, m = golden_frames

@@ -17,6 +17,10 @@ def test_emu_pack_bit_exact_and_valid(emu_engine, oracle, corpus, libzstds):
     pc.check_pack(emu_engine, oracle, corpus, libzstds, big=False)
 
 
+def test_emu_level_tiers(emu_engine, oracle, corpus, libzstds):
+    pc.check_levels(emu_engine, oracle, corpus, libzstds, big=False)
+
+
 def test_emu_unpack_libzstd_golden(emu_engine, oracle, corpus, golden_frames):
     pc.check_unpack_golden(emu_engine, oracle, corpus, golden_frames, limit=140000)
 

@@ -20,6 +20,11 @@ def test_gpu_pack_bit_exact_and_valid(engine, oracle, corpus, libzstds):
     pc.check_pack(engine, oracle, corpus, libzstds, big=True)
 
 
+@pytest.mark.gpu
+def test_gpu_level_tiers(engine, oracle, corpus, libzstds):
+    pc.check_levels(engine, oracle, corpus, libzstds, big=True)
+
+
 def test_gpu_unpack_libzstd_golden(engine, oracle, corpus, golden_frames):
     pc.check_unpack_golden(engine, oracle, corpus, golden_frames)
 

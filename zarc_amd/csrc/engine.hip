@@ -152,6 +152,10 @@ ZgeParams derive_params(const zarc_gpu_params &p)
     z.far_cdc_log = deep ? 0 : 4;
     z.far_min_frame = deep ? 0 : 65536; // smaller frames do without the far table: the near table reaches 64 KiB
     z.far_back = 48; z.far_skip = deep ? 0 : 64;
+    if (deep && level >= 15) z.rep_pass = 4; // levels 15 .. 22: two more rounds of the live recent-offset pass (a run-time count: the same kernel)
+    if (level <= 1) { // level 1 and the negative levels: the fast finder (zarc_zge_match_fast) -- the near table alone, no lazy step, no extension round
+        z.far_log = 0; z.rep_pass = 0; z.lazy = 0;
+    }
     z.dbg = diag_env("ZARC_GPU_DBG", 0); // timing-only ablations (outputs invalid when set): diagnostic build only
     return z;
 }
@@ -517,11 +521,13 @@ int pack_device_impl(zarc_gpu_t *h, size_t n, const void *d_src_base, const uint
 #endif
     // the match finder has these compiled in (zge_match.hip: F_*)
     const bool dp = P.level >= 9; // the deep finder (zarc_zge_match_deep)
+    const bool fp = P.level <= 1; // the fast finder (zarc_zge_match_fast): the level-3 finder's near table without everything behind it
     if (P.rep_back != 256 || P.back_cap != 8 || P.lazy_delta != 5 || P.min_rep != 3 || P.rep_search != 2 || P.seg_log != 21 || P.short_window_log < 30 ||
-        P.lit_cost != (dp ? 6 : 5) || P.rep_cost != 9 || P.tag_bits != 10 || P.far_log != 16 || P.match_cost != (dp ? 10 : 12) || P.far_ways != (dp ? 2 : 1) ||
+        P.lit_cost != (dp ? 6 : 5) || P.rep_cost != 9 || P.tag_bits != 10 || P.far_log != (fp ? 0 : 16) || P.match_cost != (dp ? 10 : 12) || P.far_ways != (dp ? 2 : 1) ||
         P.far_step_log != (dp ? 1 : 5) || P.far_res_log != (dp ? 0 : 2) || (P.far_short != 0) != dp || P.long_log != 13 ||
-        P.near16 != (dp ? 0 : 1) || P.short_log != (dp ? 13 : 15) || P.far_cdc_log != (dp ? 0 : 4) || P.lazy2_delta != (dp ? 5 : 0) || P.rep_pass != (dp ? 2 : 1) || P.live_reps != (dp ? 1 : 0) || P.ext_cap != 960 || P.far_cap != 0 || P.cont_cap != (dp ? 960 : 0) ||
-        P.far_back != 48 || P.far_skip != (dp ? 0 : 64)) { set_error(h, "internal: encoder parameters differ from the compiled-in ones"); return ZARC_GPU_E_PARAM; }
+        P.near16 != (dp ? 0 : 1) || P.short_log != (dp ? 13 : 15) || P.far_cdc_log != (dp ? 0 : 4) || P.lazy2_delta != (dp ? 5 : 0) ||
+        P.rep_pass != (dp ? (P.level >= 15 ? 4 : 2) : (fp ? 0 : 1)) || P.live_reps != (dp ? 1 : 0) || P.ext_cap != 960 || P.far_cap != 0 || P.cont_cap != (dp ? 960 : 0) ||
+        P.far_back != 48 || P.far_skip != (dp ? 0 : 64) || (fp && P.lazy)) { set_error(h, "internal: encoder parameters differ from the compiled-in ones"); return ZARC_GPU_E_PARAM; }
     uint64_t need = 0;
     for (size_t i = 0; i < n; i++) {
         if (src_off[i] % ZARC_GPU_ALIGN) { set_error(h, "entry offset not 16-byte aligned"); return ZARC_GPU_E_PARAM; }
@@ -652,7 +658,7 @@ int pack_device_impl(zarc_gpu_t *h, size_t n, const void *d_src_base, const uint
         const size_t n_units = units.size() / 2;
         if ((rc = upload_u32(h, h->d_units, units.data(), units.size()))) return rc;
         HOST_PHASE(2); // sub-batch lists + uploads
-        auto match_kernel = deep ? zarc_zge_match_deep : zarc_zge_match;
+        auto match_kernel = deep ? zarc_zge_match_deep : (P.level <= 1 ? zarc_zge_match_fast : zarc_zge_match);
 #ifdef ZARC_GPU_DIAG
         if (P.dbg) match_kernel = deep ? zarc_zge_match_deep_diag : zarc_zge_match_diag;
 #endif
@@ -900,7 +906,7 @@ int unpack_device_once(zarc_gpu_t *h, size_t n, const void *d_frames_base, const
         ZHIP(h->d_seqidx.reserve(nslots * 8));
         ZHIP(h->d_litidx.reserve(nslots * 8));
         ZHIP(h->d_ztables.reserve(nslots * (size_t)ZDEC_TABLE_CELLS * 2));
-        ZHIP(h->d_seqflag.reserve((nslots / 64 + (size_t)zarc_gpu::DEC_GROUPS + 2) * 4));
+        ZHIP(h->d_seqflag.reserve((nslots / 16 + (size_t)zarc_gpu::DEC_GROUPS + 2) * 4));
         ZHIP(hipMemsetAsync(h->d_zblocks.p, 0xFF, nslots * sizeof(ZdecBlock), h->stream));
         ZHIP(hipMemsetAsync(h->d_nseq.p, 0, nslots * 8, h->stream));
         hipLaunchKernelGGL(zarc_zdec_scan, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, h->stream, (const uint8_t *)d_frames_base, h->d_frame_off.as<uint64_t>(),
@@ -958,6 +964,10 @@ int unpack_device_once(zarc_gpu_t *h, size_t n, const void *d_frames_base, const
             const uint64_t g_seqs = seqidx[s1] - seqidx[s0], g_lits = litidx[s1] - litidx[s0];
             // the literal and the sequence kernels are independent and neither fills the chip: they run side by side
             hipStream_t sl = side ? sb : sa;
+            // the shared-table sequence kernel needs 25 KiB of LDS per wave: launched first it gets its place on every CU at once and the
+            // literal waves (9 KiB each) fill what is left; behind them it would wait for LDS (diagnostic switch: ZARC_GPU_LIT_FIRST)
+            const bool lit_first = diag_env("ZARC_GPU_LIT_FIRST", 0) != 0;
+            auto launch_literals = [&]() -> int {
             if (g_lits) {
                 ZHIP(hipEventRecord(ev[2], sl));
                 hipLaunchKernelGGL(zarc_zdec_literals, dim3((unsigned)((s1 - s0 + ZDEC_LIT_GROUP - 1) / ZDEC_LIT_GROUP)), dim3(64), 0, sl, (const uint8_t *)d_frames_base,
@@ -967,6 +977,8 @@ int unpack_device_once(zarc_gpu_t *h, size_t n, const void *d_frames_base, const
                 ZHIP(hipEventRecord(ev[3], sl));
                 have_lit_t[g] = true;
             }
+            return ZARC_GPU_OK; };
+            if (lit_first && (rc = launch_literals())) return rc;
             if (g_seqs) {
                 ZHIP(hipEventRecord(ev[0], sa));
                 // Each lane is a long serial chain (about one L2/HBM round trip and 340 instructions per sequence).  Partly filled
@@ -986,17 +998,21 @@ int unpack_device_once(zarc_gpu_t *h, size_t n, const void *d_frames_base, const
                     // Waves whose 64 blocks share their tables (the engine's own frames: one table set per group of eight blocks; libzstd's
                     // Repeat_Mode blocks) decode with the tables in LDS; the others raise their flag and are done by the second launch with a
                     // table set per block in HBM scratch, as before.
-                    const bool shared = seq_lanes == 64 && diag_env("ZARC_GPU_SEQ_SHARED", 1) != 0;
-                    const size_t waves = (size_t)((split - s0 + 63) / 64);
+                    const bool shared = diag_env("ZARC_GPU_SEQ_SHARED", 1) != 0;
+                    int sw = diag_env("ZARC_GPU_SEQ_WIDTH", 32); // block slots per workgroup of the shared-table kernel (measured at configs[1]: 64 -> 27.3 ms, 32 -> 23.7, 16 -> 27.3: tools/r4_ab4.sh)
+                    if (sw != 16 && sw != 32 && sw != 64) sw = 32;
+                    if (!shared) sw = seq_lanes;
+                    const size_t waves = (size_t)((split - s0 + (uint64_t)sw - 1) / (uint64_t)sw);
                     uint32_t *flags = nullptr;
                     if (shared) {
-                        flags = h->d_seqflag.as<uint32_t>() + (size_t)(s0 / 64) + (size_t)g; // (a group's slots need not start at a multiple of 64)
+                        flags = h->d_seqflag.as<uint32_t>() + (size_t)(s0 / 16) + (size_t)g; // (a group's slots need not start at a multiple of the width)
                         ZHIP(hipMemsetAsync(flags, 0, waves * 4, sa));
-                        hipLaunchKernelGGL(zarc_zdec_seqs_shared, dim3((unsigned)waves), dim3(64), 0, sa, (const uint8_t *)d_frames_base, h->d_frame_off.as<uint64_t>(),
+                        auto kern = sw == 64 ? zarc_zdec_seqs_shared : (sw == 32 ? zarc_zdec_seqs_shared32 : zarc_zdec_seqs_shared16);
+                        hipLaunchKernelGGL(kern, dim3((unsigned)waves), dim3(sw), 0, sa, (const uint8_t *)d_frames_base, h->d_frame_off.as<uint64_t>(),
                                            split, h->d_slot_prefix.as<uint64_t>(), h->d_zblocks.as<ZdecBlock>(), h->d_seqidx.as<uint64_t>(), h->d_seqs.as<uint64_t>(),
                                            h->d_fast.as<uint32_t>(), s0, flags);
                     }
-                    hipLaunchKernelGGL(zarc_zdec_seqs, dim3((unsigned)((split - s0 + seq_lanes - 1) / seq_lanes)), dim3(seq_lanes), 0, sa, (const uint8_t *)d_frames_base,
+                    hipLaunchKernelGGL(zarc_zdec_seqs, dim3((unsigned)waves), dim3(sw), 0, sa, (const uint8_t *)d_frames_base,
                                        h->d_frame_off.as<uint64_t>(), split, h->d_slot_prefix.as<uint64_t>(), h->d_zblocks.as<ZdecBlock>(), h->d_seqidx.as<uint64_t>(),
                                        h->d_seqs.as<uint64_t>(), h->d_ztables.as<uint16_t>(), h->d_fast.as<uint32_t>(), s0, (const uint32_t *)flags);
                 }
@@ -1005,6 +1021,7 @@ int unpack_device_once(zarc_gpu_t *h, size_t n, const void *d_frames_base, const
                 ZHIP(hipEventRecord(ev[1], sa));
                 have_seq_t[g] = true;
             }
+            if (!lit_first && (rc = launch_literals())) return rc;
             sa = sa_post; sb = sb_post;
             if (groups > 1) { ZHIP(hipEventRecord(ev[1], pa)); ZHIP(hipStreamWaitEvent(sa, ev[1], 0)); } // (re-recorded when the group has no sequences: it still orders the group behind the descriptors)
             if (g_lits && side) { ZHIP(hipEventRecord(ev[10], pb)); ZHIP(hipStreamWaitEvent(sa, ev[10], 0)); }
@@ -1142,6 +1159,13 @@ int unpack_device_once(zarc_gpu_t *h, size_t n, const void *d_frames_base, const
         size_t np = 0;
         for (int g = 0; g < groups; g++) np += pieces[g].size();
         fprintf(stderr, "zstd_decode: %zu of %zu frames on the fast path, %d group(s), %zu piece(s)\n", nf, n, groups, np);
+        if (h->d_seqflag.p) {
+            std::vector<uint32_t> wf(nslots / 16 + 1);
+            ZHIP(hipMemcpy(wf.data(), h->d_seqflag.p, wf.size() * 4, hipMemcpyDeviceToHost));
+            size_t nw = 0;
+            for (uint32_t v : wf) nw += v != 0;
+            fprintf(stderr, "zdec_seqs: %zu of %zu 64-slot waves workgroups turned down by the shared-table kernel (of at most that many; one group: exact)\n", nw, wf.size());
+        }
     }
     h->ms[ZARC_GPU_T_DECODE] = elapsed(h, e0, e1);
     // per-kernel times: sums over the groups (with several groups the kernels of different groups overlap, so the sums exceed T_DECODE)

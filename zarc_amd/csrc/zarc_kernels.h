@@ -138,6 +138,13 @@ __global__ void zarc_zdec_seqs(const uint8_t *frames_base, const uint64_t *frame
 __global__ void zarc_zdec_seqs_shared(const uint8_t *frames_base, const uint64_t *frame_off, uint64_t n_slots, const uint64_t *slot_prefix,
                                       ZdecBlock *zblocks, const uint64_t *seq_index, uint64_t *seqs, uint32_t *fast, uint64_t slot_base,
                                       uint32_t *wave_flag);
+// the same with 32 / 16 block slots per workgroup (a flag per workgroup; the launch of zarc_zdec_seqs behind it uses the same width)
+__global__ void zarc_zdec_seqs_shared32(const uint8_t *frames_base, const uint64_t *frame_off, uint64_t n_slots, const uint64_t *slot_prefix,
+                                        ZdecBlock *zblocks, const uint64_t *seq_index, uint64_t *seqs, uint32_t *fast, uint64_t slot_base,
+                                        uint32_t *wave_flag);
+__global__ void zarc_zdec_seqs_shared16(const uint8_t *frames_base, const uint64_t *frame_off, uint64_t n_slots, const uint64_t *slot_prefix,
+                                        ZdecBlock *zblocks, const uint64_t *seq_index, uint64_t *seqs, uint32_t *fast, uint64_t slot_base,
+                                        uint32_t *wave_flag);
 // status[i]: keeps decode errors; else CHECKSUM if the stored XXH64 differs; else DIGEST if expect differs
 __global__ void zarc_unpack_verdict(uint32_t n, const uint64_t *xxh, const uint32_t *stored_checksum, const uint32_t *digests,
                                     const uint32_t *expect /* may be null */, int32_t *status);
@@ -147,6 +154,10 @@ __global__ void zarc_corpus_fill(uint8_t *base, const uint64_t *off, const uint6
 __global__ void zarc_zge_match(ZgeParams P, const uint8_t *src_base, const uint64_t *src_off, const uint64_t *src_len,
                                const uint32_t *order, const uint32_t *units /* (queue slot, first block) per 2 MiB segment */, uint32_t n_units, const uint64_t *block_prefix, ZgeBlock *blocks,
                                uint64_t *seq_scratch, uint8_t *lit_scratch, uint32_t *queue, uint32_t *far_scratch);
+// the fast finder (level 1 and below): the same near table, no far table, no lazy step, no extension round
+__global__ void zarc_zge_match_fast(ZgeParams P, const uint8_t *src_base, const uint64_t *src_off, const uint64_t *src_len,
+                                    const uint32_t *order, const uint32_t *units, uint32_t n_units, const uint64_t *block_prefix, ZgeBlock *blocks,
+                                    uint64_t *seq_scratch, uint8_t *lit_scratch, uint32_t *queue, uint32_t *far_scratch);
 // the same with the ZARC_GPU_DBG switches (diagnostic build only)
 __global__ void zarc_zge_match_diag(ZgeParams P, const uint8_t *src_base, const uint64_t *src_off, const uint64_t *src_len,
                                const uint32_t *order, const uint32_t *units /* (queue slot, first block) per 2 MiB segment */, uint32_t n_units, const uint64_t *block_prefix, ZgeBlock *blocks,

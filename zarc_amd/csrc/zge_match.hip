@@ -1098,6 +1098,18 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
     zge_match_body<15, 5, 12, 16, 1, false, 5, 2, 64, 48, false, true, 4, 5, 0, false, 0, true>(L, P, src_base, src_off, src_len, order, units, n_units, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
 }
 
+// The fast finder (level 1 and the negative levels): the level-3 finder's 16-bit near table, follower runs and recent-offset guesses,
+// and nothing behind them -- no far table (no slab, no requests), no lazy step (P.lazy 0), no extension round.
+__global__ void __launch_bounds__(512, 4) zarc_zge_match_fast(ZgeParams P, const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off,
+                                                           const uint64_t *__restrict__ src_len, const uint32_t *__restrict__ order, const uint32_t *__restrict__ units, uint32_t n_units,
+                                                           const uint64_t *__restrict__ block_prefix, ZgeBlock *__restrict__ blocks,
+                                                           uint64_t *__restrict__ seq_scratch, uint8_t *__restrict__ lit_scratch, uint32_t *__restrict__ queue,
+                                                           uint32_t *__restrict__ far_scratch)
+{
+    __shared__ MatchLds<15, true> L;
+    zge_match_body<15, 5, 12, 0, 0, false, 0, 0, 0, 8, false, true, 0, 5, 0, false, 0, false>(L, P, src_base, src_off, src_len, order, units, n_units, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
+}
+
 #ifdef ZARC_GPU_DIAG
 // the same kernel with the ZARC_GPU_DBG switches (stage clocks, timing-only ablations): only in the diagnostic build of the
 // library (make DIAG=1 -> libzarc_gpu_diag.so, used by tools/); the product library has no such code

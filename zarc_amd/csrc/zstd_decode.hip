@@ -29,7 +29,7 @@
 namespace {
 
 constexpr int BLOCK_MAX = 128 * 1024;
-constexpr int ZDEC_SH_SETS = 10; // zarc_zdec_seqs_shared: tables per type a wave keeps in LDS
+ // zarc_zdec_seqs_shared: tables per type a wave keeps in LDS
 #ifdef ZARC_HIPEMU
 typedef const uint16_t *ZDEC_LDS_TAB;
 #else
@@ -1379,6 +1379,83 @@ __device__ __forceinline__ void seq_chain(bool ok, const uint8_t *__restrict__ s
     else *fast_f = 0; // the frame pass decodes this frame inline and reports whatever is wrong with it
 }
 
+// The same chain with ONE bitstream request per sequence (Bits128: the 16 bytes that end at the cursor, asked for at the top of the step
+// and in flight during the table lookups) instead of a refill -- a dependent load and a wait -- behind any of the nine bit fields: with
+// 64 blocks in lockstep every refill site is taken by some lane in every step, and a step then is six to nine memory round trips.  For
+// tables that cost no memory request (LDS).
+template <typename TAB>
+__device__ __forceinline__ void seq_chain128(bool ok, const uint8_t *__restrict__ src, const ZdecBlock &zb, const SeqHeader &own, const uint32_t end,
+                                          TAB tl, TAB to, TAB tm, const int al_l, const int al_o, const int al_m, uint64_t *__restrict__ outp,
+                                          ZdecBlock *__restrict__ zslot, uint32_t *__restrict__ fast_f)
+{
+    // repeat-offset history, symbolic: hv = offset (hr = 0) or hv = slot | delta << 2 of the history at block start (hr = 1)
+    uint32_t hv0 = 0, hv1 = 1, hv2 = 2, hr0 = 1, hr1 = 1, hr2 = 1;
+    uint32_t bpos_ = 0, reach_ = 0, msum_ = 0; // output position inside the block, farthest reach in front of it, sum of the match lengths
+    if (ok) {
+        Bits128 b;
+        ok = b.init(src + own.bits_off, end - own.bits_off);
+        uint32_t sl = 0, so = 0, sm = 0;
+        if (ok) { b.request(); b.settle(); sl = b.take((uint32_t)al_l); so = b.take((uint32_t)al_o); sm = b.take((uint32_t)al_m); ok = b.bitpos >= 0; } // <= 7 + 26 bits
+        for (uint32_t i = 0; i < zb.nseq && ok; i++) {
+            b.request(); // one bitstream window per sequence, in flight during the table lookups
+            const uint32_t cl = tl[sl], co = to[so], cm = tm[sm];
+            b.settle();
+            const uint32_t ofc = cell_sym(co), mlc = cell_sym(cm), llc = cell_sym(cl);
+            if (ofc > 27 || mlc > 52 || llc > 35) { ok = false; break; } // offsets past the format's largest window: left to the frame pass
+            const uint32_t ofv = (1u << ofc) + b.take(ofc);                // phase 1: <= 7 + 27 + 16 bits
+            uint32_t mbase, mbits, lbase, lbits;
+            ml_code_info(mlc, mbase, mbits);
+            ll_code_info(llc, lbase, lbits);
+            const uint32_t ml = mbase + b.take(mbits);
+            b.second_phase();                                              // phase 2: <= 16 + 9 + 9 + 8 bits
+            const uint32_t ll = lbase + b.take(lbits);
+            uint32_t ov, orf; // this sequence's offset, same symbolic form
+            if (ofv > 3) { ov = ofv - 3; orf = 0; hv2 = hv1; hr2 = hr1; hv1 = hv0; hr1 = hr0; hv0 = ov; hr0 = orf; }
+            else {
+                const uint32_t idx = ofv - 1 + (ll == 0 ? 1u : 0u);
+                if (idx == 0) { ov = hv0; orf = hr0; }
+                else {
+                    if (idx == 1) { ov = hv1; orf = hr1; }
+                    else if (idx == 2) { ov = hv2; orf = hr2; }
+                    else { // first history entry minus one
+                        ov = hv0; orf = hr0;
+                        if (orf) { if ((ov >> 2) >= ZDEC_MAX_DELTA) { ok = false; break; } ov += 4; } // delta + 1 (only absurd chains are left to the frame pass)
+                        else { if (ov <= 1) { ok = false; break; } ov -= 1; }
+                    }
+                    if (idx > 1) { hv2 = hv1; hr2 = hr1; }
+                    hv1 = hv0; hr1 = hr0;
+                    hv0 = ov; hr0 = orf;
+                }
+            }
+            // where this match's source starts, relative to the block: in front of it by `reach` bytes at most (an offset that still
+            // refers to the history at the block's start is not known here)
+            bpos_ += ll;
+            if (orf) reach_ = ZDEC_REACH_UNKNOWN; else if (ov > bpos_ && ov - bpos_ > reach_) reach_ = ov - bpos_;
+            bpos_ += ml; msum_ += ml;
+            // a plain store: eight steps fill a 64-byte line in L2 before it leaves for HBM.  (The non-temporal form of the HBM-table
+            // kernel -- which keeps its tables in L2 -- sends every 8-byte store of every lane to memory on its own, and the step's wait
+            // for the bitstream also waits for that store: 40.9 -> 26.6 ms at BASELINE configs[1].)
+            outp[i] = zge_pack_seq(ll | (orf ? ZDEC_LL_REF : 0u), ml, ov);
+            if (i + 1 < zb.nseq) {
+                sl = cell_base(cl, al_l) + b.take(cell_nbits(cl, al_l));
+                sm = cell_base(cm, al_m) + b.take(cell_nbits(cm, al_m));
+                so = cell_base(co, al_o) + b.take(cell_nbits(co, al_o));
+            }
+            if (b.bitpos < 0) ok = false;
+        }
+        if (ok && b.bitpos != 0) ok = false;
+    }
+    if (ok) {
+        zslot->rep[0] = hr0 ? (ZDEC_REP_REF | hv0) : hv0;
+        zslot->rep[1] = hr1 ? (ZDEC_REP_REF | hv1) : hv1;
+        zslot->rep[2] = hr2 ? (ZDEC_REP_REF | hv2) : hv2;
+        zslot->pad[0] = reach_;
+        zslot->pad[1] = zb.lit_len + msum_;
+        zslot->state = 1;
+    }
+    else *fast_f = 0; // the frame pass decodes this frame inline and reports whatever is wrong with it
+}
+
 // Where the table of type t of block slot s is described: the block's own header or, in Repeat mode, the nearest earlier block of the
 // frame that has sequences and sets this table.  *owner = the slot that describes it.
 __device__ bool seq_table_source(int t, const SeqHeader &own, const uint8_t *src, uint64_t s, uint32_t f, const uint64_t *__restrict__ slot_prefix,
@@ -1443,16 +1520,17 @@ __global__ void __launch_bounds__(64) zarc_zdec_seqs(const uint8_t *__restrict__
 // wave, six waves per CU), and the three lookups per sequence stop being 64-byte lines from 80 000 tables in HBM / MALL (178 GB per
 // launch at BASELINE configs[1], 11 x the whole path's algorithmic bytes).  A wave that needs more tables of some type than fit
 // sets wave_flag[its index] and leaves: the launch of zarc_zdec_seqs behind this one does its 64 slots the old way.
-__global__ void __launch_bounds__(64) zarc_zdec_seqs_shared(const uint8_t *__restrict__ frames_base, const uint64_t *__restrict__ frame_off, uint64_t n_slots,
-                                                            const uint64_t *__restrict__ slot_prefix, ZdecBlock *__restrict__ zblocks,
-                                                            const uint64_t *__restrict__ seq_index, uint64_t *__restrict__ seqs,
-                                                            uint32_t *__restrict__ fast, uint64_t slot_base, uint32_t *__restrict__ wave_flag)
+template <int LANES, int SETS>
+__device__ __forceinline__ void zdec_seqs_shared_body(const uint8_t *__restrict__ frames_base, const uint64_t *__restrict__ frame_off, uint64_t n_slots,
+                                                      const uint64_t *__restrict__ slot_prefix, ZdecBlock *__restrict__ zblocks,
+                                                      const uint64_t *__restrict__ seq_index, uint64_t *__restrict__ seqs,
+                                                      uint32_t *__restrict__ fast, uint64_t slot_base, uint32_t *__restrict__ wave_flag)
 {
-    __shared__ uint16_t T_ll[ZDEC_SH_SETS][512], T_ml[ZDEC_SH_SETS][512], T_of[ZDEC_SH_SETS][256];
-    __shared__ int32_t T_al[3][ZDEC_SH_SETS];
-    __shared__ uint32_t lead[3][ZDEC_SH_SETS];
+    __shared__ uint16_t T_ll[SETS][512], T_ml[SETS][512], T_of[SETS][256];
+    __shared__ int32_t T_al[3][SETS];
+    __shared__ uint32_t lead[3][SETS];
     const int lane = zd::lane_id();
-    const uint64_t s = slot_base + (uint64_t)blockIdx.x * 64 + (uint64_t)lane;
+    const uint64_t s = slot_base + (uint64_t)blockIdx.x * LANES + (uint64_t)lane;
     ZdecBlock zb;
     zb.type = 0xFFFFFFFFu; zb.nseq = 0; zb.frame = 0; zb.payload = 0; zb.size = 0; zb.seq_hdr = 0; zb.lit_len = 0;
     if (s < n_slots) zb = zblocks[s];
@@ -1483,19 +1561,19 @@ __global__ void __launch_bounds__(64) zarc_zdec_seqs_shared(const uint8_t *__res
             const uint32_t k = zd::readlane(key[t], first);
             const uint64_t m = zd::ballot(ok && key[t] == k);
             if (ok && key[t] == k) idx[t] = n;
-            if (n < (uint32_t)ZDEC_SH_SETS && lane == 0) lead[t][n] = first;
+            if (n < (uint32_t)SETS && lane == 0) lead[t][n] = first;
             n++;
             rem &= ~m;
         }
         most = n > most ? n : most;
-        if (lane == 0) for (uint32_t i = n; i < (uint32_t)ZDEC_SH_SETS; i++) lead[t][i] = 0xFFFFFFFFu;
+        if (lane == 0) for (uint32_t i = n; i < (uint32_t)SETS; i++) lead[t][i] = 0xFFFFFFFFu;
     }
-    if (most > (uint32_t)ZDEC_SH_SETS) { if (lane == 0) wave_flag[blockIdx.x] = 1; return; } // uniform: zarc_zdec_seqs takes these 64 slots
+    if (most > (uint32_t)SETS) { if (lane == 0) wave_flag[blockIdx.x] = 1; return; } // uniform: zarc_zdec_seqs takes these 64 slots
     zd::wave_sync();
     // build: lane L builds table L % SETS of type L / SETS from its first user's description (3 x SETS <= 64 lanes at once)
     {
-        static_assert(3 * ZDEC_SH_SETS <= 64, "one building lane per table");
-        const int bt = lane / ZDEC_SH_SETS, bn = lane % ZDEC_SH_SETS;
+        static_assert(3 * SETS <= LANES, "one building lane per table");
+        const int bt = lane / SETS, bn = lane % SETS;
         const uint32_t from = bt < 3 ? lead[bt][bn] : 0xFFFFFFFFu;
         const int fl = from == 0xFFFFFFFFu ? lane : (int)from;
         uint32_t bmode = 0, boff = 0, blen = 0;
@@ -1516,10 +1594,36 @@ __global__ void __launch_bounds__(64) zarc_zdec_seqs_shared(const uint8_t *__res
     int al_l = 0, al_o = 0, al_m = 0;
     if (ok) { al_l = T_al[0][idx[0]]; al_o = T_al[1][idx[1]]; al_m = T_al[2][idx[2]]; ok = al_l >= 0 && al_o >= 0 && al_m >= 0; }
     const uint32_t i0 = ok ? idx[0] : 0u, i1 = ok ? idx[1] : 0u, i2 = ok ? idx[2] : 0u;
-    seq_chain<ZDEC_LDS_TAB>(ok, src, zb, own, end, (ZDEC_LDS_TAB)&T_ll[i0][0], (ZDEC_LDS_TAB)&T_of[i1][0], (ZDEC_LDS_TAB)&T_ml[i2][0],
+    seq_chain128<ZDEC_LDS_TAB>(ok, src, zb, own, end, (ZDEC_LDS_TAB)&T_ll[i0][0], (ZDEC_LDS_TAB)&T_of[i1][0], (ZDEC_LDS_TAB)&T_ml[i2][0],
                             al_l, al_o, al_m, seqs + seq_index[s], zblocks + s, fast + f);
 }
 
+
+// Lanes per wave: the chain of a block is ~235 instructions and one bitstream round trip per sequence, and 80 000 blocks are 1 250 full
+// waves -- 1.2 per SIMD, nothing to overlap a wait with (SQ_WAIT_ANY 81 % of the wave-cycles).  Narrower workgroups put more waves on a
+// SIMD for the same blocks; their share of the tables shrinks with them (16 lanes = the blocks of two or three frames: 3 tables per type,
+// 7.5 KiB, 20 waves per CU).
+__global__ void __launch_bounds__(64) zarc_zdec_seqs_shared(const uint8_t *__restrict__ frames_base, const uint64_t *__restrict__ frame_off, uint64_t n_slots,
+                                                            const uint64_t *__restrict__ slot_prefix, ZdecBlock *__restrict__ zblocks,
+                                                            const uint64_t *__restrict__ seq_index, uint64_t *__restrict__ seqs,
+                                                            uint32_t *__restrict__ fast, uint64_t slot_base, uint32_t *__restrict__ wave_flag)
+{
+    zdec_seqs_shared_body<64, 10>(frames_base, frame_off, n_slots, slot_prefix, zblocks, seq_index, seqs, fast, slot_base, wave_flag);
+}
+__global__ void __launch_bounds__(32) zarc_zdec_seqs_shared32(const uint8_t *__restrict__ frames_base, const uint64_t *__restrict__ frame_off, uint64_t n_slots,
+                                                              const uint64_t *__restrict__ slot_prefix, ZdecBlock *__restrict__ zblocks,
+                                                              const uint64_t *__restrict__ seq_index, uint64_t *__restrict__ seqs,
+                                                              uint32_t *__restrict__ fast, uint64_t slot_base, uint32_t *__restrict__ wave_flag)
+{
+    zdec_seqs_shared_body<32, 5>(frames_base, frame_off, n_slots, slot_prefix, zblocks, seq_index, seqs, fast, slot_base, wave_flag);
+}
+__global__ void __launch_bounds__(16) zarc_zdec_seqs_shared16(const uint8_t *__restrict__ frames_base, const uint64_t *__restrict__ frame_off, uint64_t n_slots,
+                                                              const uint64_t *__restrict__ slot_prefix, ZdecBlock *__restrict__ zblocks,
+                                                              const uint64_t *__restrict__ seq_index, uint64_t *__restrict__ seqs,
+                                                              uint32_t *__restrict__ fast, uint64_t slot_base, uint32_t *__restrict__ wave_flag)
+{
+    zdec_seqs_shared_body<16, 3>(frames_base, frame_off, n_slots, slot_prefix, zblocks, seq_index, seqs, fast, slot_base, wave_flag);
+}
 
 // Stage 2, tables in LDS.  The lookups of zarc_zdec_seqs go to 80 000 different 2.5 KiB tables: every 2-byte lookup costs a
 // cache line from HBM / MALL (about 170 GB per launch on BASELINE configs[1]).  Here a workgroup is ONE wave with 16 active
