@@ -694,7 +694,10 @@ int pack_device_impl(zarc_gpu_t *h, size_t n, const void *d_src_base, const uint
             unsigned long long *const eprof = (P.dbg & 1024) ? (unsigned long long *)((char *)h->d_queue.p + 128) : (unsigned long long *)nullptr;
             if (bp[1] - bp[0] > 1) {
                 // the sub-batch holds frames of several blocks (the largest comes first): the entropy stage runs in two passes around the
-                // table plan, which lets the blocks of a group share their sequence tables (zge_entropy.hip: zarc_zge_plan)
+                // table plan, which lets the blocks of a group share their sequence tables (zge_entropy.hip: zarc_zge_plan).  (Pass 2 on
+                // its own is bound by LDS instruction issue -- 18.7 ms where its share of the one-pass kernel was 13.7 -- and neither running
+                // pass 1 of one half of the blocks beside pass 2 of the other nor moving the digest kernels beside pass 2 gave any of that
+                // back: tools/r4_ab5.sh, r4_ab7.sh, EXPERIMENTS.md.)
                 ZHIP(h->d_plan.reserve(nb * sizeof(ZgePlan)));
                 hipLaunchKernelGGL(zarc_zge_entropy_p1, dim3((unsigned)nb), dim3(64), 0, h->stream, (uint32_t)nb, slot, h->d_blocks.as<ZgeBlock>(),
                                    h->d_seq.as<uint64_t>(), h->d_lit.as<uint8_t>(), h->d_out.as<uint8_t>(), eprof, h->d_plan.as<ZgePlan>());
