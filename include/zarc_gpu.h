@@ -77,6 +77,11 @@ enum {
     ZARC_GPU_P_MIN_MATCH = 105,
     ZARC_GPU_P_TARGET_LENGTH = 106,
     ZARC_GPU_P_STRATEGY = 107,
+    ZARC_GPU_P_ENABLE_LDM = 160,
+    ZARC_GPU_P_LDM_HASH_LOG = 161,
+    ZARC_GPU_P_LDM_MIN_MATCH = 162,
+    ZARC_GPU_P_LDM_BUCKET_SIZE_LOG = 163,
+    ZARC_GPU_P_LDM_HASH_RATE_LOG = 164,
     ZARC_GPU_P_CONTENT_SIZE_FLAG = 200,
     ZARC_GPU_P_CHECKSUM_FLAG = 201,
     ZARC_GPU_P_DICT_ID_FLAG = 202,
@@ -95,12 +100,14 @@ enum {
                                         Ordinary (pageable) buffers are staged either way. */
 };
 /* What the engine does with the libzstd ids (pack.rs:86-217 forwards them all):
- *   CompressionLevel  -131072..22 accepted.  Levels <= 8 run the level-3 finder (one LDS table of 2^15 16-bit entries on a 5-byte
- *                     hash, candidates up to 64 KiB back; a 2^16-bucket far table in HBM on a 12-byte hash, content-sampled one
- *                     position in 16; one-byte lazy evaluation from level 2 on); levels >= 9 run the deep finder (two tagged LDS
- *                     tables, 4-byte short hash, 2-way far tables on both hashes, a parse that tries the live repeat offsets in
- *                     two more rounds per tile and looks two bytes ahead).  Levels 10..22 are NOT stronger than 9 and
- *                     negative levels are NOT faster than 1: there are exactly these two finders.
+ *   CompressionLevel  -131072..22 accepted; four finders (zarc_gpu_level_finder says which one a level runs):
+ *                     <= 1 (level 1 and the negative levels): the FAST finder -- one LDS table of 2^15 16-bit entries on a 5-byte hash,
+ *                     candidates up to 64 KiB back, recent-offset guesses; no far table, no lazy step;
+ *                     2..8 (0 = default = 3): the level-3 finder -- the same table plus a 2^16-bucket far table in HBM on a 12-byte hash,
+ *                     content-sampled one position in 16, one-byte lazy evaluation, long matches continued in an extension round;
+ *                     9..14: the deep finder -- two tagged LDS tables, 4-byte short hash, 2-way far tables on both hashes, a parse that
+ *                     tries the live repeat offsets in two more rounds per tile and looks two bytes ahead;
+ *                     15..22: the deep finder with four such rounds.  Levels inside one tier give identical frames.
  *   WindowLog         honoured for the frame header / the farthest offset (10..27; default 21, level >= 9: 22).
  *   MinMatch          4..7 honoured (3 is raised to 4); default 5, level >= 9: 4.
  *   HashLog, ChainLog, SearchLog, TargetLength, Strategy
@@ -108,7 +115,11 @@ enum {
  *                     zarc_gpu_get_params, and ADVISORY: table sizes and the search are fixed by the kernels, so the frames are the
  *                     level's frames whatever these say (libzstd would search harder or less hard; the frames are valid either way).
  *   ContentSizeFlag   only 1.  ChecksumFlag honoured.  DictIdFlag accepted (zarc has no dictionaries).
- *   LDM (160-164), NbWorkers / JobSize / OverlapLog (400-402), experimental ids: ZARC_GPU_E_UNSUPPORTED. */
+ *   EnableLongDistanceMatching, LdmHashLog, LdmMinMatch, LdmBucketSizeLog, LdmHashRateLog (160-164)
+ *                     accepted inside libzstd's bounds and ADVISORY as well: the far tables of the finders are the engine's long-distance
+ *                     matcher at every level above 1, whatever these say.
+ *   NbWorkers / JobSize / OverlapLog (400-402), experimental ids: ZARC_GPU_E_UNSUPPORTED.
+ * zarc_gpu_parameter_advisory(id) tells a caller (the CLI prints a warning) that an id is accepted but changes nothing. */
 
 typedef struct {
     int level;             /* 0 => default 3 (encode.rs:62 init(0))                                  */
@@ -140,6 +151,12 @@ const char *zarc_gpu_error_name(int code);         /* call-level codes (negative
 const char *zarc_gpu_frame_status_name(int status); /* per-frame status (>= 0)     */
 const char *zarc_gpu_last_error(const zarc_gpu_t *h);
 int zarc_gpu_abi_version(void);
+/* The level whose finder `level` runs: 1 (level <= 1), 3 (2..8 and 0), 9 (9..14) or 15 (15..22).  `zarc pack --level 19` warns that it packs
+ * with the level-15 finder (zarc-cli/src/pack.rs:24-33 accepts -131072..22 and libzstd has a parameter set for each). */
+int zarc_gpu_level_finder(int level);
+/* 1 = the parameter id is accepted and remembered but ADVISORY (search-effort and long-distance-matching hints, pack.rs:86-217): the
+ * frames are the level's frames whatever its value.  0 = honoured, or not accepted at all. */
+int zarc_gpu_parameter_advisory(int id);
 
 /* ---- pack: BLAKE3 + Zstandard frame encode (+ XXH64) ------------------------------------------- */
 /* Host-memory form (mirrors add_data_frame's `&[u8]` input).  For every entry i the engine writes one

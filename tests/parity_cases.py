@@ -231,6 +231,17 @@ def check_params(engine):
         assert ei.value.code == _lib.E_PARAM
         engine.set_parameter(pid, 0)      # back to "use the default"
         assert getattr(engine.params(), field) == 0
+    # long-distance matching: accepted inside libzstd's bounds, advisory (the far tables are the engine's long-distance matcher)
+    for pid, good, bad in ((_lib.P_ENABLE_LDM, 1, 3), (_lib.P_LDM_HASH_LOG, 20, 31), (_lib.P_LDM_MIN_MATCH, 64, 3), (_lib.P_LDM_BUCKET_SIZE_LOG, 3, 9),
+                           (_lib.P_LDM_HASH_RATE_LOG, 7, 26)):
+        engine.set_parameter(pid, good)
+        assert engine.lib.zarc_gpu_parameter_advisory(pid) == 1
+        with pytest.raises(ZarcGpuError) as ei:
+            engine.set_parameter(pid, bad)
+        assert ei.value.code == _lib.E_PARAM
+        engine.set_parameter(pid, 0)
+    assert engine.lib.zarc_gpu_parameter_advisory(_lib.P_STRATEGY) == 1 and engine.lib.zarc_gpu_parameter_advisory(_lib.P_WINDOW_LOG) == 0
+    assert [engine.lib.zarc_gpu_level_finder(l) for l in (-131072, -1, 0, 1, 2, 3, 8, 9, 14, 15, 22)] == [1, 1, 3, 1, 3, 3, 3, 9, 9, 15, 15]
     with pytest.raises(ZarcGpuError):
         engine.set_parameter(31337, 1)    # unknown id
     assert engine.params().checksum_flag == 1

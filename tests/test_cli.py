@@ -139,6 +139,22 @@ def run_cli(binary, tmp_path, corpus, oracle, libzstds, store=False, gpus=0, env
             assert (dest2 / "src" / name).read_bytes() == data, name
         many = subprocess.run([binary, "unpack", str(arc2), "--gpus", "63"], cwd=dest2, capture_output=True, timeout=600, env=env)
         assert many.returncode == 1 and b"--gpus 63" in many.stderr             # more than the box has: a clean error, not a crash
+    # --- levels and hints the engine maps or ignores say so once (the reference forwards them all to libzstd, pack.rs:24-33, 86-217) ---
+    if not store:
+        w = subprocess.run([binary, "pack", "--output", str(tmp_path / "w.zarc"), "--level", "19", "--zstd", "Strategy=btopt", "--zstd", "EnableLongDistanceMatching=true",
+                            "--zstd", "WindowLog=20", "src"], cwd=tmp_path, capture_output=True, timeout=900, env=env)
+        assert w.returncode == 0, w.stderr[-500:]
+        assert b"warning: --level 19 packs with the engine's level-15 finder" in w.stderr
+        assert w.stderr.count(b"is accepted but advisory") == 2                 # Strategy and EnableLongDistanceMatching, not WindowLog
+        q = subprocess.run([binary, "pack", "--output", str(tmp_path / "q.zarc"), "--level", "3", "src"], cwd=tmp_path, capture_output=True, timeout=900, env=env)
+        assert q.returncode == 0 and b"warning" not in q.stderr
+        f = subprocess.run([binary, "pack", "--output", str(tmp_path / "f.zarc"), "--level=-5", "src"], cwd=tmp_path, capture_output=True, timeout=900, env=env)
+        assert f.returncode == 0 and b"level-1 finder" in f.stderr, f.stderr[-300:]
+        dest3 = tmp_path / "dest-f"
+        dest3.mkdir()
+        subprocess.run([binary, "unpack", str(tmp_path / "f.zarc")], cwd=dest3, capture_output=True, timeout=900, check=True, env=env)
+        for name, data in files.items():
+            assert (dest3 / "src" / name).read_bytes() == data, name
     # --- errors inside the pipeline end in "Error: ..." and exit code 1, never in an abort (reader / writer threads are joined) ---
     if os.path.exists("/dev/full"):
         full = subprocess.run([binary, "pack", "--output", "/dev/full", "src"], cwd=tmp_path, capture_output=True, timeout=900, env=env)

@@ -21,6 +21,7 @@ OK, E_DEVICE, E_NOMEM, E_PARAM, E_UNSUPPORTED, E_DSTSIZE = 0, -1, -2, -3, -4, -5
 FRAME_OK, FRAME_CORRUPT, FRAME_CHECKSUM, FRAME_DIGEST, FRAME_DSTSIZE, FRAME_BAD_MAGIC, FRAME_UNSUPPORTED, FRAME_SRCSIZE, FRAME_DUPLICATE = range(9)
 # parameter ids (ZSTD_cParameter values, what zstd_safe::CParameter maps to)
 P_COMPRESSION_LEVEL, P_WINDOW_LOG, P_HASH_LOG, P_CHAIN_LOG, P_SEARCH_LOG, P_MIN_MATCH, P_TARGET_LENGTH, P_STRATEGY = 100, 101, 102, 103, 104, 105, 106, 107
+P_ENABLE_LDM, P_LDM_HASH_LOG, P_LDM_MIN_MATCH, P_LDM_BUCKET_SIZE_LOG, P_LDM_HASH_RATE_LOG = 160, 161, 162, 163, 164
 P_CONTENT_SIZE_FLAG, P_CHECKSUM_FLAG, P_DICT_ID_FLAG = 200, 201, 202
 # engine tuning (batching only; frames are identical for every value)
 PX_SCRATCH_MB, PX_STAGE_CHUNK, PX_STAGE_THREAD, PX_COPY_THREADS, PX_DEC_GROUPS, PX_ZERO_COPY = 9001, 9002, 9003, 9004, 9005, 9006
@@ -28,7 +29,7 @@ PX_SCRATCH_MB, PX_STAGE_CHUNK, PX_STAGE_THREAD, PX_COPY_THREADS, PX_DEC_GROUPS, 
 T_BLAKE3, T_XXH64, T_MATCH, T_ENTROPY, T_ASSEMBLE, T_DECODE, T_TOTAL, T_DEC_SEQS, T_DEC_LITS, T_DEC_FRAMES = range(10)
 
 EXPORTS = [
-    "zarc_gpu_abi_version", "zarc_gpu_device_count", "zarc_gpu_create", "zarc_gpu_destroy", "zarc_gpu_set_parameter", "zarc_gpu_get_params",
+    "zarc_gpu_abi_version", "zarc_gpu_level_finder", "zarc_gpu_parameter_advisory", "zarc_gpu_device_count", "zarc_gpu_create", "zarc_gpu_destroy", "zarc_gpu_set_parameter", "zarc_gpu_get_params",
     "zarc_gpu_enable_compression", "zarc_gpu_bound", "zarc_gpu_error_name", "zarc_gpu_frame_status_name", "zarc_gpu_last_error",
     "zarc_gpu_pack_batch", "zarc_gpu_pack_batch_device", "zarc_gpu_pack_batch_dedup", "zarc_gpu_pack_batch_device_dedup", "zarc_gpu_unpack_batch", "zarc_gpu_unpack_batch_device",
     "zarc_gpu_blake3_batch", "zarc_gpu_blake3_batch_device", "zarc_gpu_xxh64_batch_device", "zarc_gpu_last_kernel_ms",
@@ -66,6 +67,8 @@ def load(path=None):
     if got != ABI_VERSION:  # checked BEFORE the newer symbols are resolved: a stale library fails here, by version, not at a symbol lookup
         raise OSError("%s has ABI version %d, this binding needs %d -- rebuild it (make -C zarc_amd/csrc)" % (path, got, ABI_VERSION))
     lib.zarc_gpu_device_count.restype = c.c_int
+    lib.zarc_gpu_level_finder.argtypes = [c.c_int]
+    lib.zarc_gpu_parameter_advisory.argtypes = [c.c_int]
     lib.zarc_gpu_create.argtypes = [c.POINTER(vp), c.c_int]
     lib.zarc_gpu_destroy.argtypes = [vp]
     lib.zarc_gpu_destroy.restype = None

@@ -91,6 +91,7 @@ struct zarc_gpu {
     int copy_threads = 8;      // ZARC_GPU_PX_COPY_THREADS
     uint8_t *meta_pin = nullptr; // page-locked arena for descriptor uploads (meta_take)
     size_t meta_cap = 0, meta_used = 0;
+    int ldm[5] = {0, 0, 0, 0, 0}; // EnableLongDistanceMatching, LdmHashLog, LdmMinMatch, LdmBucketSizeLog, LdmHashRateLog: remembered, advisory
     int zero_copy = 4096;      // ZARC_GPU_PX_ZERO_COPY: page-locked caller memory in runs of this many KiB on average is read / written by the DMA engines directly (0 = never)
 };
 
@@ -155,6 +156,9 @@ ZgeParams derive_params(const zarc_gpu_params &p)
     if (deep && level >= 15) z.rep_pass = 4; // levels 15 .. 22: two more rounds of the live recent-offset pass (a run-time count: the same kernel)
     if (level <= 1) { // level 1 and the negative levels: the fast finder (zarc_zge_match_fast) -- the near table alone, no lazy step, no extension round
         z.far_log = 0; z.rep_pass = 0; z.lazy = 0;
+#if defined(ZGE_EXP) && ZGE_EXP == 3
+        z.lazy = 1; // timing experiment: what the lazy step costs the fast finder
+#endif
     }
     z.dbg = diag_env("ZARC_GPU_DBG", 0); // timing-only ablations (outputs invalid when set): diagnostic build only
     return z;
@@ -411,14 +415,37 @@ int zarc_gpu_set_parameter(zarc_gpu_t *h, int id, int value)
         return ZARC_GPU_OK;
     case ZARC_GPU_P_CHECKSUM_FLAG: h->params.checksum_flag = value ? 1 : 0; return ZARC_GPU_OK;
     case ZARC_GPU_P_DICT_ID_FLAG: return ZARC_GPU_OK; // no dictionaries in zarc
+    // Long-distance matching (pack.rs:89-109 forwards these; libzstd accepts them single-threaded): accepted inside libzstd's bounds and
+    // ADVISORY like the search-effort hints -- the finders' far tables in HBM ARE a long-distance matcher, at every level above 1
+    case ZARC_GPU_P_ENABLE_LDM: if (value < 0 || value > 2) return ZARC_GPU_E_PARAM; h->ldm[0] = value; return ZARC_GPU_OK;
+    case ZARC_GPU_P_LDM_HASH_LOG: if (value != 0 && (value < 6 || value > 30)) return ZARC_GPU_E_PARAM; h->ldm[1] = value; return ZARC_GPU_OK;
+    case ZARC_GPU_P_LDM_MIN_MATCH: if (value != 0 && (value < 4 || value > 4096)) return ZARC_GPU_E_PARAM; h->ldm[2] = value; return ZARC_GPU_OK;
+    case ZARC_GPU_P_LDM_BUCKET_SIZE_LOG: if (value != 0 && (value < 1 || value > 8)) return ZARC_GPU_E_PARAM; h->ldm[3] = value; return ZARC_GPU_OK;
+    case ZARC_GPU_P_LDM_HASH_RATE_LOG: if (value < 0 || value > 25) return ZARC_GPU_E_PARAM; h->ldm[4] = value; return ZARC_GPU_OK;
     default:
-        // long-distance matching (160-164), nbWorkers/jobSize/overlapLog (400-402) and the experimental ids
-        if ((id >= 160 && id <= 164) || (id >= 400 && id <= 402) || (id >= 500 && id <= 1020)) return ZARC_GPU_E_UNSUPPORTED;
+        // nbWorkers/jobSize/overlapLog (400-402) and the experimental ids
+        if ((id >= 400 && id <= 402) || (id >= 500 && id <= 1020)) return ZARC_GPU_E_UNSUPPORTED;
         return ZARC_GPU_E_PARAM;
     }
 }
 
 void zarc_gpu_get_params(const zarc_gpu_t *h, zarc_gpu_params *out) { if (h && out) *out = h->params; }
+
+int zarc_gpu_level_finder(int level)
+{
+    if (level == 0) level = 3; // encode.rs:62: init(0) = the default level
+    return level <= 1 ? 1 : (level < 9 ? 3 : (level < 15 ? 9 : 15));
+}
+
+int zarc_gpu_parameter_advisory(int id)
+{
+    switch (id) {
+    case ZARC_GPU_P_HASH_LOG: case ZARC_GPU_P_CHAIN_LOG: case ZARC_GPU_P_SEARCH_LOG: case ZARC_GPU_P_TARGET_LENGTH: case ZARC_GPU_P_STRATEGY:
+    case ZARC_GPU_P_ENABLE_LDM: case ZARC_GPU_P_LDM_HASH_LOG: case ZARC_GPU_P_LDM_MIN_MATCH: case ZARC_GPU_P_LDM_BUCKET_SIZE_LOG: case ZARC_GPU_P_LDM_HASH_RATE_LOG:
+        return 1;
+    default: return 0;
+    }
+}
 void zarc_gpu_enable_compression(zarc_gpu_t *h, int compress) { if (h) h->params.compress = compress ? 1 : 0; }
 
 size_t zarc_gpu_bound(size_t n)
@@ -527,7 +554,11 @@ int pack_device_impl(zarc_gpu_t *h, size_t n, const void *d_src_base, const uint
         P.far_step_log != (dp ? 1 : 5) || P.far_res_log != (dp ? 0 : 2) || (P.far_short != 0) != dp || P.long_log != 13 ||
         P.near16 != (dp ? 0 : 1) || P.short_log != (dp ? 13 : 15) || P.far_cdc_log != (dp ? 0 : 4) || P.lazy2_delta != (dp ? 5 : 0) ||
         P.rep_pass != (dp ? (P.level >= 15 ? 4 : 2) : (fp ? 0 : 1)) || P.live_reps != (dp ? 1 : 0) || P.ext_cap != 960 || P.far_cap != 0 || P.cont_cap != (dp ? 960 : 0) ||
-        P.far_back != 48 || P.far_skip != (dp ? 0 : 64) || (fp && P.lazy)) { set_error(h, "internal: encoder parameters differ from the compiled-in ones"); return ZARC_GPU_E_PARAM; }
+        P.far_back != 48 || P.far_skip != (dp ? 0 : 64)
+#if !defined(ZGE_EXP)
+        || (fp && P.lazy)
+#endif
+        ) { set_error(h, "internal: encoder parameters differ from the compiled-in ones"); return ZARC_GPU_E_PARAM; }
     uint64_t need = 0;
     for (size_t i = 0; i < n; i++) {
         if (src_off[i] % ZARC_GPU_ALIGN) { set_error(h, "entry offset not 16-byte aligned"); return ZARC_GPU_E_PARAM; }

@@ -321,6 +321,7 @@ int cmd_pack(const std::vector<std::string> &a)
     for (size_t i = 0; i < a.size(); i++) {
         if (a[i] == "--output" && i + 1 < a.size()) output = a[++i];
         else if (a[i] == "--level" && i + 1 < a.size()) { level = std::atoi(a[++i].c_str()); have_level = true; }
+        else if (a[i].rfind("--level=", 0) == 0) { level = std::atoi(a[i].c_str() + 8); have_level = true; }
         else if (a[i] == "--zstd" && i + 1 < a.size()) { ZstdParam p; if (!parse_zstd_param(a[++i], &p)) { std::fprintf(stderr, "error: invalid --zstd value\n"); return 2; } params.push_back(p); }
         else if (a[i] == "--store") store = true;
         else if (a[i] == "-L" || a[i] == "--follow-symlinks") follow = true;
@@ -338,6 +339,17 @@ int cmd_pack(const std::vector<std::string> &a)
     enc.set_zstd_parameter(ZARC_GPU_P_CHECKSUM_FLAG, 1); // pack.rs:227
     if (have_level) enc.set_zstd_parameter(ZARC_GPU_P_COMPRESSION_LEVEL, level);
     for (const auto &p : params) enc.set_zstd_parameter(p.id, p.value);
+    // What the engine does differently from libzstd with these is said once, on stderr and in the log: a level runs its tier's finder, the
+    // search-effort and long-distance-matching hints are accepted (the reference forwards them all, pack.rs:86-217) but change nothing.
+    if (have_level && level != 0 && zarc_gpu_level_finder(level) != level) {
+        std::fprintf(stderr, "warning: --level %d packs with the engine's level-%d finder (tiers: <= 1, 2..8, 9..14, 15..22)\n", level, zarc_gpu_level_finder(level));
+        LOGF(1, "level mapped to a finder tier", "level=%d finder=%d", level, zarc_gpu_level_finder(level));
+    }
+    for (const auto &p : params)
+        if (zarc_gpu_parameter_advisory(p.id)) {
+            std::fprintf(stderr, "warning: --zstd parameter %d=%d is accepted but advisory on this engine: the frames are the level's frames\n", p.id, p.value);
+            LOGF(1, "advisory zstd parameter", "id=%d value=%d", p.id, p.value);
+        }
     if (store) enc.enable_compression(false);
 
     std::vector<Walked> entries;
