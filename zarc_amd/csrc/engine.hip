@@ -1032,7 +1032,9 @@ int unpack_device_once(zarc_gpu_t *h, size_t n, const void *d_frames_base, const
                     // Waves whose 64 blocks share their tables (the engine's own frames: one table set per group of eight blocks; libzstd's
                     // Repeat_Mode blocks) decode with the tables in LDS; the others raise their flag and are done by the second launch with a
                     // table set per block in HBM scratch, as before.
-                    const bool shared = diag_env("ZARC_GPU_SEQ_SHARED", 1) != 0;
+                    // (a batch of small frames -- fewer than four blocks per frame on average -- has nothing to share: a workgroup's 32 blocks
+                    // would belong to a dozen frames with a dozen table sets, and every workgroup would hand its blocks on after looking)
+                    const bool shared = diag_env("ZARC_GPU_SEQ_SHARED", 1) != 0 && (s1 - s0) >= 4 * (uint64_t)ng;
                     int sw = diag_env("ZARC_GPU_SEQ_WIDTH", 32); // block slots per workgroup of the shared-table kernel (measured at configs[1]: 64 -> 27.3 ms, 32 -> 23.7, 16 -> 27.3: tools/r4_ab4.sh)
                     if (sw != 16 && sw != 32 && sw != 64) sw = 32;
                     if (!shared) sw = seq_lanes;

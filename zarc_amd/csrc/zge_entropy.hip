@@ -120,10 +120,10 @@ struct EntLds {
         struct {
             uint16_t st[1280];     // state tables: LL at 0, ML at 512, OF at 1024 (one array: the chains index it with the table's start folded into the symbol constant)
             int32_t dnb_ll[36], dfs_ll[36], dnb_ml[53], dfs_ml[53], dnb_of[32], dfs_of[32];
+            int16_t norm[3][64];   // (8-byte aligned: once the tables are built, the chains keep the states before their steps here, four to a 64-bit store)
             uint32_t cl[36], co[32], cm[53];
-            int16_t norm[3][64];
             uint8_t desc[3][80];
-            uint64_t pre[3][64];   // LL / OF / ML of the current 64 sequences: in {dnb, dfs} of the symbol, out {dnb, state before the step}
+            uint64_t pre[3][64];   // LL / OF / ML of the current 64 sequences: {dnb, byte offset of dfs in st[]} of each sequence's symbol
         } s;
     };
 };
@@ -1020,6 +1020,12 @@ __device__ __forceinline__ void zge_entropy_body(EntLds &L, uint32_t n_blocks, u
                         // the bits each step emits follow from (state before, symbol constant) and are worked out by all lanes below.
                         // Four steps per trip: their symbol constants are fetched together and the loop bookkeeping is paid once.
                         uint64_t *const pp = L.s.pre[lane];
+                        // the state each step starts from goes to sbp[] (the normalised counts are dead once the tables are built): four
+                        // steps' states in ONE 64-bit store -- the stage is bound by LDS instruction issue, and a store per step was a
+                        // third of the chain's LDS instructions
+                        typedef uint16_t __attribute__((may_alias)) u16a;
+                        typedef uint64_t __attribute__((may_alias)) u64a;
+                        u16a *const sbp = (u16a *)&L.s.norm[0][0] + 64 * lane;
                         uint32_t e = 0;
                         if (done == 0) { // first symbol coded: the state that needs no bits (fse_init_state)
                             const uint64_t c0 = pp[0];
@@ -1029,15 +1035,20 @@ __device__ __forceinline__ void zge_entropy_body(EntLds &L, uint32_t n_blocks, u
                             state = *(const uint16_t *)((const uint8_t *)L.s.st + (2 * (value >> nb0) + f));
                             e = 1;
                         }
-#define CHAIN_STEP(cur, at) do { ((uint32_t *)&pp[at])[1] = state; /* the state this step starts from, in place of dfs */ \
-                                 const uint32_t nb_ = (state + (uint32_t)(cur)) >> 16;                                     \
-                                 state = *(const uint16_t *)((const uint8_t *)L.s.st + ((int)((state >> nb_) << 1) + (int32_t)(uint32_t)((cur) >> 32))); } while (0)
+#define CHAIN_NEXT(cur) do { const uint32_t nb_ = (state + (uint32_t)(cur)) >> 16;                                     \
+                             state = *(const uint16_t *)((const uint8_t *)L.s.st + ((int)((state >> nb_) << 1) + (int32_t)(uint32_t)((cur) >> 32))); } while (0)
+                        for (; (e & 3u) && e < cnt; e++) { const uint64_t c0 = pp[e]; sbp[e] = (uint16_t)state; CHAIN_NEXT(c0); }
                         for (; e + 4 <= cnt; e += 4) {
                             const uint64_t c0 = pp[e], c1 = pp[e + 1], c2 = pp[e + 2], c3 = pp[e + 3];
-                            CHAIN_STEP(c0, e); CHAIN_STEP(c1, e + 1); CHAIN_STEP(c2, e + 2); CHAIN_STEP(c3, e + 3);
+                            uint64_t four = state;
+                            CHAIN_NEXT(c0); four |= (uint64_t)state << 16;
+                            CHAIN_NEXT(c1); four |= (uint64_t)state << 32;
+                            CHAIN_NEXT(c2); four |= (uint64_t)state << 48;
+                            CHAIN_NEXT(c3);
+                            *(u64a *)(sbp + e) = four; // states are below 2^11 (table size 2^9 at most, states T .. 2T - 1)
                         }
-                        for (; e < cnt; e++) { const uint64_t c0 = pp[e]; CHAIN_STEP(c0, e); }
-#undef CHAIN_STEP
+                        for (; e < cnt; e++) { const uint64_t c0 = pp[e]; sbp[e] = (uint16_t)state; CHAIN_NEXT(c0); }
+#undef CHAIN_NEXT
                     }
                     zd::wave_sync();
                     uint64_t lo = 0;
@@ -1048,9 +1059,9 @@ __device__ __forceinline__ void zge_entropy_body(EntLds &L, uint32_t n_blocks, u
                         uint32_t bo = 0, bm = 0, bl = 0;
                         const bool first = done + (uint32_t)lane == 0;
                         if (!first) {
-                            if (mode_o != 1) { const uint64_t c = L.s.pre[1][lane]; const uint32_t sb = (uint32_t)(c >> 32), n_ = (sb + (uint32_t)c) >> 16; bo = (sb & ((1u << n_) - 1)) | (n_ << 16); }
-                            if (mode_m != 1) { const uint64_t c = L.s.pre[2][lane]; const uint32_t sb = (uint32_t)(c >> 32), n_ = (sb + (uint32_t)c) >> 16; bm = (sb & ((1u << n_) - 1)) | (n_ << 16); }
-                            if (mode_l != 1) { const uint64_t c = L.s.pre[0][lane]; const uint32_t sb = (uint32_t)(c >> 32), n_ = (sb + (uint32_t)c) >> 16; bl = (sb & ((1u << n_) - 1)) | (n_ << 16); }
+                            if (mode_o != 1) { const uint32_t c = (uint32_t)L.s.pre[1][lane], sb = ((const uint16_t __attribute__((may_alias)) *)&L.s.norm[0][0])[1 * 64 + lane], n_ = (sb + c) >> 16; bo = (sb & ((1u << n_) - 1)) | (n_ << 16); }
+                            if (mode_m != 1) { const uint32_t c = (uint32_t)L.s.pre[2][lane], sb = ((const uint16_t __attribute__((may_alias)) *)&L.s.norm[0][0])[2 * 64 + lane], n_ = (sb + c) >> 16; bm = (sb & ((1u << n_) - 1)) | (n_ << 16); }
+                            if (mode_l != 1) { const uint32_t c = (uint32_t)L.s.pre[0][lane], sb = ((const uint16_t __attribute__((may_alias)) *)&L.s.norm[0][0])[0 * 64 + lane], n_ = (sb + c) >> 16; bl = (sb & ((1u << n_) - 1)) | (n_ << 16); }
                         }
                         // order: OF state bits, ML state bits, LL state bits, LL extra, ML extra, OF extra
                         uint64_t acc = bo & 0xFFFF; uint32_t sh = bo >> 16;
