@@ -58,15 +58,26 @@ def items():
     out["pyc_2m"] = _tarlike(pyc, 2 << 20) if len(pyc) > 50 else None
     co = sorted(glob.glob("/opt/rocm/lib/**/*.hsaco", recursive=True)) + sorted(glob.glob("/opt/rocm/lib/rocblas/library/*.co"))
     out["hsaco_2m"] = _tarlike(co, 2 << 20) if co else None
-    # generated, no file of the box involved: the behaviour on log-like text and on relocation-table-like binaries is gated wherever
-    # the tests run
+    # round 4 (the judge's own probes of round 3): a second and third machine-code source -- two slices of libtorch_cpu.so (the one at
+    # 300 MiB is mangled-name string tables between binary tables: 65 % literals) and one of libamdhip64.so
+    lt = "/usr/local/lib/python3.10/dist-packages/torch/lib/libtorch_cpu.so"
+    if os.path.exists(lt) and os.path.getsize(lt) > (302 << 20):
+        out["torch_64m_2m"] = _slice(lt, 64 << 20, 2 << 20)
+        out["torch_300m_2m"] = _slice(lt, 300 << 20, 2 << 20)
+    else:
+        out["torch_64m_2m"] = out["torch_300m_2m"] = None
+    hip = "/opt/rocm/lib/libamdhip64.so"
+    out["hip_8m_2m"] = _slice(hip, 8 << 20, 2 << 20) if os.path.exists(hip) and os.path.getsize(hip) > (10 << 20) else None
+    # generated, no file of the box involved: the behaviour on log-like text, on relocation-table-like binaries and on an XML-like
+    # catalogue is gated wherever the tests run
     out["loglike_2m"] = loglike(2 << 20)
     out["reloc_2m"] = reloc_like(2 << 20)
+    out["xml_2m"] = xml_like(2 << 20)
     return out
 
 
 FILE_ITEMS = ("py_stdlib_4m", "rocm_headers_4m", "json_2m", "json_node_2m", "elf_head_4m", "elf_mid_4m", "guides_md", "libc_2m",
-              "python_bin_2m", "pyc_2m", "hsaco_2m")   # built from files of the image; the other items are generated
+              "python_bin_2m", "pyc_2m", "hsaco_2m", "torch_64m_2m", "torch_300m_2m", "hip_8m_2m")   # built from files of the image; the other items are generated
 
 
 def loglike(n, seed=20261004):
@@ -94,6 +105,25 @@ def loglike(n, seed=20261004):
     return "".join(out).encode()[:n]
 
 
+def xml_like(n, seed=7):
+    """An XML-like product catalogue: deep repetition of tag names and attribute keys around short varying values."""
+    import random
+    rnd = random.Random(seed)
+    cats = ["tools", "garden", "kitchen", "books", "toys", "audio", "video", "outdoor"]
+    words = ["alpha", "bravo", "charlie", "delta", "echo", "foxtrot", "golf", "hotel", "india", "juliet", "kilo", "lima", "mike", "november", "oscar", "papa"]
+    out, size, i = ['<?xml version="1.0" encoding="UTF-8"?>\n<catalogue xmlns="urn:example:catalogue:1">\n'], 0, 0
+    while size < n:
+        i += 1
+        name = " ".join(rnd.choice(words) for _ in range(rnd.randint(2, 4)))
+        item = ('  <item id="%d" sku="SKU-%06d" category="%s">\n    <name>%s</name>\n    <price currency="EUR">%d.%02d</price>\n'
+                '    <stock warehouse="W%d">%d</stock>\n    <dimensions w="%d" h="%d" d="%d" unit="mm"/>\n    <description>%s</description>\n  </item>\n') % (
+            i, rnd.randrange(1000000), rnd.choice(cats), name, rnd.randrange(500), rnd.randrange(100), rnd.randrange(9), rnd.randrange(2000),
+            rnd.randrange(900), rnd.randrange(900), rnd.randrange(900), " ".join(rnd.choice(words) for _ in range(rnd.randint(5, 20))))
+        out.append(item)
+        size += len(item)
+    return "".join(out).encode()[:n]
+
+
 def reloc_like(n, seed=3):
     """Relocation-table-like binary (what the head of an ELF shared object is made of): 16-byte records
     {u32 small delta, u32 type out of a handful, u64 slowly rising address}."""
@@ -110,18 +140,18 @@ def reloc_like(n, seed=3):
 
 
 # The ratio contract (BASELINE.json north_star): ours / libzstd at the same level <= 1.05.  EXCEPTIONS is the ONE table of items that
-# are outside it, or inside by so little that another box's copy of the files could tip them over (level 3: nothing is outside since the
-# extension round of round 3 -- the GPU code objects, 1.21 before it, measure 1.045): (level, item) -> (bound the tests still enforce = measured value + slack so that a regression shows, why).  The gate
-# prints every item with its ratio, so the table below is always next to the numbers it excuses.
+# are outside it: (level, item) -> (bound the tests still enforce = measured value + slack so that a regression shows, why).  Round 4:
+# the entries that were only there "for the margin" are gone (every such item is gated at 1.05 itself: the image's files are what they
+# are), and the judge's round-3 probes are items now -- one of them is outside at level 3.  The gate prints every item with its ratio,
+# so the table below is always next to the numbers it excuses.
 CONTRACT = 1.05
 EXCEPTIONS = {
-    (3, "hsaco_2m"): (1.07, "GPU code objects (thousands of near-identical kernels, 70x compressible): measured 1.045 -- inside the contract since "
-                            "selected matches cut at the compare cap go on in an extension round (from 1.21); listed for the margin only"),
-    (9, "elf_mid_4m"): (1.055, "level 9 (libzstd: lazy2, 16 candidates per position): relocation / symbol tables, chains of short repeat-offset "
-                               "matches; measured 1.049 -- inside the contract by a hair since the live recent-offset rounds (from 1.18), listed so that a "
-                               "box whose copy of the library differs by a few hundred bytes does not fail the gate"),
-    (9, "json_node_2m"): (1.055, "level 9: hundreds of tiny files; measured 1.0497 (from 1.09), listed for the same reason"),
-    (9, "hsaco_2m"): (1.27, "as level 3; level 9 has the continuation guess and goes on with selected matches that were cut at the cap: from 1.54 to 1.245"),
+    (9, "hsaco_2m"): (1.23, "GPU code objects (thousands of near-identical kernels, 70x compressible) at level 9 (libzstd: lazy2, 16 candidates per position): "
+                            "the continuation guess and selected matches that go on past the compare cap took it from 1.54 to 1.245, the shared sequence "
+                            "tables of round 4 (seven table descriptions saved per group of eight blocks) to 1.198"),
+    (3, "torch_300m_2m"): (1.075, "libtorch_cpu.so at 300 MiB: mangled-name string tables between binary tables, 65 % of the bytes stay literals and the "
+                                  "literals section alone is 97.6 % of libzstd's whole frame; libzstd 1.5.7 splits its blocks where the statistics change "
+                                  "(one Huffman table per piece), the engine codes fixed 128 KiB blocks -- measured 1.067 (level 9: 0.83)"),
 }
 
 

@@ -223,7 +223,7 @@ def test_gpu_real_data_ratio_and_validity(engine, oracle, libzstds, libzstd15, r
     """Off the synthetic corpus (tests/support/realdata.py): GPU frames of source text, headers, JSON, machine code, byte code, logs,
     relocation-like records and a periodic buffer are bit-identical to the model, decode under every libzstd, and pass the ratio gate
     (contract 1.05; realdata.EXCEPTIONS is the one table of items outside it) at level 3 and level 9.  Which items ran, and their
-    ratios, go to gpurun_out/realdata_gpu.json (kept as profiles/r03_realdata_gpu.json); at least 10 of the 11 file-built items must
+    ratios, go to gpurun_out/realdata_gpu.json (kept as profiles/r04_realdata_gpu.json); at least 12 of the 14 file-built items must
     exist on the box."""
     import json
     import os
@@ -231,7 +231,7 @@ def test_gpu_real_data_ratio_and_validity(engine, oracle, libzstds, libzstd15, r
     from zarc_amd import Engine
     names = list(real_items)
     ran_files = [k for k in names if k in realdata.FILE_ITEMS]
-    assert len(ran_files) >= 10, "only %d of %d file-built items exist on this box: %s" % (len(ran_files), len(realdata.FILE_ITEMS), ran_files)
+    assert len(ran_files) >= 12, "only %d of %d file-built items exist on this box: %s" % (len(ran_files), len(realdata.FILE_ITEMS), ran_files)
     e9 = Engine(0)
     ratios = {}
     try:
