@@ -140,7 +140,7 @@ def workload(args, rank, world):
         level, kind = 3, args.kind
         desc = "zarc pack %d x %d B synthetic entries per GPU, zstd level 3, checksum on (BASELINE configs[1]%s)" % (
             args.entries, args.size, "" if (args.entries, args.size) == (10000, 1 << 20) else ", scaled")
-    if args.level is not None and args.level != level:
+    if getattr(args, "level", None) is not None and args.level != level:
         desc = desc.replace("zstd level %d" % level, "zstd level %d (--level: not the configuration's %d)" % (args.level, level))
         level = args.level
     mine = shard.assign(sizes, world)[rank]          # positions in the global list

@@ -175,6 +175,56 @@ def test_cli_emulated(emu_lib_path, tmp_path, corpus, oracle, libzstds):
     run_cli(binary, tmp_path / "s", corpus, oracle, libzstds, store=True)
 
 
+def test_cli_emulated_eight_devices(emu_lib_path, tmp_path, corpus):
+    """Eight engine handles on one host (BASELINE configs[4] shape in small: sizes a few KiB .. 700 KiB, duplicates whose
+    copies land on different devices): `zarc pack --gpus 8` writes the archive `--gpus 1` writes, byte for byte up to the directory
+    (whose timestamp differs), `unpack --gpus 8` restores the tree, and a corrupt frame gives the same error either way."""
+    import random
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu"), "host"])
+    binary = os.path.join(ROOT, "tests", "emu", "_build", "zarc")
+    env8 = dict(os.environ, HIPEMU_DEVICES="8")
+    rnd = random.Random(8)
+    src = tmp_path / "tree"
+    src.mkdir()
+    files = {}
+    for i in range(26):
+        n = int(3000 * 2 ** (rnd.random() * 8))
+        files["f%02d.bin" % i] = corpus.entry(900 + i, n, i % 4)
+    for i in (3, 11, 19):
+        files["dup%02d.bin" % i] = files["f%02d.bin" % i]                    # same content, another name: one frame, wherever the copies are dealt
+    for name, data in files.items():
+        (src / name).write_bytes(data)
+    arcs = {}
+    for g in (1, 8):
+        arc = tmp_path / ("g%d.zarc" % g)
+        subprocess.run([binary, "pack", "--output", str(arc), "--gpus", str(g), "tree"], cwd=tmp_path, capture_output=True, timeout=1800, check=True, env=env8)
+        arcs[g] = arc.read_bytes()
+    # content frames are written in call order with first-wins dedup: everything in front of the directory frame is identical
+    def dir_at(img):
+        import struct
+        off = struct.unpack("<q", img[-22 + 1:-22 + 9])[0]               # epilogue: digest_type u8 | directory_offset i64 (negative, from the end)
+        return len(img) + off
+    d1, d8 = dir_at(arcs[1]), dir_at(arcs[8])
+    assert d1 == d8 and arcs[1][:d1] == arcs[8][:d8]
+    for g in (1, 8):
+        dest = tmp_path / ("dest%d" % g)
+        dest.mkdir()
+        out = subprocess.run([binary, "unpack", str(tmp_path / ("g%d.zarc" % 8)), "--gpus", str(g)], cwd=dest, capture_output=True, timeout=1800, check=True, env=env8)
+        assert b"unpacked %d files" % len(files) in out.stderr
+        for name, data in files.items():
+            assert (dest / "tree" / name).read_bytes() == data, (g, name)
+    broken = bytearray(arcs[8])
+    broken[12 + 40000] ^= 0x10                                              # inside an early content frame
+    (tmp_path / "broken.zarc").write_bytes(bytes(broken))
+    res = {}
+    for g in (1, 8):
+        dest = tmp_path / ("bad%d" % g)
+        dest.mkdir()
+        r = subprocess.run([binary, "unpack", str(tmp_path / "broken.zarc"), "--gpus", str(g)], cwd=dest, capture_output=True, timeout=1800, env=env8)
+        res[g] = (r.returncode, sorted(l for l in r.stderr.splitlines() if b"rror" in l or b"corrupt" in l.lower()))
+    assert res[1] == res[8] and res[1][0] != 0, res
+
+
 @pytest.mark.gpu
 def test_cli_gpu(tmp_path, corpus, oracle, libzstds):
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "zarc_amd", "csrc"), "host"])

@@ -7,6 +7,7 @@ import os
 import socket
 import sys
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -56,9 +57,10 @@ def _worker(rank, world, port, emu_lib, q):
     dist.destroy_process_group()
 
 
-def test_sharded_pack_over_two_ranks_equals_single_handle(emu_lib_path, oracle):
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_pack_over_ranks_equals_single_handle(emu_lib_path, oracle, world):
     from zarc_amd import Engine, _lib, shard
-    world, port = 2, _free_port()
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, emu_lib_path, q)) for r in range(world)]
@@ -68,7 +70,7 @@ def test_sharded_pack_over_two_ranks_equals_single_handle(emu_lib_path, oracle):
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    assert t == 2.0 and u == 2000.0 * (1 << 20)                  # max over ranks, sum over ranks
+    assert t == float(world) and u == world * 1000.0 * (1 << 20)   # max over ranks, sum over ranks
     # the same entries through ONE handle, merged by the same host logic
     ents = _entries()
     eng = Engine(0, emu_lib_path)
@@ -112,7 +114,8 @@ def _unpack_worker(rank, world, port, emu_lib, frames, raw_lens, digests, q):
     dist.destroy_process_group()
 
 
-def test_sharded_unpack_over_two_ranks_equals_single_handle(emu_lib_path, oracle):
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_unpack_over_ranks_equals_single_handle(emu_lib_path, oracle, world):
     """The read side of section 8(e): the frames of an archive dealt to two ranks by uncompressed bytes, each rank decodes + verifies its
     share; merged results (bytes, digests, statuses) equal the single-handle ones -- with a corrupt frame and a wrong expected digest
     on rank 1's share (crates/zarc-cli/src/unpack.rs:62-88,118-120)."""
@@ -122,17 +125,18 @@ def test_sharded_unpack_over_two_ranks_equals_single_handle(emu_lib_path, oracle
     eng.set_parameter(_lib.P_CHECKSUM_FLAG, 1)
     packed = eng.pack(ents)
     frames, digests, raw_lens = [p[0] for p in packed], [p[1] for p in packed], [len(e) for e in ents]
-    shares = shard.assign_unpack(raw_lens, 2)
-    assert sorted(shares[0] + shares[1]) == list(range(8)) and shares[0] and shares[1]
-    big = [i for i in shares[1] if raw_lens[i] > 50000]
-    corrupt, wrong = big[0], big[1]
+    shares = shard.assign_unpack(raw_lens, world)
+    assert sorted(i for sh in shares for i in sh) == list(range(8)) and all(shares)
+    big = [i for sh in shares[1:] for i in sh if raw_lens[i] > 50000]      # on ranks other than the one that gathers
+    corrupt, wrong = big[0], big[-1]
+    assert corrupt != wrong
     f = bytearray(frames[corrupt])
     f[len(f) // 2] ^= 0x40
     frames[corrupt] = bytes(f)
     digests[wrong] = bytes(32)
     single = eng.unpack(frames, raw_lens, digests)
     eng.close()
-    world, port = 2, _free_port()
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_unpack_worker, args=(r, world, port, emu_lib_path, frames, raw_lens, digests, q)) for r in range(world)]

@@ -113,6 +113,17 @@ inline std::vector<std::vector<size_t>> shard_assign(const size_t *len, size_t n
     return out;
 }
 
+// Host-thread budget of G handles working at once (`--gpus G`): every handle's host-pointer entry points fill / drain their pinned
+// staging ring with ZARC_GPU_PX_COPY_THREADS threads (default 8) beside two helper threads and the caller's own.  Eight handles at the
+// default would be 64 copy threads on one host for a PCIe complex that 16 saturate: the total is capped at 16 (at least 2 per handle).
+inline void cap_copy_threads(const std::vector<std::unique_ptr<Engine>> &engines)
+{
+    const size_t g = engines.size();
+    if (g <= 2) return;
+    const int per = (int)std::max<size_t>(2, 16 / g);
+    for (auto &e : engines) e->check(zarc_gpu_set_parameter(e->get(), ZARC_GPU_PX_COPY_THREADS, per));
+}
+
 class Encoder {
   public:
     // Encoder::new: creates the context and writes the 12-byte header (encode.rs:58-78)
@@ -122,6 +133,7 @@ class Encoder {
     {
         if (devices.empty()) throw Error(ZARC_GPU_E_PARAM, "no device");
         for (int d : devices) engines_.emplace_back(new Engine(d));
+        cap_copy_threads(engines_);
         writer_.write((const char *)FILE_MAGIC, sizeof FILE_MAGIC);
         offset_ = sizeof FILE_MAGIC;
     }
@@ -255,6 +267,7 @@ class FrameReader {
     {
         if (devices.empty()) throw Error(ZARC_GPU_E_PARAM, "no device");
         for (int d : devices) engines_.emplace_back(new Engine(d));
+        cap_copy_threads(engines_);
     }
     size_t devices() const { return engines_.size(); }
 
