@@ -50,6 +50,26 @@ def aggregate(local_seconds, local_units, dist=None, device=None):
     return float(t.item()), float(u.item())
 
 
+def usable_cores():
+    """Host threads this process can really run at once: the affinity mask, cut to the cgroup's CPU quota where there is one (the GPU boxes
+    show 256 CPUs in the mask and grant a share of them: 256 threads then time-slice on that share, which is what round 3's all-cores
+    figure measured)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]                       # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())                          # cgroup v1
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(sample, size, first_index, level, kind=-1):
     """The reference's CPU path on this box's host cores (rank 0, N = 1 only), bounded sample: tests/support/cpu_baseline.c --
     one CCtx with session resets (content_frame.rs:37-41), decompressStream in 131 075 / 131 072-byte steps
@@ -65,7 +85,7 @@ def cpu_baseline(sample, size, first_index, level, kind=-1):
         probe[z.path] = r["pack_seconds"]
     zbest = min(zs, key=lambda z: probe[z.path])
     z15 = next((z for z in zs if z.version.startswith("1.5")), zbest)
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = usable_cores()
     one = harness.cpu_baseline(zbest.path, level, 1, sample, size, first_index, kind)
     # every thread gets 64 entries (at most 8192 in all: 8 GiB of 1 MiB entries + their frame buffers, allocated before the clock starts)
     many = harness.cpu_baseline(zbest.path, level, cores, max(min(64 * cores, 8192), cores), size, first_index, kind) if cores > 1 else None

@@ -65,7 +65,7 @@ struct zarc_gpu {
     // hashing
     DevBuf d_cvs, d_cvs_tmp, d_digests, d_xxh, d_expect;
     // encoder
-    DevBuf d_blocks, d_seq, d_lit, d_out, d_far, d_plan;
+    DevBuf d_blocks, d_seq, d_lit, d_out, d_far, d_plan, d_groups;
     // decoder
     DevBuf d_declit, d_status, d_stored_ck;
     DevBuf d_slot_prefix, d_zblocks, d_nseq, d_fast, d_seqidx, d_seqs, d_ztables, d_litidx, d_lits, d_seqflag; // decoder fast path (sequences decoded ahead)
@@ -730,9 +730,14 @@ int pack_device_impl(zarc_gpu_t *h, size_t n, const void *d_src_base, const uint
                 // pass 1 of one half of the blocks beside pass 2 of the other nor moving the digest kernels beside pass 2 gave any of that
                 // back: tools/r4_ab5.sh, r4_ab7.sh, EXPERIMENTS.md.)
                 ZHIP(h->d_plan.reserve(nb * sizeof(ZgePlan)));
+                std::vector<uint32_t> groups; // first block slot of every group of a frame with more than one block (frames come largest first)
+                for (size_t j = 0; j < m && bp[j + 1] - bp[j] > 1; j++)
+                    for (uint64_t g0 = bp[j]; g0 < bp[j + 1]; g0 += ZGE_TABLE_GROUP) groups.push_back((uint32_t)g0);
+                if ((rc = upload_u32(h, h->d_groups, groups.data(), groups.size()))) return rc;
                 hipLaunchKernelGGL(zarc_zge_entropy_p1, dim3((unsigned)nb), dim3(64), 0, h->stream, (uint32_t)nb, slot, h->d_blocks.as<ZgeBlock>(),
                                    h->d_seq.as<uint64_t>(), h->d_lit.as<uint8_t>(), h->d_out.as<uint8_t>(), eprof, h->d_plan.as<ZgePlan>());
-                hipLaunchKernelGGL(zarc_zge_plan, dim3((unsigned)nb), dim3(64), 0, h->stream, (uint32_t)nb, h->d_blocks.as<ZgeBlock>(), h->d_plan.as<ZgePlan>());
+                hipLaunchKernelGGL(zarc_zge_plan, dim3((unsigned)groups.size()), dim3(64), 0, h->stream, (uint32_t)nb, h->d_blocks.as<ZgeBlock>(), h->d_plan.as<ZgePlan>(),
+                                   h->d_groups.as<uint32_t>());
                 hipLaunchKernelGGL(zarc_zge_entropy_p2, dim3((unsigned)nb), dim3(64), 0, h->stream, (uint32_t)nb, slot, h->d_blocks.as<ZgeBlock>(),
                                    h->d_seq.as<uint64_t>(), h->d_lit.as<uint8_t>(), h->d_out.as<uint8_t>(), eprof, h->d_plan.as<ZgePlan>());
             } else

@@ -177,7 +177,7 @@ __global__ void zarc_zge_entropy(uint32_t n_blocks, uint32_t slot_bytes, ZgeBloc
 // ... or in two passes around the table plan: literals + sequence pre-pass + histograms + own choices -> plans[]; the plan; sequences
 __global__ void zarc_zge_entropy_p1(uint32_t n_blocks, uint32_t slot_bytes, ZgeBlock *blocks, uint64_t *seq_scratch, const uint8_t *lit_scratch,
                                     uint8_t *out_scratch, unsigned long long *prof, ZgePlan *plans);
-__global__ void zarc_zge_plan(uint32_t n_blocks, const ZgeBlock *blocks, ZgePlan *plans);
+__global__ void zarc_zge_plan(uint32_t n_blocks, const ZgeBlock *blocks, ZgePlan *plans, const uint32_t *group_start);
 __global__ void zarc_zge_entropy_p2(uint32_t n_blocks, uint32_t slot_bytes, ZgeBlock *blocks, uint64_t *seq_scratch, const uint8_t *lit_scratch,
                                     uint8_t *out_scratch, unsigned long long *prof, ZgePlan *plans);
 __global__ void zarc_zge_assemble(ZgeParams P, const uint8_t *src_base, const uint64_t *src_off, const uint64_t *src_len,

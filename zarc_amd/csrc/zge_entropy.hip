@@ -1128,21 +1128,22 @@ __global__ void __launch_bounds__(64, 5) zarc_zge_entropy_p2(uint32_t n_blocks, 
     zge_entropy_body<2>(L, n_blocks, slot_bytes, blocks, seq_scratch, lit_scratch, out_scratch, prof, plans);
 }
 
-// The table plan (model: zstd_enc_model.c, seq_plan_group).  One wave per group of ZGE_TABLE_GROUP blocks of a frame (the wave of the
-// group's first block slot; the others leave at once), one lane per symbol.  Per table type: the sum of the blocks' histograms is
+// The table plan (model: zstd_enc_model.c, seq_plan_group).  One wave per group of ZGE_TABLE_GROUP blocks of a frame (the host lists
+// the groups' first block slots), one lane per symbol.  Per table type: the sum of the blocks' histograms is
 // normalised like a block's own table would be; if coding every block of the group with that one table costs at most 1/64 more bits
 // than the blocks' own choices, the first block describes it and the others say Repeat_Mode -- as long as the chain holds: a block
 // hands the table on only if an upper bound of its coded size (every state transition at its symbol's larger bit count) is below its
 // raw size, i.e. it cannot end up a raw block, whose tables the decoder never sees; the block behind any other describes the table
 // again.  Blocks that keep RLE mode for a type break that type's chain the same way.  Costs fit 32 bits: a group holds at most
 // 8 x 43 690 sequences at 9 x 256 units each.
-__global__ void __launch_bounds__(64) zarc_zge_plan(uint32_t n_blocks, const ZgeBlock *__restrict__ blocks, ZgePlan *__restrict__ plans)
+__global__ void __launch_bounds__(64) zarc_zge_plan(uint32_t n_blocks, const ZgeBlock *__restrict__ blocks, ZgePlan *__restrict__ plans,
+                                                    const uint32_t *__restrict__ group_start /* first block slot of each group of a multi-block frame */)
 {
     __shared__ int16_t gnorm[3][64];
     __shared__ uint8_t gdesc[3][80];
     __shared__ uint32_t gdl[3];
     const int lane = zd::lane_id();
-    const uint32_t bi = blockIdx.x;
+    const uint32_t bi = group_start[blockIdx.x];
     if (bi >= n_blocks) return;
     const uint32_t frame = blocks[bi].frame, index0 = blocks[bi].index;
     if (index0 % ZGE_TABLE_GROUP) return;
