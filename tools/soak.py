@@ -15,7 +15,7 @@ oracle, corpus, zs = harness.Oracle(), harness.Corpus(), harness.libzstds()
 t_end = time.time() + budget
 rounds = frames = 0
 while time.time() < t_end:
-    level = rnd.choice([1, 3, 3, 9])
+    level = rnd.choice([1, -3, 2, 3, 3, 9, 9, 15])   # all four finder tiers (round 4)
     checksum = rnd.randrange(2)
     eng = Engine(0)
     eng.set_parameter(_lib.P_COMPRESSION_LEVEL, level)

@@ -1359,8 +1359,12 @@ int direct_copy(zarc_gpu *h, hipStream_t stream, const std::vector<Seg> &segs, u
         size_t e = k + 1;
         uint64_t len = segs[k].len;
         while (e < segs.size() && segs[e].host == segs[k].host + len && segs[e].dev == segs[k].dev + len && len + segs[e].len < ((uint64_t)1 << 31)) { len += segs[e].len; e++; }
-        if (to_device) ZHIP(hipMemcpyAsync(dev_base + segs[k].dev, segs[k].host, len, hipMemcpyHostToDevice, stream));
-        else ZHIP(hipMemcpyAsync(segs[k].host, dev_base + segs[k].dev, len, hipMemcpyDeviceToHost, stream));
+        // A run may span two page-locked allocations that happen to be adjacent, or a buffer with an unpinned hole (segs_pinned looks at
+        // the first and the last byte of a segment): the runtime may refuse such a copy.  That is no device error: the caller falls
+        // back to the staging ring, which redoes the whole range (copies already queued here move the same bytes).
+        const hipError_t e_ = to_device ? hipMemcpyAsync(dev_base + segs[k].dev, segs[k].host, len, hipMemcpyHostToDevice, stream)
+                                        : hipMemcpyAsync(segs[k].host, dev_base + segs[k].dev, len, hipMemcpyDeviceToHost, stream);
+        if (e_ != hipSuccess) { (void)hipGetLastError(); (void)h; return 1; }
         k = e;
     }
     return 0;
@@ -1369,7 +1373,7 @@ int direct_copy(zarc_gpu *h, hipStream_t stream, const std::vector<Seg> &segs, u
 // caller memory -> device range [0, total) at `dev_base`, through the pinned ring on `stream` (or straight from pinned caller memory)
 int staged_h2d(zarc_gpu *h, hipStream_t stream, const std::vector<Seg> &segs, uint8_t *dev_base, uint64_t total)
 {
-    if (h->zero_copy && segs_pinned(segs, (uint64_t)h->zero_copy << 10)) return direct_copy(h, stream, segs, dev_base, true);
+    if (h->zero_copy && segs_pinned(segs, (uint64_t)h->zero_copy << 10) && direct_copy(h, stream, segs, dev_base, true) == 0) return 0;
     int rc = pin_ring(h);
     if (rc) return rc;
     size_t first = 0;
@@ -1389,10 +1393,10 @@ int staged_h2d(zarc_gpu *h, hipStream_t stream, const std::vector<Seg> &segs, ui
 int staged_d2h(zarc_gpu *h, hipStream_t stream, const std::vector<Seg> &segs, const uint8_t *dev_base, uint64_t total)
 {
     if (h->zero_copy && segs_pinned(segs, (uint64_t)h->zero_copy << 10)) { // the callers synchronise the stream before they hand the buffers back
-        const int r = direct_copy(h, stream, segs, (uint8_t *)dev_base, false);
-        if (r) return r;
-        ZHIP(hipStreamSynchronize(stream));
-        return 0;
+        if (direct_copy(h, stream, segs, (uint8_t *)dev_base, false) == 0) {
+            ZHIP(hipStreamSynchronize(stream));
+            return 0;
+        }
     }
     int rc = pin_ring(h);
     if (rc) return rc;
