@@ -161,6 +161,21 @@ def test_emu_frame_pass_in_pieces(emu_engine, oracle, corpus, libzstd15):
     bad = bytearray(frames[0]); bad[len(bad) // 2] ^= 0x55
     res = emu_engine.unpack([bytes(bad), frames[1]], [len(text), len(rnd)], [oracle.blake3(text), oracle.blake3(rnd)])
     assert res[0][2] != _lib.FRAME_OK and res[1][2] == _lib.FRAME_OK and res[1][0] == rnd
+    # one large frame among many small ones (round 4, lean sizing: offsets are prefix sums made on the device, only the large frame gets a
+    # piece list, the small frames behind it are made up by the frame kernel) -- alone, and dealt into two size groups
+    tiny = [corpus.entry(5200 + i, 40 + 37 * i, i % 4) for i in range(70)]
+    tframes = [f for f, _ in emu_engine.pack(tiny)]
+    order = list(range(70))
+    mixed_f = tframes[:30] + [frames[2]] + tframes[30:] + [frames[1]]
+    mixed_r = tiny[:30] + [text] + tiny[30:] + [rnd]
+    for g in (0, 2):
+        emu_engine.set_parameter(_lib.PX_DEC_GROUPS, g)
+        try:
+            res = emu_engine.unpack(mixed_f, [len(r) for r in mixed_r], [oracle.blake3(r) for r in mixed_r])
+        finally:
+            emu_engine.set_parameter(_lib.PX_DEC_GROUPS, 0)
+        for raw, (out, dig, st) in zip(mixed_r, res):
+            assert st == _lib.FRAME_OK and out == raw and dig == oracle.blake3(raw), (g, len(raw))
 
 
 def test_emu_zero_copy_for_pinned_caller_memory(emu_lib_path, oracle, corpus, golden_frames, monkeypatch):

@@ -68,7 +68,7 @@ struct zarc_gpu {
     DevBuf d_blocks, d_seq, d_lit, d_out, d_far, d_plan, d_groups;
     // decoder
     DevBuf d_declit, d_status, d_stored_ck;
-    DevBuf d_slot_prefix, d_zblocks, d_nseq, d_fast, d_seqidx, d_seqs, d_ztables, d_litidx, d_lits, d_seqflag; // decoder fast path (sequences decoded ahead)
+    DevBuf d_slot_prefix, d_zblocks, d_nseq, d_fast, d_seqidx, d_seqs, d_ztables, d_litidx, d_lits, d_seqflag, d_totals; // decoder fast path (sequences decoded ahead)
     DevBuf d_queue; // frame queues of the persistent kernels (one u32 each)
     int num_cus = 1;
     int deep_per_cu = 0; // workgroups of zarc_zge_match_deep a CU holds (0: not asked yet)
@@ -887,20 +887,39 @@ int unpack_device_once(zarc_gpu_t *h, size_t n, const void *d_frames_base, const
     bool fastpath = diag_env("ZARC_GPU_DEC_FAST", 1) != 0;
     // slots of the fast path: one per block, counted on the device first (a frame the count turns down keeps one slot and goes to the
     // general decoder)
-    std::vector<uint64_t> slot_prefix(n + 1, 0);
+    // Lean sizing (round 4): a batch without large frames needs nothing on the host but three totals -- no frame is cut into pieces, there
+    // is one group -- so the slot / sequence / literal offsets are prefix sums made on the device (zarc_scan_u32) and stay there.  With
+    // large frames (4 MiB and more) the host needs the per-block summaries anyway and takes the arrays as before.
+    size_t n_large = 0; // frames of 4 MiB and more (sorted order: a prefix): the ones the host may cut into pieces
+    while (n_large < n && raw_len[n_large] >= ((uint64_t)4 << 20)) n_large++;
+    bool lean = fastpath && (n_large == 0 || n_large * 64 <= n) && diag_env("ZARC_GPU_DEC_LEAN", 1) != 0;
+    uint64_t lean_totals[3] = {0, 0, 0};
+    std::vector<uint64_t> slot_prefix(n + 1, 0); // lean: only the entries the host needs are filled in (the large frames', the groups' bounds, [n])
     if (fastpath) {
-        std::vector<uint32_t> nblk(n);
         ZHIP(h->d_fast.reserve(n * 4));
         hipLaunchKernelGGL(zarc_zdec_count, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, h->stream, (const uint8_t *)d_frames_base, h->d_frame_off.as<uint64_t>(),
                            h->d_frame_len.as<uint64_t>(), h->d_raw_len.as<uint64_t>(), (uint32_t)n, h->d_fast.as<uint32_t>());
         ZHIP(hipGetLastError());
-        ZHIP(hipMemcpyAsync(nblk.data(), h->d_fast.p, n * 4, hipMemcpyDeviceToHost, h->stream));
-        ZHIP(hipStreamSynchronize(h->stream));
-        for (size_t i = 0; i < n; i++) slot_prefix[i + 1] = slot_prefix[i] + std::max<uint32_t>(nblk[i], 1u);
+        if (lean) {
+            ZHIP(h->d_slot_prefix.reserve((n + 1) * 8));
+            ZHIP(h->d_totals.reserve(64));
+            hipLaunchKernelGGL(zarc_scan_u32, dim3(1), dim3(1024), 0, h->stream, h->d_fast.as<uint32_t>(), 1u, 1u, (uint64_t)n, h->d_slot_prefix.as<uint64_t>(),
+                               h->d_totals.as<uint64_t>());
+            ZHIP(hipGetLastError());
+            ZHIP(hipMemcpyAsync(lean_totals, h->d_totals.p, 8, hipMemcpyDeviceToHost, h->stream));
+            if (n_large) ZHIP(hipMemcpyAsync(slot_prefix.data(), h->d_slot_prefix.p, (n_large + 1) * 8, hipMemcpyDeviceToHost, h->stream));
+            ZHIP(hipStreamSynchronize(h->stream));
+            slot_prefix[n] = lean_totals[0];
+        } else {
+            std::vector<uint32_t> nblk(n);
+            ZHIP(hipMemcpyAsync(nblk.data(), h->d_fast.p, n * 4, hipMemcpyDeviceToHost, h->stream));
+            ZHIP(hipStreamSynchronize(h->stream));
+            for (size_t i = 0; i < n; i++) slot_prefix[i + 1] = slot_prefix[i] + std::max<uint32_t>(nblk[i], 1u);
+        }
     } else
         for (size_t i = 0; i < n; i++) slot_prefix[i + 1] = slot_prefix[i] + 1;
     const size_t nslots = (size_t)slot_prefix[n];
-    if (nslots * (size_t)ZDEC_TABLE_CELLS * 2 > ((size_t)8 << 30)) fastpath = false; // table scratch out of proportion (millions of tiny frames)
+    if (nslots * (size_t)ZDEC_TABLE_CELLS * 2 > ((size_t)8 << 30)) { fastpath = false; if (lean) { lean = false; for (size_t i = 0; i < n; i++) slot_prefix[i + 1] = i + 1; } } // table scratch out of proportion (millions of tiny frames)
     // groups: [gf[g], gf[g+1]) in sorted order, equal shares of the bytes.  One group (the stages simply follow each other) unless the
     // batch holds frames large enough for their chains to matter.
     int groups = h->dec_groups;
@@ -920,6 +939,10 @@ int unpack_device_once(zarc_gpu_t *h, size_t n, const void *d_frames_base, const
           if (acc * (uint64_t)groups >= total_raw * (uint64_t)g && i + 1 + (size_t)(groups - g) <= n) gf[g++] = i + 1; // every group keeps a frame
       }
       for (; g < groups; g++) gf[g] = std::max(gf[g - 1] + 1, n - (size_t)(groups - g)); }
+    if (lean && fastpath && groups > 1) { // the slot at which every group starts (lean: the prefix sums live on the device)
+        for (int g = 1; g < groups; g++) ZHIP(hipMemcpyAsync(&slot_prefix[gf[g]], h->d_slot_prefix.as<uint64_t>() + gf[g], 8, hipMemcpyDeviceToHost, h->stream));
+        ZHIP(hipStreamSynchronize(h->stream));
+    }
     // digest descriptors: per group, chunk prefixes rebased to the group's first chunk (the kernels take sub-ranges by pointer)
     std::vector<uint64_t> cprefix(n + (size_t)groups), gchunk0(groups + 1, 0);
     { uint64_t c = 0;
@@ -937,13 +960,15 @@ int unpack_device_once(zarc_gpu_t *h, size_t n, const void *d_frames_base, const
     ZHIP(h->d_digests.reserve(n * 32));
     ZHIP(h->d_xxh.reserve(n * 8));
     std::vector<uint64_t> seqidx, litidx;
+    uint64_t total_seqs = 0, total_lits = 0;
+    uint64_t g_seq_at[zarc_gpu::DEC_GROUPS + 1] = {}, g_lit_at[zarc_gpu::DEC_GROUPS + 1] = {}; // lean: the groups' first sequence / literal
     if (fastpath) {
-        if ((rc = upload_u64(h, h->d_slot_prefix, slot_prefix.data(), n + 1))) return rc;
+        if (!lean && (rc = upload_u64(h, h->d_slot_prefix, slot_prefix.data(), n + 1))) return rc;
         ZHIP(h->d_zblocks.reserve(nslots * sizeof(ZdecBlock)));
         ZHIP(h->d_nseq.reserve(nslots * 8));
         ZHIP(h->d_fast.reserve(n * 4));
-        ZHIP(h->d_seqidx.reserve(nslots * 8));
-        ZHIP(h->d_litidx.reserve(nslots * 8));
+        ZHIP(h->d_seqidx.reserve((nslots + 1) * 8));
+        ZHIP(h->d_litidx.reserve((nslots + 1) * 8));
         ZHIP(h->d_ztables.reserve(nslots * (size_t)ZDEC_TABLE_CELLS * 2));
         ZHIP(h->d_seqflag.reserve((nslots / 16 + (size_t)zarc_gpu::DEC_GROUPS + 2) * 4));
         ZHIP(hipMemsetAsync(h->d_zblocks.p, 0xFF, nslots * sizeof(ZdecBlock), h->stream));
@@ -952,18 +977,37 @@ int unpack_device_once(zarc_gpu_t *h, size_t n, const void *d_frames_base, const
                            h->d_frame_len.as<uint64_t>(), h->d_raw_len.as<uint64_t>(), (uint32_t)n, h->d_slot_prefix.as<uint64_t>(), h->d_zblocks.as<ZdecBlock>(),
                            h->d_nseq.as<uint32_t>(), h->d_fast.as<uint32_t>());
         ZHIP(hipGetLastError());
-        std::vector<uint32_t> counts(nslots * 2);
-        ZHIP(hipMemcpyAsync(counts.data(), h->d_nseq.p, nslots * 8, hipMemcpyDeviceToHost, h->stream));
-        ZHIP(hipStreamSynchronize(h->stream)); // the sequence / literal scratch is sized exactly: sums of the blocks' counts
-        seqidx.resize(nslots + 1); litidx.resize(nslots + 1);
-        uint64_t total = 0, lit_total = 0;
-        for (size_t i = 0; i < nslots; i++) { seqidx[i] = total; total += counts[2 * i]; litidx[i] = lit_total; lit_total += counts[2 * i + 1]; }
-        seqidx[nslots] = total; litidx[nslots] = lit_total;
-        if (h->scratch_budget && n > 1 && total * 8 + lit_total + nslots * (uint64_t)(ZDEC_TABLE_CELLS * 2 + sizeof(ZdecBlock) + 32) > h->scratch_budget) return UNPACK_SPLIT;
-        if ((rc = upload_u64(h, h->d_seqidx, seqidx.data(), nslots))) return rc;
-        if ((rc = upload_u64(h, h->d_litidx, litidx.data(), nslots))) return rc;
-        ZHIP(h->d_seqs.reserve(std::max<uint64_t>(total, 1) * 8));
-        ZHIP(h->d_lits.reserve(std::max<uint64_t>(lit_total, 1) + 64));
+        if (lean) { // the sequence / literal scratch is sized exactly: sums of the blocks' counts, made where the counts are
+            hipLaunchKernelGGL(zarc_scan_u32, dim3(1), dim3(1024), 0, h->stream, h->d_nseq.as<uint32_t>(), 2u, 0u, (uint64_t)nslots, h->d_seqidx.as<uint64_t>(),
+                               h->d_totals.as<uint64_t>() + 1);
+            hipLaunchKernelGGL(zarc_scan_u32, dim3(1), dim3(1024), 0, h->stream, h->d_nseq.as<uint32_t>() + 1, 2u, 0u, (uint64_t)nslots, h->d_litidx.as<uint64_t>(),
+                               h->d_totals.as<uint64_t>() + 2);
+            ZHIP(hipGetLastError());
+            ZHIP(hipMemcpyAsync(lean_totals + 1, h->d_totals.as<uint64_t>() + 1, 16, hipMemcpyDeviceToHost, h->stream));
+            for (int g = 1; g < groups; g++) { // where every group's sequences / literals start
+                ZHIP(hipMemcpyAsync(&g_seq_at[g], h->d_seqidx.as<uint64_t>() + slot_prefix[gf[g]], 8, hipMemcpyDeviceToHost, h->stream));
+                ZHIP(hipMemcpyAsync(&g_lit_at[g], h->d_litidx.as<uint64_t>() + slot_prefix[gf[g]], 8, hipMemcpyDeviceToHost, h->stream));
+            }
+            ZHIP(hipStreamSynchronize(h->stream));
+            total_seqs = lean_totals[1]; total_lits = lean_totals[2];
+            g_seq_at[groups] = total_seqs; g_lit_at[groups] = total_lits;
+        } else {
+            std::vector<uint32_t> counts(nslots * 2);
+            ZHIP(hipMemcpyAsync(counts.data(), h->d_nseq.p, nslots * 8, hipMemcpyDeviceToHost, h->stream));
+            ZHIP(hipStreamSynchronize(h->stream)); // the sequence / literal scratch is sized exactly: sums of the blocks' counts
+            seqidx.resize(nslots + 1); litidx.resize(nslots + 1);
+            uint64_t total = 0, lit_total = 0;
+            for (size_t i = 0; i < nslots; i++) { seqidx[i] = total; total += counts[2 * i]; litidx[i] = lit_total; lit_total += counts[2 * i + 1]; }
+            seqidx[nslots] = total; litidx[nslots] = lit_total;
+            total_seqs = total; total_lits = lit_total;
+        }
+        if (h->scratch_budget && n > 1 && total_seqs * 8 + total_lits + nslots * (uint64_t)(ZDEC_TABLE_CELLS * 2 + sizeof(ZdecBlock) + 32) > h->scratch_budget) return UNPACK_SPLIT;
+        if (!lean) {
+            if ((rc = upload_u64(h, h->d_seqidx, seqidx.data(), nslots))) return rc;
+            if ((rc = upload_u64(h, h->d_litidx, litidx.data(), nslots))) return rc;
+        }
+        ZHIP(h->d_seqs.reserve(std::max<uint64_t>(total_seqs, 1) * 8));
+        ZHIP(h->d_lits.reserve(std::max<uint64_t>(total_lits, 1) + 64));
     }
     ZHIP(hipMemsetAsync(h->d_queue.p, 0, 256, h->stream)); // two queues per group: the fast frame pass and the general decoder each walk the group's frames
     ZHIP(hipMemsetAsync(h->d_status.p, 0, n * 4, h->stream)); // the pieces of a frame raise its status with atomicMax
@@ -977,12 +1021,12 @@ int unpack_device_once(zarc_gpu_t *h, size_t n, const void *d_frames_base, const
     if (lds_frac < 0) lds_frac = 0;
     if (lds_frac > 1) lds_frac = 1;
     bool have_seq_t[zarc_gpu::DEC_GROUPS] = {}, have_lit_t[zarc_gpu::DEC_GROUPS] = {};
-    std::vector<uint32_t> nblk_of(n); // blocks per frame (sorted order)
-    for (size_t i = 0; i < n; i++) nblk_of[i] = (uint32_t)(slot_prefix[i + 1] - slot_prefix[i]);
+    std::vector<uint32_t> nblk_of(lean ? n_large : n); // blocks per frame (sorted order; lean: of the large frames only)
+    for (size_t i = 0; i < nblk_of.size(); i++) nblk_of[i] = (uint32_t)(slot_prefix[i + 1] - slot_prefix[i]);
     std::vector<ZdecPiece> pieces[zarc_gpu::DEC_GROUPS];
     std::vector<ZdecBlock> hblocks;
     std::vector<uint32_t> hfast;
-    ZHIP(h->d_pieces.reserve((nslots / 8 + n + 16) * sizeof(ZdecPiece)));
+    ZHIP(h->d_pieces.reserve(lean ? (size_t)(slot_prefix[n_large] / 8 + n_large + 16) * sizeof(ZdecPiece) : (nslots / 8 + n + 16) * sizeof(ZdecPiece)));
     size_t piece_base = 0;
     // phase 0 queues the stages ahead of every group, phase 1 the frame passes and hashes: in between the host may have to look at what
     // stage 2 found out about a group's blocks (pieces, below), and the next group's stages ahead must be running by then
@@ -1000,7 +1044,7 @@ int unpack_device_once(zarc_gpu_t *h, size_t n, const void *d_frames_base, const
             hipStream_t sa_post = sa, sb_post = sb;
             sa = pa; sb = pb; // this block launches the stages ahead
             const uint64_t s0 = slot_prefix[f0], s1 = slot_prefix[f1];
-            const uint64_t g_seqs = seqidx[s1] - seqidx[s0], g_lits = litidx[s1] - litidx[s0];
+            const uint64_t g_seqs = lean ? g_seq_at[g + 1] - g_seq_at[g] : seqidx[s1] - seqidx[s0], g_lits = lean ? g_lit_at[g + 1] - g_lit_at[g] : litidx[s1] - litidx[s0];
             // the literal and the sequence kernels are independent and neither fills the chip: they run side by side
             hipStream_t sl = side ? sb : sa;
             // the shared-table sequence kernel needs 25 KiB of LDS per wave: launched first it gets its place on every CU at once and the
@@ -1074,20 +1118,21 @@ int unpack_device_once(zarc_gpu_t *h, size_t n, const void *d_frames_base, const
         // frames are made of independent 2 MiB segments (zge_match.hip), libzstd's multi-threaded ones of independent jobs.  The host
         // cuts such frames (4 MiB and more) at those blocks, gives every piece its output position and repeat-offset history, and the
         // pieces decode side by side.
+        const size_t fl = lean ? std::max(f0, std::min(f1, n_large)) : f1; // lean: frames [f0, fl) get a piece list, [fl, f1) are one piece each (no list)
         if (fastpath) {
-            const uint64_t s0 = slot_prefix[f0], s1 = slot_prefix[f1];
+            const uint64_t s0 = slot_prefix[f0], s1 = slot_prefix[fl];
             bool large = false;
-            for (size_t i = f0; i < f1 && !large; i++) large = nblk_of[i] >= 32;
+            for (size_t i = f0; i < fl && !large; i++) large = nblk_of[i] >= 32;
             if (large) {
                 ZHIP(hipEventSynchronize(ev[11]));
-                hblocks.resize(s1 - s0); hfast.resize(ng);
+                hblocks.resize(s1 - s0); hfast.resize(fl - f0);
                 ZHIP(hipMemcpyAsync(hblocks.data(), h->d_zblocks.as<ZdecBlock>() + s0, (s1 - s0) * sizeof(ZdecBlock), hipMemcpyDeviceToHost, sa));
-                ZHIP(hipMemcpyAsync(hfast.data(), h->d_fast.as<uint32_t>() + f0, ng * 4, hipMemcpyDeviceToHost, sa));
+                ZHIP(hipMemcpyAsync(hfast.data(), h->d_fast.as<uint32_t>() + f0, (fl - f0) * 4, hipMemcpyDeviceToHost, sa));
                 ZHIP(hipStreamSynchronize(sa));
             }
             std::vector<ZdecPiece> &pc = pieces[g];
             std::vector<uint64_t> start, need;
-            for (size_t i = f0; i < f1; i++) {
+            for (size_t i = f0; i < fl; i++) {
                 const uint32_t nb = nblk_of[i];
                 ZdecPiece whole{(uint32_t)i, 0u, 0xFFFFFFFFu, {1u, 4u, 8u}, 0ull, raw_len[i]};
                 if (!large || nb < 32 || !hfast[i - f0]) { pc.push_back(whole); continue; }
@@ -1126,15 +1171,15 @@ int unpack_device_once(zarc_gpu_t *h, size_t n, const void *d_frames_base, const
                 }
             }
             std::stable_sort(pc.begin(), pc.end(), [](const ZdecPiece &x, const ZdecPiece &y) { return x.out_len > y.out_len; }); // longest first
-            ZHIP(hipMemcpyAsync(h->d_pieces.as<ZdecPiece>() + piece_base, pc.data(), pc.size() * sizeof(ZdecPiece), hipMemcpyHostToDevice, sa));
+            if (!pc.empty()) ZHIP(hipMemcpyAsync(h->d_pieces.as<ZdecPiece>() + piece_base, pc.data(), pc.size() * sizeof(ZdecPiece), hipMemcpyHostToDevice, sa));
         }
         ZHIP(hipEventRecord(ev[4], sa));
         const size_t grid_g = std::max<size_t>(1, std::min<size_t>(ng, dec_grid / (size_t)groups));
         if (fastpath) {
-            const size_t np = pieces[g].size();
+            const size_t listed = pieces[g].size(), np = listed + (f1 - fl); // behind the list: frames [fl, f1), one piece each, made up by the kernel
             hipLaunchKernelGGL(zarc_zstd_frames, dim3((unsigned)std::min<size_t>(np, (size_t)h->num_cus * 16)), dim3(64), 0, sa, (const uint8_t *)d_frames_base, h->d_frame_off.as<uint64_t>(),
                                h->d_frame_len.as<uint64_t>(), (uint8_t *)d_dst_base, h->d_dst_off.as<uint64_t>(), h->d_raw_len.as<uint64_t>(),
-                               h->d_pieces.as<ZdecPiece>() + piece_base, (uint32_t)np, h->d_status.as<int32_t>(), h->d_stored_ck.as<uint32_t>(), dec_dbg, h->d_queue.as<uint32_t>() + 2 * g,
+                               h->d_pieces.as<ZdecPiece>() + piece_base, (uint32_t)listed, (uint32_t)fl, (uint32_t)np, h->d_status.as<int32_t>(), h->d_stored_ck.as<uint32_t>(), dec_dbg, h->d_queue.as<uint32_t>() + 2 * g,
                                h->d_fast.as<uint32_t>(), h->d_slot_prefix.as<uint64_t>(), h->d_zblocks.as<ZdecBlock>(), h->d_seqidx.as<uint64_t>(),
                                h->d_seqs.as<uint64_t>(), h->d_litidx.as<uint64_t>(), h->d_lits.as<uint8_t>());
             ZHIP(hipGetLastError());

@@ -110,13 +110,16 @@ __global__ void zarc_zstd_decode(const uint8_t *frames_base, const uint64_t *fra
                                  const uint32_t *fast /* per frame: handled by zarc_zstd_frames; null = take every frame */);
 // frame pass of the decoder fast path: frames whose sequences and literals were decoded ahead (fast[f] != 0)
 __global__ void zarc_zstd_frames(const uint8_t *frames_base, const uint64_t *frame_off, const uint64_t *frame_len, uint8_t *dst_base,
-                                 const uint64_t *dst_off, const uint64_t *raw_len, const ZdecPiece *pieces, uint32_t n_pieces, int32_t *status,
+                                 const uint64_t *dst_off, const uint64_t *raw_len, const ZdecPiece *pieces, uint32_t n_listed /* pieces[] holds this many */,
+                                 uint32_t first_unlisted /* behind them: frames first_unlisted .. as one piece each */, uint32_t n_pieces, int32_t *status,
                                  uint32_t *stored_checksum, int dbg, uint32_t *queue, const uint32_t *fast, const uint64_t *slot_prefix,
                                  const ZdecBlock *zblocks, const uint64_t *seq_index, const uint64_t *seqs, const uint64_t *lit_index,
                                  const uint8_t *lits);
 __global__ void zarc_gather(const uint8_t *src_base, const uint64_t *src_off, const uint64_t *len, const uint64_t *dense_off, uint32_t n, uint8_t *dst);
 __global__ void zarc_zge_store(const uint8_t *src_base, const uint64_t *src_off, const uint64_t *src_len, uint32_t n_frames, uint8_t *dst_base,
                                const uint64_t *dst_off, uint64_t *dst_len);
+// exclusive prefix sum of in[i * stride] (at least `floor` each) -> out[0 .. n] and *total; one workgroup of 1024 threads
+__global__ void zarc_scan_u32(const uint32_t *in, uint32_t stride, uint32_t floor_, uint64_t n, uint64_t *out, uint64_t *total);
 // decoder fast path, stage 1: one LANE per frame walks the block headers (no payload is touched) -> block slots, nseq[], fast[]
 __global__ void zarc_zdec_count(const uint8_t *frames_base, const uint64_t *frame_off, const uint64_t *frame_len, const uint64_t *raw_len, uint32_t n_frames,
                                 uint32_t *nblocks);

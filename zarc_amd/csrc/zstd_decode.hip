@@ -1184,7 +1184,8 @@ __global__ void __launch_bounds__(64, 4) zarc_zstd_decode(const uint8_t *__restr
 __global__ void __launch_bounds__(64, 4) zarc_zstd_frames(const uint8_t *__restrict__ frames_base, const uint64_t *__restrict__ frame_off,
                                                        const uint64_t *__restrict__ frame_len, uint8_t *__restrict__ dst_base,
                                                        const uint64_t *__restrict__ dst_off, const uint64_t *__restrict__ raw_len,
-                                                       const ZdecPiece *__restrict__ pieces, uint32_t n_pieces, int32_t *__restrict__ status,
+                                                       const ZdecPiece *__restrict__ pieces, uint32_t n_listed, uint32_t first_unlisted, uint32_t n_pieces,
+                                                       int32_t *__restrict__ status,
                                                        uint32_t *__restrict__ stored_checksum,
                                                        int dbg /* timing-only ablations: 1 no copies; 8 no near matches, 16 no flush, 32 no literal staging, 64 no far-match staging, 128 all near matches in order */,
                                                        uint32_t *__restrict__ queue, const uint32_t *__restrict__ fast,
@@ -1199,7 +1200,12 @@ __global__ void __launch_bounds__(64, 4) zarc_zstd_frames(const uint8_t *__restr
         if (lane == 0) slot = atomicAdd(queue, 1u);
         slot = zd::uniform(slot);
         if (slot >= n_pieces) break;
-        const ZdecPiece piece = pieces[slot];
+        ZdecPiece piece;
+        if (slot < n_listed) piece = pieces[slot];
+        else { // behind the list: frames first_unlisted, first_unlisted + 1, ... are one piece each (engine.hip: only large frames are cut and listed)
+            piece.frame = first_unlisted + (slot - n_listed); piece.first = 0; piece.count = 0xFFFFFFFFu; piece.rep[0] = 1; piece.rep[1] = 4; piece.rep[2] = 8;
+            piece.out_start = 0; piece.out_len = raw_len[piece.frame];
+        }
         const uint32_t f = piece.frame;
         if (zd::uniform(fast[f]) == 0) continue; // zarc_zstd_decode has it
         const uint64_t first = slot_prefix[f];
@@ -1207,6 +1213,37 @@ __global__ void __launch_bounds__(64, 4) zarc_zstd_frames(const uint8_t *__restr
                            zblocks + first, seq_index + first, seqs, lit_index + first, lits, piece);
         zd::wave_sync_global(); // the LDS staging buffer is reused by the next frame
     }
+}
+
+// Exclusive prefix sum of n 32-bit values (in[i * stride], at least `floor` each) into out[0 .. n] (64-bit; out[n] = the total, also at
+// *total).  ONE workgroup of 1024 threads, four values per thread and trip: the decoder's slot / sequence / literal offsets of a batch
+// are sized on the device, so that the host reads back three totals instead of per-slot arrays (a million small frames: 12 MB of
+// counts down, 24 MB of offsets up and five host loops over them, a third of the call).
+__global__ void __launch_bounds__(1024) zarc_scan_u32(const uint32_t *__restrict__ in, uint32_t stride, uint32_t floor_, uint64_t n,
+                                                      uint64_t *__restrict__ out, uint64_t *__restrict__ total)
+{
+    __shared__ uint32_t wsum[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint64_t carry = 0;
+    for (uint64_t base = 0; base < n; base += 4096) {
+        const uint64_t i0 = base + 4ull * tid;
+        uint32_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const uint64_t i = i0 + (uint64_t)k; v[k] = i < n ? in[i * stride] : 0u; if (i < n && v[k] < floor_) v[k] = floor_; }
+        const uint32_t mine = v[0] + v[1] + v[2] + v[3]; // (a trip's sum stays far below 2^32: 4096 values of at most 2^17)
+        const uint32_t incl = zd::wave_scan_incl(mine);
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t before = 0, all = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 16; w++) { const uint32_t x = wsum[w]; all += x; if (w < wave) before += x; }
+        uint64_t at = carry + before + (incl - mine);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { if (i0 + (uint64_t)k < n) out[i0 + k] = at; at += v[k]; }
+        carry += all;
+        __syncthreads(); // wsum is rewritten by the next trip
+    }
+    if (tid == 0) { out[n] = carry; *total = carry; }
 }
 
 // Stage 0 of the fast path: how many blocks does every frame hold?  (One lane per frame walks the block headers only.)  The slots of
