@@ -24,6 +24,10 @@ namespace {
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); } // (zarc_gpu_destroy deletes the handle: every scratch buffer goes with it)
     hipError_t reserve(size_t n)
     {
         if (n <= cap) return hipSuccess;
@@ -68,7 +72,7 @@ struct zarc_gpu {
     DevBuf d_blocks, d_seq, d_lit, d_out, d_far, d_plan, d_groups;
     // decoder
     DevBuf d_declit, d_status, d_stored_ck;
-    DevBuf d_slot_prefix, d_zblocks, d_nseq, d_fast, d_seqidx, d_seqs, d_ztables, d_litidx, d_lits, d_seqflag, d_totals; // decoder fast path (sequences decoded ahead)
+    DevBuf d_slot_prefix, d_zblocks, d_nseq, d_fast, d_seqidx, d_seqs, d_ztables, d_litidx, d_lits, d_seqflag, d_totals, d_predef; // decoder fast path (sequences decoded ahead)
     DevBuf d_queue; // frame queues of the persistent kernels (one u32 each)
     int num_cus = 1;
     int deep_per_cu = 0; // workgroups of zarc_zge_match_deep a CU holds (0: not asked yet)
@@ -970,6 +974,11 @@ int unpack_device_once(zarc_gpu_t *h, size_t n, const void *d_frames_base, const
         ZHIP(h->d_seqidx.reserve((nslots + 1) * 8));
         ZHIP(h->d_litidx.reserve((nslots + 1) * 8));
         ZHIP(h->d_ztables.reserve(nslots * (size_t)ZDEC_TABLE_CELLS * 2));
+        if (!h->d_predef.p) { // the predefined tables: once per handle
+            ZHIP(h->d_predef.reserve(ZDEC_PREDEF_CELLS * 2));
+            hipLaunchKernelGGL(zarc_zdec_predef, dim3(1), dim3(64), 0, h->stream, h->d_predef.as<uint16_t>());
+            ZHIP(hipGetLastError());
+        }
         ZHIP(h->d_seqflag.reserve((nslots / 16 + (size_t)zarc_gpu::DEC_GROUPS + 2) * 4));
         ZHIP(hipMemsetAsync(h->d_zblocks.p, 0xFF, nslots * sizeof(ZdecBlock), h->stream));
         ZHIP(hipMemsetAsync(h->d_nseq.p, 0, nslots * 8, h->stream));
@@ -1099,7 +1108,8 @@ int unpack_device_once(zarc_gpu_t *h, size_t n, const void *d_frames_base, const
                     }
                     hipLaunchKernelGGL(zarc_zdec_seqs, dim3((unsigned)waves), dim3(sw), 0, sa, (const uint8_t *)d_frames_base,
                                        h->d_frame_off.as<uint64_t>(), split, h->d_slot_prefix.as<uint64_t>(), h->d_zblocks.as<ZdecBlock>(), h->d_seqidx.as<uint64_t>(),
-                                       h->d_seqs.as<uint64_t>(), h->d_ztables.as<uint16_t>(), h->d_fast.as<uint32_t>(), s0, (const uint32_t *)flags);
+                                       h->d_seqs.as<uint64_t>(), h->d_ztables.as<uint16_t>(), h->d_fast.as<uint32_t>(), s0, (const uint32_t *)flags,
+                                       h->d_predef.as<uint16_t>());
                 }
                 if (split < s1) ZHIP(hipStreamWaitEvent(sa, h->ev_join3, 0));
                 ZHIP(hipGetLastError());

@@ -136,7 +136,9 @@ __global__ void zarc_zdec_seqs_lds(const uint8_t *frames_base, const uint64_t *f
 // 64-slot waves zarc_zdec_seqs_shared turned down
 __global__ void zarc_zdec_seqs(const uint8_t *frames_base, const uint64_t *frame_off, uint64_t n_slots, const uint64_t *slot_prefix,
                                ZdecBlock *zblocks, const uint64_t *seq_index, uint64_t *seqs, uint16_t *tables, uint32_t *fast, uint64_t slot_base,
-                               const uint32_t *wave_flag /* may be null */);
+                               const uint32_t *wave_flag /* may be null */, const uint16_t *predef /* zarc_zdec_predef's tables, or null */);
+constexpr int ZDEC_PREDEF_LL = 0, ZDEC_PREDEF_OF = 64, ZDEC_PREDEF_ML = 96, ZDEC_PREDEF_CELLS = 160;
+__global__ void zarc_zdec_predef(uint16_t *out);
 // stage 2 with the tables shared by a wave's 64 blocks in LDS (Repeat_Mode / equal descriptions); sets wave_flag[wave] where they do not fit
 __global__ void zarc_zdec_seqs_shared(const uint8_t *frames_base, const uint64_t *frame_off, uint64_t n_slots, const uint64_t *slot_prefix,
                                       ZdecBlock *zblocks, const uint64_t *seq_index, uint64_t *seqs, uint32_t *fast, uint64_t slot_base,

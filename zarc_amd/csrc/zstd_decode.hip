@@ -1527,7 +1527,8 @@ __device__ int make_seq_table(uint16_t *tab, int t, const SeqHeader &own, const 
 __global__ void __launch_bounds__(64) zarc_zdec_seqs(const uint8_t *__restrict__ frames_base, const uint64_t *__restrict__ frame_off, uint64_t n_slots,
                                                      const uint64_t *__restrict__ slot_prefix, ZdecBlock *__restrict__ zblocks,
                                                      const uint64_t *__restrict__ seq_index, uint64_t *__restrict__ seqs, uint16_t *__restrict__ tables,
-                                                     uint32_t *__restrict__ fast, uint64_t slot_base, const uint32_t *__restrict__ wave_flag)
+                                                     uint32_t *__restrict__ fast, uint64_t slot_base, const uint32_t *__restrict__ wave_flag,
+                                                     const uint16_t *__restrict__ predef)
 {
     if (wave_flag && !wave_flag[blockIdx.x]) return; // (launched with 64 lanes per workgroup then: the flags are per 64 slots)
     const uint64_t s = slot_base + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; // slots [slot_base, n_slots); waves may be partly filled (engine.hip)
@@ -1540,14 +1541,31 @@ __global__ void __launch_bounds__(64) zarc_zdec_seqs(const uint8_t *__restrict__
     const uint32_t end = zb.payload + zb.size;
     uint16_t *tab = tables + s * (uint64_t)ZDEC_TABLE_CELLS;
     uint16_t *const tabs[3] = {tab, tab + 1024, tab + 512}; // LL, OF, ML
+    const uint16_t *use[3] = {tabs[0], tabs[1], tabs[2]};
     SeqHeader own;
     bool ok = scan_seq_header(src, zb.seq_hdr, end, &own);
     int al[3] = {0, 0, 0};
     for (int t = 0; t < 3 && ok; t++) {
-        al[t] = make_seq_table(tabs[t], t, own, src, s, f, slot_prefix, zblocks);
+        uint32_t mode, off, len;
+        uint64_t owner;
+        ok = seq_table_source(t, own, src, s, f, slot_prefix, zblocks, &mode, &off, &len, &owner);
+        if (!ok) break;
+        if (mode == 0 && predef) { // the predefined distributions: one table for everybody, built once per handle (small blocks use little else)
+            use[t] = predef + (t == 0 ? ZDEC_PREDEF_LL : (t == 1 ? ZDEC_PREDEF_OF : ZDEC_PREDEF_ML));
+            al[t] = t == 1 ? 5 : 6;
+            continue;
+        }
+        al[t] = build_seq_table(tabs[t], t, mode, src + off, mode == 2 ? len : (mode == 1 ? 1u : 0u));
         if (al[t] < 0) ok = false;
     }
-    seq_chain<const uint16_t *>(ok, src, zb, own, end, tabs[0], tabs[1], tabs[2], al[0], al[1], al[2], seqs + seq_index[s], zblocks + s, fast + f);
+    seq_chain<const uint16_t *>(ok, src, zb, own, end, use[0], use[1], use[2], al[0], al[1], al[2], seqs + seq_index[s], zblocks + s, fast + f);
+}
+
+// the three predefined decode tables (RFC 8878 3.1.1.3.2.2), built once per handle: LL at 0 (64 cells), OF at 64 (32), ML at 96 (64)
+__global__ void zarc_zdec_predef(uint16_t *__restrict__ out)
+{
+    const int t = (int)threadIdx.x;
+    if (t < 3) (void)build_seq_table(out + (t == 0 ? ZDEC_PREDEF_LL : (t == 1 ? ZDEC_PREDEF_OF : ZDEC_PREDEF_ML)), t, 0u, nullptr, 0u);
 }
 
 // Stage 2 with the tables of a wave's 64 blocks SHARED in LDS.  The engine's own frames code the eight blocks of a 1 MiB entry with
