@@ -107,10 +107,10 @@ def check_levels(engine, oracle, corpus, libzstds, big):
     table only), 2..8 the level-3 finder, 9..14 the deep finder, 15..22 the deep finder with two more live rounds.  Every tier bit-exact
     against the model at the same level, valid for the oracle decoder and libzstd; levels of one tier give the same bytes."""
     cases = encode_cases(corpus, big)
-    names = [k for k in ("k0_64k", "k1_64k", "k0_200k", "far_repeat", "per3", "cold_hot", "abc", "empty") if k in cases] + (["k0_4m", "far_2m3"] if big else [])
+    names = [k for k in ("k0_64k", "k1_64k", "k0_200k", "far_repeat", "per3", "abc", "empty") if k in cases] + (["cold_hot", "k0_4m", "far_2m3"] if big else [])
     frames = {}
     try:
-        for level in (1, -1, -7, 2, 9, 15, 22):
+        for level in ((1, -1, -7, 2, 9, 15, 22) if big else (1, -7, 2, 9, 15)):
             engine.set_parameter(_lib.P_COMPRESSION_LEVEL, level)
             res = engine.pack([cases[k] for k in names])
             frames[level] = [f for f, _ in res]
@@ -122,8 +122,9 @@ def check_levels(engine, oracle, corpus, libzstds, big):
                 for z in libzstds:
                     got, err = z.decompress(frame, len(raw))
                     assert got == raw, (k, level, z.version, err)
-        assert frames[1] == frames[-1] == frames[-7] and frames[15] == frames[22]
-        assert frames[1] != frames[2] and frames[2] != frames[9]
+        assert frames[1] == frames[-7] and frames[1] != frames[2] and frames[2] != frames[9]
+        if big:
+            assert frames[1] == frames[-1] and frames[15] == frames[22]
     finally:
         engine.set_parameter(_lib.P_COMPRESSION_LEVEL, 3)
 

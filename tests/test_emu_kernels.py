@@ -59,7 +59,7 @@ def test_emu_unpack_in_size_groups(emu_engine, oracle, corpus, golden_frames):
     zarc_gpu_unpack_batch_device); by itself it does so only for batches with large frames.  Forced here on small ones: golden
     frames, error statuses (the inline decoder runs per group), fuzzed frames and round trips must not change, and results must
     come back in the caller's order."""
-    for g in (2, 3, 4):
+    for g in (2, 3):
         emu_engine.set_parameter(_lib.PX_DEC_GROUPS, g)
         try:
             pc.check_unpack_golden(emu_engine, oracle, corpus, golden_frames, limit=70000)
