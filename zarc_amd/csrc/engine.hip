@@ -160,9 +160,6 @@ ZgeParams derive_params(const zarc_gpu_params &p)
     if (deep && level >= 15) z.rep_pass = 4; // levels 15 .. 22: two more rounds of the live recent-offset pass (a run-time count: the same kernel)
     if (level <= 1) { // level 1 and the negative levels: the fast finder (zarc_zge_match_fast) -- the near table alone, no lazy step, no extension round
         z.far_log = 0; z.rep_pass = 0; z.lazy = 0;
-#if defined(ZGE_EXP) && ZGE_EXP == 3
-        z.lazy = 1; // timing experiment: what the lazy step costs the fast finder
-#endif
     }
     z.dbg = diag_env("ZARC_GPU_DBG", 0); // timing-only ablations (outputs invalid when set): diagnostic build only
     return z;
@@ -558,11 +555,7 @@ int pack_device_impl(zarc_gpu_t *h, size_t n, const void *d_src_base, const uint
         P.far_step_log != (dp ? 1 : 5) || P.far_res_log != (dp ? 0 : 2) || (P.far_short != 0) != dp || P.long_log != 13 ||
         P.near16 != (dp ? 0 : 1) || P.short_log != (dp ? 13 : 15) || P.far_cdc_log != (dp ? 0 : 4) || P.lazy2_delta != (dp ? 5 : 0) ||
         P.rep_pass != (dp ? (P.level >= 15 ? 4 : 2) : (fp ? 0 : 1)) || P.live_reps != (dp ? 1 : 0) || P.ext_cap != 960 || P.far_cap != 0 || P.cont_cap != (dp ? 960 : 0) ||
-        P.far_back != 48 || P.far_skip != (dp ? 0 : 64)
-#if !defined(ZGE_EXP)
-        || (fp && P.lazy)
-#endif
-        ) { set_error(h, "internal: encoder parameters differ from the compiled-in ones"); return ZARC_GPU_E_PARAM; }
+        P.far_back != 48 || P.far_skip != (dp ? 0 : 64) || (fp && P.lazy)) { set_error(h, "internal: encoder parameters differ from the compiled-in ones"); return ZARC_GPU_E_PARAM; }
     uint64_t need = 0;
     for (size_t i = 0; i < n; i++) {
         if (src_off[i] % ZARC_GPU_ALIGN) { set_error(h, "entry offset not 16-byte aligned"); return ZARC_GPU_E_PARAM; }

@@ -124,13 +124,7 @@ __device__ __forceinline__ void atomic_max_l2(uint32_t *p, uint32_t v)
 #ifdef ZARC_HIPEMU
     if (*p < v) *p = v;
 #else
-#if defined(ZGE_EXP) && ZGE_EXP == 1
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // timing experiment: a plain (sc1) store instead of the atomic
-#elif defined(ZGE_EXP) && ZGE_EXP == 2
-    *p = v;                                                               // timing experiment: an ordinary store
-#else
     (void)__hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
 #endif
 }
 // wait until every vector-memory operation this wave has issued (loads, stores, atomics) is complete

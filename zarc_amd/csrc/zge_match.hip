@@ -1095,11 +1095,7 @@ __global__ void __launch_bounds__(512, 4) zarc_zge_match(ZgeParams P, const uint
                                                       uint32_t *__restrict__ far_scratch)
 {
     __shared__ MatchLds<15, true> L;
-#if defined(ZGE_EXP) && ZGE_EXP == 4
-    zge_match_body<15, 5, 12, 16, 1, false, 5, 2, 64, 48, false, true, 4, 5, 0, false, 0, false>(L, P, src_base, src_off, src_len, order, units, n_units, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch); // timing experiment: no extension round
-#else
     zge_match_body<15, 5, 12, 16, 1, false, 5, 2, 64, 48, false, true, 4, 5, 0, false, 0, true>(L, P, src_base, src_off, src_len, order, units, n_units, block_prefix, blocks, seq_scratch, lit_scratch, queue, far_scratch);
-#endif
 }
 
 // The fast finder (level 1 and the negative levels): the level-3 finder's 16-bit near table, follower runs and recent-offset guesses,

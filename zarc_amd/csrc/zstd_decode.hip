@@ -37,18 +37,7 @@ typedef const uint16_t __attribute__((address_space(3))) *ZDEC_LDS_TAB; // a poi
 #endif
 constexpr int SEQ_BATCH = 64;
 
-__constant__ const uint32_t D_LL_BASE[36] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18,
-                                             20, 22, 24, 28, 32, 40, 48, 64, 128, 256, 512, 1024, 2048,
-                                             4096, 8192, 16384, 32768, 65536};
-__constant__ const uint8_t D_LL_BITS[36] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1,
-                                            1, 1, 2, 2, 3, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
-__constant__ const uint32_t D_ML_BASE[53] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19,
-                                             20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34,
-                                             35, 37, 39, 41, 43, 47, 51, 59, 67, 83, 99, 131, 259, 515,
-                                             1027, 2051, 4099, 8195, 16387, 32771, 65539};
-__constant__ const uint8_t D_ML_BITS[53] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
-                                            0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1,
-                                            2, 2, 3, 3, 4, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+// (literal-length / match-length baselines and extra bits are worked out arithmetically: ll_code_info / ml_code_info below)
 __constant__ const int8_t D_LL_DEFAULT[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2,
                                               2, 2, 2, 2, 2, 2, 2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1};
 __constant__ const int8_t D_ML_DEFAULT[53] = {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1,
