@@ -842,6 +842,7 @@ int zarc_gpu_pack_batch_device_dedup(zarc_gpu_t *h, size_t n, const void *d_src_
 // descending size and dealt into up to DEC_GROUPS groups of equal bytes, each group with its own pair of streams: the frame pass and
 // the hashes of the large frames start as soon as THEIR sequences and literals are decoded and run beside the earlier stages of the
 // groups behind them.  Per-frame arrays are uploaded in that order (group = index range = slot range); results go back in the caller's.
+} // extern "C"
 namespace {
 constexpr int UNPACK_SPLIT = -1000; // internal: the decoder's scratch for this batch exceeds the budget, run it in two parts
 
@@ -1310,6 +1311,7 @@ int unpack_device_split(zarc_gpu_t *h, size_t n, const void *d_frames_base, cons
     return ZARC_GPU_OK;
 }
 } // namespace
+extern "C" {
 
 int zarc_gpu_unpack_batch_device(zarc_gpu_t *h, size_t n, const void *d_frames_base, const uint64_t *frame_off, const uint64_t *frame_len,
                                  void *d_dst_base, const uint64_t *dst_off, const uint64_t *raw_len, const uint8_t *expect, uint8_t *digest,
@@ -1330,6 +1332,7 @@ int zarc_gpu_unpack_batch_device(zarc_gpu_t *h, size_t n, const void *d_frames_b
 // Chunks are large (2 GiB of content for pack, 4 GiB for unpack): the kernels need thousands of frames in flight to fill the
 // chip (a 1 MiB frame is a ~10 ms serial chain for one workgroup / wave), measured: 256 MiB chunks halve the throughput.
 // SURVEY.md 8 row f4.
+} // extern "C"
 namespace {
 
 // A byte range of the caller's memory and where it sits in a flat device range
@@ -1498,6 +1501,7 @@ std::vector<Chunk> make_chunks(size_t n, const std::vector<uint64_t> &in_sz, con
 }
 
 } // namespace
+extern "C" {
 
 int zarc_gpu_blake3_batch(zarc_gpu_t *h, size_t n, const void *const *src, const size_t *len, uint8_t (*digest)[ZARC_GPU_DIGEST_LEN])
 {
