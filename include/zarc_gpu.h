@@ -143,7 +143,7 @@ int zarc_gpu_set_parameter(zarc_gpu_t *h, int param_id, int value);
 void zarc_gpu_get_params(const zarc_gpu_t *h, zarc_gpu_params *out);
 /* Encoder::enable_compression */
 void zarc_gpu_enable_compression(zarc_gpu_t *h, int compress);
-/* Worst-case frame size for an n-byte entry (all raw blocks): n + 3*max(1,ceil(n/131072)) + 18,
+/* Worst-case frame size for an n-byte entry (all raw blocks): n + 3*max(1,ceil(n/65536)) + 18,
  * rounded up to ZARC_GPU_ALIGN.  The reference's Vec capacity rule (lowlevel_frames.rs:21) is smaller
  * than libzstd's own bound; this one never fails. */
 size_t zarc_gpu_bound(size_t n);

@@ -10,7 +10,7 @@
 extern "C" {
 #endif
 
-#define ZGE_BLOCK (128 * 1024)
+#define ZGE_BLOCK (64 * 1024) /* zarc_kernels.h: ZARC_BLOCK -- the encoder's blocks (round 4: 64 KiB; the format allows 128) */
 #define ZGE_SPLIT_MIN ((size_t)4 << 20) /* zarc_kernels.h: ZARC_SPLIT_MIN */
 #define ZGE_MIN_HUF_LITERALS 64
 

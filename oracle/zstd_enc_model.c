@@ -511,9 +511,9 @@ static void choose_table(seq_table_choice *c, const uint32_t *count, int maxsym,
 }
 
 /* Shared sequence tables (Repeat_Mode, RFC 8878 3.1.1.3.2.1: "the table used in the previous Compressed_Block with
- * Number_of_Sequences > 0 will be used again").  The blocks of a frame are taken in GROUPS of ZGE_TABLE_GROUP (block index / 8: the eight
- * blocks of a 1 MiB entry are one group).  Per table type (LL, OF, ML) a group may code all its blocks with ONE table, normalised from
- * the SUM of the blocks' code histograms: the first block describes it, the others say Repeat.  That saves seven descriptions, and --
+ * Number_of_Sequences > 0 will be used again").  The blocks of a frame are taken in GROUPS of ZGE_TABLE_GROUP (block index / 16: the sixteen
+ * 64 KiB blocks of a 1 MiB entry are one group).  Per table type (LL, OF, ML) a group may code all its blocks with ONE table, normalised from
+ * the SUM of the blocks' code histograms: the first block describes it, the others say Repeat.  That saves fifteen descriptions, and --
  * the point for the engine's decoder -- the blocks of an entry share one table set, which zstd_decode.hip keeps in LDS for the whole
  * wave instead of one 2.5 KiB table set per block in HBM.  Taken when it costs at most 1/64 more table-coded bits than the blocks' own
  * best choices (the sum's cost is linear in the counts: one dist_cost call).
@@ -523,7 +523,7 @@ static void choose_table(seq_table_choice *c, const uint32_t *count, int maxsym,
  * describes the table again.  A block whose codes of one type are all equal keeps RLE mode for that type and breaks that type's chain
  * the same way.  Blocks without sequences, RLE blocks and blocks whose literals failed to code take no part: they leave the decoder's
  * tables alone. */
-#define ZGE_TABLE_GROUP 8
+#define ZGE_TABLE_GROUP 16
 typedef struct {
     int active;                /* the block has sequences to code (and its literals section exists) */
     uint32_t nseq;

@@ -49,8 +49,8 @@ def encode_cases(corpus, big):
     c = {"empty": b"", "one": b"a", "abc": b"abc" * 9, "zeros": bytes(300000), "rand": corpus.entry(3, 70000, 3),
          "k0_1000": corpus.entry(0, 1000, 0), "k0_64k": corpus.entry(4, 65536, 0), "k1_64k": corpus.entry(5, 65536, 1),
          "k2_64k": corpus.entry(6, 65536, 2), "k0_200k": corpus.entry(8, 200000, 0), "k1_131073": corpus.entry(9, 131073, 1),
-         # ten blocks = two table groups (eight blocks share their sequence tables: Repeat_Mode), an RLE block and a stretch of random bytes
-         # inside the first group (blocks that take no part / break the chain)
+         # eighteen 64 KiB blocks = two table groups (sixteen blocks share their sequence tables: Repeat_Mode), RLE blocks and a stretch of
+         # random bytes inside the first group (blocks that take no part / break the chain)
          "grp_10blk": corpus.entry(50, 3 * 131072, 2) + bytes(131072) + corpus.entry(51, 131072 + 70000, 3) + corpus.entry(52, 4 * 131072 - 70000 + 99, 0),
          "sparse": bytes(rnd.randrange(256) if i % 7 else 0 for i in range(100000)),
          "runs": make_golden.recipe_bytes({"kind": "runs", "n": 120000, "seed": 9}, corpus),

@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol(product_lib):
 def test_bound_and_error_names(product_lib):
     from zarc_amd import _lib
     lib = _lib.load(product_lib)
-    assert lib.zarc_gpu_bound(0) == 32 and lib.zarc_gpu_bound(65536) == 65568
+    assert lib.zarc_gpu_bound(0) == 32 and lib.zarc_gpu_bound(65536) == 65568 and lib.zarc_gpu_bound(131073) == 131104   # three 64 KiB blocks
     assert lib.zarc_gpu_bound(131073) >= 131073 + 6 + 18
     assert lib.zarc_gpu_frame_status_name(1) == b"Data corruption detected"
     assert lib.zarc_gpu_frame_status_name(2) == b"Restored data doesn't match checksum"

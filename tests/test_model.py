@@ -70,7 +70,7 @@ def test_model_cold_stretches_keep_the_ratio_on_mixed_content(oracle, corpus, li
     assert rc == 0 and out == mixed and used == len(frame)
     assert len(frame) <= len(z.compress(mixed, 3, 1)) * 1.05
     rnd = corpus.entry(7, 1 << 20, 3)
-    assert len(oracle.zge_encode(rnd)) == len(rnd) + 4 + 1 + 4 + 3 * 8 + 4   # magic, descriptor, size, 8 raw-block headers, checksum
+    assert len(oracle.zge_encode(rnd)) == len(rnd) + 4 + 1 + 4 + 3 * 16 + 4   # magic, descriptor, size, 16 raw-block headers (64 KiB blocks), checksum
 
 
 def test_model_ratio_on_real_data(oracle, libzstd15, libzstds, real_items):
@@ -93,10 +93,10 @@ def test_model_ratio_on_real_data(oracle, libzstd15, libzstds, real_items):
 
 
 def test_model_joins_the_pieces_of_long_matches(oracle):
-    """4 MB of period 200: one sequence per block once the 256-byte pieces are joined (round 1 emitted 15 166 sequences, 28x libzstd)."""
+    """4 MB of period 200: one sequence per 64 KiB block once the 256-byte pieces are joined (round 1 emitted 15 166 sequences, 28x libzstd)."""
     raw = bytes(range(200)) * 20000
     frame, st = oracle.zge_encode(raw, stats=True)
-    assert st.seqs == st.blk_comp == 31 and len(frame) < 700
+    assert st.seqs == st.blk_comp == 62 and len(frame) < 1200   # (64 KiB blocks since round 4: 62 of them)
 
 
 def test_model_long_far_repeats_with_far_cap_and_continuation_guess(oracle, corpus, libzstds):

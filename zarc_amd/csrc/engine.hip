@@ -866,7 +866,7 @@ int unpack_device_once(zarc_gpu_t *h, size_t n, const void *d_frames_base, const
     if ((rc = upload_u64(h, h->d_raw_len, raw_len.data(), n))) return rc;
     { std::vector<uint32_t> ident(n); std::iota(ident.begin(), ident.end(), 0u); if ((rc = upload_u32(h, h->d_order, ident.data(), n))) return rc; } // the queues walk the (sorted) indices
     const size_t dec_grid = std::min<size_t>(n, (size_t)h->num_cus * 16); // 4 waves per SIMD (launch bounds of the frame kernels: 128 VGPRs, no spills)
-    ZHIP(h->d_declit.reserve(dec_grid * (size_t)(ZARC_BLOCK + 64)));
+    ZHIP(h->d_declit.reserve(dec_grid * (size_t)(ZARC_BLOCK_MAX + 64)));
     ZHIP(h->d_queue.reserve(256));
     ZHIP(h->d_status.reserve(n * 4));
     ZHIP(h->d_stored_ck.reserve(n * 8));
@@ -1081,7 +1081,7 @@ int unpack_device_once(zarc_gpu_t *h, size_t n, const void *d_frames_base, const
                     ZHIP(hipEventRecord(h->ev_join3, h->stream3));
                 }
                 if (split > s0) {
-                    // Waves whose 64 blocks share their tables (the engine's own frames: one table set per group of eight blocks; libzstd's
+                    // Waves whose 64 blocks share their tables (the engine's own frames: one table set per group of sixteen 64 KiB blocks; libzstd's
                     // Repeat_Mode blocks) decode with the tables in LDS; the others raise their flag and are done by the second launch with a
                     // table set per block in HBM scratch, as before.
                     // (a batch of small frames -- fewer than four blocks per frame on average -- has nothing to share: a workgroup's 32 blocks
@@ -1193,7 +1193,7 @@ int unpack_device_once(zarc_gpu_t *h, size_t n, const void *d_frames_base, const
         hipLaunchKernelGGL(zarc_zstd_decode, dim3((unsigned)grid_g), dim3(64), (size_t)diag_env("ZARC_GPU_DEC_PADLDS", 0), sa,
                            (const uint8_t *)d_frames_base, h->d_frame_off.as<uint64_t>(), h->d_frame_len.as<uint64_t>(), (uint8_t *)d_dst_base,
                            h->d_dst_off.as<uint64_t>(), h->d_raw_len.as<uint64_t>(), h->d_order.as<uint32_t>() + f0, (uint32_t)ng,
-                           h->d_declit.as<uint8_t>() + (size_t)g * (dec_grid / (size_t)groups) * (size_t)(ZARC_BLOCK + 64),
+                           h->d_declit.as<uint8_t>() + (size_t)g * (dec_grid / (size_t)groups) * (size_t)(ZARC_BLOCK_MAX + 64),
                            h->d_status.as<int32_t>(), h->d_stored_ck.as<uint32_t>(), dec_dbg, h->d_queue.as<uint32_t>() + 2 * g + 1,
                            fastpath ? h->d_fast.as<uint32_t>() : (const uint32_t *)nullptr);
         ZHIP(hipGetLastError());

@@ -9,7 +9,14 @@ enum {
     ZARC_FRAME_DSTSIZE = 4, ZARC_FRAME_BAD_MAGIC = 5, ZARC_FRAME_UNSUPPORTED = 6, ZARC_FRAME_SRCSIZE = 7
 };
 
-constexpr uint32_t ZARC_BLOCK = 128 * 1024;          // Zstandard Block_Maximum_Size
+constexpr uint32_t ZARC_BLOCK_MAX = 128 * 1024;      // Zstandard Block_Maximum_Size: what the decoder must take, what store-mode frames use
+// The ENCODER's blocks are 64 KiB (round 4).  A block is the unit of everything that is serial in the format -- one Huffman table for its
+// literals, one FSE state chain for its sequences -- so halving it doubles the decoder's parallelism (sequence and literal chains half as
+// long) and lets the literal statistics follow the data (libzstd 1.5 splits blocks where they change: its frame of a libtorch slice has
+// 112 blocks for 2 MiB).  Model, ours / libzstd -3, 128 -> 64 KiB: ELF tables 1.015 -> 0.999, package.json 1.033 -> 1.022, machine code
+// 1.039 -> 1.033, the libtorch string tables 1.067 -> 1.049 (inside the contract), text +0.02 .. 0.1 %, GPU code objects 1.024 -> 1.038;
+// 32 KiB: text +0.3 %, code objects 1.07.  The sequence tables are shared by groups of 16 blocks (1 MiB, as before).
+constexpr uint32_t ZARC_BLOCK = 64 * 1024;
 constexpr uint32_t ZARC_MAX_SEQ = ZARC_BLOCK / 3 + 8; // sequences per block (every match >= 3 bytes)
 
 // ---- encoder tuning (mirrors oracle/zge_model.h zge_params; plain ints so the struct can be passed by value)
@@ -39,7 +46,7 @@ struct ZgeBlock {
 // Sequence-table plan of one block (entropy stage, multi-block frames): written by pass 1 (code histograms, the block's own best table
 // per type), settled per group of ZGE_TABLE_GROUP blocks by zarc_zge_plan (one shared table per type where that is cheap: the first
 // block describes it, the others say Repeat_Mode), read by pass 2 (model: zstd_enc_model.c, seq_plan / seq_plan_group).
-constexpr uint32_t ZGE_TABLE_GROUP = 8;
+constexpr uint32_t ZGE_TABLE_GROUP = 16;
 struct ZgePlanTable {
     int16_t norm[64];   // normalised counts of the table to code with (pass 1: the block's own choice; zarc_zge_plan: the group's)
     uint8_t desc[80];   // its FSE description (mode 2)

@@ -115,10 +115,10 @@ __global__ void __launch_bounds__(256) zarc_zge_store(const uint8_t *__restrict_
         for (int i = 0; i < 8; i++) dst[6 + i] = (uint8_t)(n >> (8 * i));
     }
     uint64_t pos = 14;
-    const uint64_t nblocks = n == 0 ? 1 : (n + ZARC_BLOCK - 1) / ZARC_BLOCK;
+    const uint64_t nblocks = n == 0 ? 1 : (n + ZARC_BLOCK_MAX - 1) / ZARC_BLOCK_MAX; // store mode: the format's largest blocks
     for (uint64_t b = 0; b < nblocks; b++) {
-        const uint64_t at = b * ZARC_BLOCK;
-        const uint32_t cnt = (uint32_t)(n - at > ZARC_BLOCK ? ZARC_BLOCK : n - at);
+        const uint64_t at = b * ZARC_BLOCK_MAX;
+        const uint32_t cnt = (uint32_t)(n - at > ZARC_BLOCK_MAX ? ZARC_BLOCK_MAX : n - at);
         const uint32_t hdr = (b + 1 == nblocks ? 1u : 0u) | (cnt << 3); // type 0 = Raw
         if (tid == 0) { dst[pos] = (uint8_t)hdr; dst[pos + 1] = (uint8_t)(hdr >> 8); dst[pos + 2] = (uint8_t)(hdr >> 16); }
         pos += 3;

@@ -1,7 +1,7 @@
 // zarc_amd/csrc/zge_entropy.hip -- encoder stage 2: Huffman literals + FSE sequences -> block bytes (gfx950).
 //
 // Part of the replacement for `CCtx::compress2` at crates/zarc/src/encode/lowlevel_frames.rs:29-31.
-// One wave per 128 KiB block (blocks are independent here: no Treeless / Repeat modes are emitted and
+// One wave per block (64 KiB since round 4; blocks are independent here but for the table plan below, and
 // the repcode history restarts per block), so tens of thousands of waves are in flight and the serial
 // pieces (tree construction, table normalisation, FSE state chains) are latency-hidden by occupancy:
 //   - byte histograms with LDS atomics, symbol ranking by counting (256 symbols, 4 per lane)
@@ -1135,7 +1135,7 @@ __global__ void __launch_bounds__(64, 5) zarc_zge_entropy_p2(uint32_t n_blocks, 
 // hands the table on only if an upper bound of its coded size (every state transition at its symbol's larger bit count) is below its
 // raw size, i.e. it cannot end up a raw block, whose tables the decoder never sees; the block behind any other describes the table
 // again.  Blocks that keep RLE mode for a type break that type's chain the same way.  Costs fit 32 bits: a group holds at most
-// 8 x 43 690 sequences at 9 x 256 units each.
+// 16 x 21 845 sequences at 9 x 256 units each.
 __global__ void __launch_bounds__(64) zarc_zge_plan(uint32_t n_blocks, const ZgeBlock *__restrict__ blocks, ZgePlan *__restrict__ plans,
                                                     const uint32_t *__restrict__ group_start /* first block slot of each group of a multi-block frame */)
 {

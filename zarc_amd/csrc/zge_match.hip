@@ -7,7 +7,7 @@
 // near hash table(s) of a frame -- level 3: one table of 2^15 16-bit entries on the 5-byte hash; level >= 9: an 8-byte "long" and a
 // 4-byte "short" hash table of 2^13 u32 entries each, an entry packing (position+1) << 10 | 10 hash check bits -- are 64 KiB of LDS
 // and stay there for the whole frame, so matches reach back across all earlier blocks (64 KiB / the 2 MiB table segment).  The kernel is bound by VALU issue and by barrier / L2 waits, not by HBM.
-// A block (<= 128 KiB) is swept in tiles of 1024 positions, two positions per thread (t and t+512):
+// A block (<= 64 KiB: ZARC_BLOCK) is swept in tiles of 1024 positions, two positions per thread (t and t+512):
 //   S0/S1 the tile's window (recent-offset range before it, compare overrun after it) goes to LDS -- the dword of the
 //         NEXT tile is requested now and parked in a register; every position is hashed (32-bit multiplies)
 //   S2    ordered lookup + insert, one wave per table, 64 positions per step: LDS executes one wave's instructions

@@ -1557,7 +1557,7 @@ __global__ void zarc_zdec_predef(uint16_t *__restrict__ out)
     if (t < 3) (void)build_seq_table(out + (t == 0 ? ZDEC_PREDEF_LL : (t == 1 ? ZDEC_PREDEF_OF : ZDEC_PREDEF_ML)), t, 0u, nullptr, 0u);
 }
 
-// Stage 2 with the tables of a wave's 64 blocks SHARED in LDS.  The engine's own frames code the eight blocks of a 1 MiB entry with
+// Stage 2 with the tables of a wave's 64 blocks SHARED in LDS.  The engine's own frames code the sixteen 64 KiB blocks of a 1 MiB entry with
 // one table per type (zge_entropy.hip: zarc_zge_plan; libzstd repeats tables as well): blocks whose tables come from the same
 // description (their own, or the same earlier block's through Repeat_Mode; the predefined distributions; an RLE symbol) use one copy.
 // A wave's 64 consecutive block slots typically need 8 table sets instead of 64: they fit LDS (ZDEC_SH_SETS tables per type, 25 KiB per
@@ -1875,11 +1875,30 @@ __device__ __forceinline__ uint32_t canon_symbol(const HufCanon &C, int max_bits
     *nbits = (uint32_t)max_bits + 1u - w;
     return C.sorted[ad + (int32_t)(x >> (w - 1))];
 }
+// The weight of a cell x (x = the next max_bits bits) is 1 + the number of weights ww >= 2 whose first cell start[ww] is <= x (the cells are
+// ordered by weight, start[] rises): ten compares against values the lane keeps in registers for the whole stream.  (Until round 4 a
+// 128-entry index gave the weight in one LDS access where its bucket lay inside one weight and a loop over start[] in LDS otherwise -- with
+// 64 streams in lockstep some lane took the loop at nearly every symbol, and every lane waited for its eleven LDS reads.)
+struct CanonStarts { uint32_t st[10]; };
+__device__ __forceinline__ void canon_starts(const HufCanon &C, int max_bits, CanonStarts &R)
+{
+#pragma unroll
+    for (int ww = 2; ww <= 11; ww++) R.st[ww - 2] = ww <= max_bits ? (uint32_t)C.start[ww] : 0xFFFFFFFFu;
+}
+__device__ __forceinline__ uint32_t canon_symbol_r(const HufCanon &C, const CanonStarts &R, int max_bits, uint32_t x, uint32_t *nbits)
+{
+    uint32_t w = 1;
+#pragma unroll
+    for (int k = 0; k < 10; k++) w += x >= R.st[k] ? 1u : 0u;
+    *nbits = (uint32_t)max_bits + 1u - w;
+    return C.sorted[(int32_t)C.adj[w] + (int32_t)(x >> (w - 1))];
+}
 __device__ bool huf_decode_stream_canon(const HufCanon &C, int max_bits, const uint8_t *src, uint32_t len, uint8_t *out, uint32_t nout)
 {
     BackBits b;
     if (!b.init(src, len)) return false;
-    const int sh = max_bits - (max_bits < 7 ? max_bits : 7);
+    CanonStarts R;
+    canon_starts(C, max_bits, R);
     uint32_t i = 0;
     for (; i + 8 <= nout; i += 8) {
         uint64_t w = 0;
@@ -1889,7 +1908,7 @@ __device__ bool huf_decode_stream_canon(const HufCanon &C, int max_bits, const u
             // refill would have some lane of the wave waiting for its load at nearly every symbol
             if ((j & 3) == 0) b.refill();
             uint32_t nb;
-            const uint32_t sym = canon_symbol(C, max_bits, sh, (uint32_t)((b.c << b.used) >> (64 - max_bits)), &nb);
+            const uint32_t sym = canon_symbol_r(C, R, max_bits, (uint32_t)((b.c << b.used) >> (64 - max_bits)), &nb);
             b.skip((int)nb);
             w |= (uint64_t)sym << (8 * j);
         }
@@ -1897,7 +1916,7 @@ __device__ bool huf_decode_stream_canon(const HufCanon &C, int max_bits, const u
     }
     for (; i < nout; i++) {
         uint32_t nb;
-        out[i] = (uint8_t)canon_symbol(C, max_bits, sh, b.peek(max_bits), &nb);
+        out[i] = (uint8_t)canon_symbol_r(C, R, max_bits, b.peek(max_bits), &nb);
         b.skip((int)nb);
     }
     return b.bitpos == 0;
