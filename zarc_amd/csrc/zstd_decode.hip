@@ -32,8 +32,10 @@ constexpr int BLOCK_MAX = 128 * 1024;
  // zarc_zdec_seqs_shared: tables per type a wave keeps in LDS
 #ifdef ZARC_HIPEMU
 typedef const uint16_t *ZDEC_LDS_TAB;
+typedef const uint32_t *ZDEC_LDS_INFO;
 #else
 typedef const uint16_t __attribute__((address_space(3))) *ZDEC_LDS_TAB; // a pointer the compiler knows to be LDS: ds_read_u16, not flat loads
+typedef const uint32_t __attribute__((address_space(3))) *ZDEC_LDS_INFO;
 #endif
 constexpr int SEQ_BATCH = 64;
 
@@ -173,7 +175,7 @@ struct Bits128 {
     __device__ __forceinline__ uint32_t take(uint32_t k) // 0 <= k <= 32, within the phase's budget
     {
         const uint32_t t = (uint32_t)((hi << u) >> 32);
-        const uint32_t v = k ? t >> (32 - k) : 0u;
+        const uint32_t v = (t >> 1) >> (31u - k); // (k = 0 -> 0 without a select; k <= 31 everywhere: table logs, offset codes <= 27, length codes <= 16 bits)
         u += (int32_t)k;
         bitpos -= (int32_t)k;
         return v;
@@ -236,6 +238,34 @@ __device__ bool fse_build_dtable(uint16_t *tab, const int16_t *norm, int nsym, i
     for (int i = 0; i < T; i++) {
         const uint32_t s = tab[i];
         const uint32_t x = next[s]++;
+        tab[i] = (uint16_t)(s | (x << 6));
+    }
+    return true;
+}
+
+// The same table with ONE scratch array: nn[] holds the normalised counts on entry and the symbols' state counters afterwards.  (For
+// the lanes that build tables side by side with the scratch in LDS: two 64-entry arrays of a lane's own end up as registers selected by
+// compare chains, ~130 instructions per access.)
+__device__ bool fse_build_dtable_inplace(uint16_t *tab, int16_t *nn, int nsym, int al)
+{
+    const int T = 1 << al;
+    int high = T - 1;
+    for (int s = 0; s < nsym; s++) if (nn[s] == -1) tab[high--] = (uint16_t)s;
+    const int step = (T >> 1) + (T >> 3) + 3, mask = T - 1;
+    int pos = 0;
+    for (int s = 0; s < nsym; s++) {
+        const int c = nn[s];
+        for (int i = 0; i < c; i++) {
+            tab[pos] = (uint16_t)s;
+            do { pos = (pos + step) & mask; } while (pos > high);
+        }
+        if (c == -1) nn[s] = 1;
+    }
+    if (pos != 0) return false;
+    for (int i = 0; i < T; i++) {
+        const uint32_t s = tab[i];
+        const uint32_t x = (uint16_t)nn[s];
+        nn[s] = (int16_t)(x + 1);
         tab[i] = (uint16_t)(s | (x << 6));
     }
     return true;
@@ -647,6 +677,26 @@ __device__ int build_seq_table(uint16_t *tab, int t, uint32_t mode, const uint8_
     int nsym = 0, al = 0;
     const int used = fse_read_desc(desc, len, t == 1 ? 8 : 9, max_sym, norm, &nsym, &al);
     if (used <= 0 || !fse_build_dtable(tab, norm, nsym, al, next)) return -1;
+    return al;
+}
+// (scratch: 64 entries the caller provides, see fse_build_dtable_inplace)
+__device__ __forceinline__ int build_seq_table(uint16_t *tab, int t, uint32_t mode, const uint8_t *desc, uint32_t len, int16_t *scratch)
+{
+    const int max_sym = t == 0 ? 35 : (t == 1 ? 31 : 52);
+    if (mode == 0) {
+        const int8_t *def = t == 0 ? D_LL_DEFAULT : (t == 1 ? D_OF_DEFAULT : D_ML_DEFAULT);
+        const int def_n = t == 0 ? 36 : (t == 1 ? 29 : 53), def_al = t == 1 ? 5 : 6;
+        for (int i = 0; i < def_n; i++) scratch[i] = def[i];
+        return fse_build_dtable_inplace(tab, scratch, def_n, def_al) ? def_al : -1;
+    }
+    if (mode == 1) {
+        if (len < 1 || desc[0] > max_sym) return -1;
+        tab[0] = (uint16_t)(desc[0] | (1u << 6));
+        return 0;
+    }
+    int nsym = 0, al = 0;
+    const int used = fse_read_desc(desc, len, t == 1 ? 8 : 9, max_sym, scratch, &nsym, &al);
+    if (used <= 0 || !fse_build_dtable_inplace(tab, scratch, nsym, al)) return -1;
     return al;
 }
 
@@ -1409,72 +1459,72 @@ __device__ __forceinline__ void seq_chain(bool ok, const uint8_t *__restrict__ s
 // and in flight during the table lookups) instead of a refill -- a dependent load and a wait -- behind any of the nine bit fields: with
 // 64 blocks in lockstep every refill site is taken by some lane in every step, and a step then is six to nine memory round trips.  For
 // tables that cost no memory request (LDS).
-template <typename TAB>
+template <class TAB, class INFO>
 __device__ __forceinline__ void seq_chain128(bool ok, const uint8_t *__restrict__ src, const ZdecBlock &zb, const SeqHeader &own, const uint32_t end,
-                                          TAB tl, TAB to, TAB tm, const int al_l, const int al_o, const int al_m, uint64_t *__restrict__ outp,
-                                          ZdecBlock *__restrict__ zslot, uint32_t *__restrict__ fast_f)
+                                          TAB tl, TAB to, TAB tm, const int al_l, const int al_o, const int al_m, INFO info /* seq_code_info(): [0,64) literal lengths, [64,128) match lengths */,
+                                          uint64_t *__restrict__ outp, ZdecBlock *__restrict__ zslot, uint32_t *__restrict__ fast_f)
 {
-    // repeat-offset history, symbolic: hv = offset (hr = 0) or hv = slot | delta << 2 of the history at block start (hr = 1)
-    uint32_t hv0 = 0, hv1 = 1, hv2 = 2, hr0 = 1, hr1 = 1, hr2 = 1;
+    // The step of a sequence is straight-line code: every lane of the wave walks its own block, so a branch some lane takes is a
+    // branch all of them pay for (round 4: 17 branches, 147 + 103 instructions per step -> selects; the code -> baseline / extra-bits
+    // rules come from a 128-entry table in LDS).  Whatever goes wrong sets `bad`, which ends the lane's loop at its next test.
+    // repeat-offset history, symbolic: an offset, or ZDEC_REP_REF | slot | delta << 2 of the history at block start
+    uint32_t h0 = ZDEC_REP_REF | 0u, h1 = ZDEC_REP_REF | 1u, h2 = ZDEC_REP_REF | 2u;
     uint32_t bpos_ = 0, reach_ = 0, msum_ = 0; // output position inside the block, farthest reach in front of it, sum of the match lengths
     if (ok) {
         Bits128 b;
         ok = b.init(src + own.bits_off, end - own.bits_off);
         uint32_t sl = 0, so = 0, sm = 0;
         if (ok) { b.request(); b.settle(); sl = b.take((uint32_t)al_l); so = b.take((uint32_t)al_o); sm = b.take((uint32_t)al_m); ok = b.bitpos >= 0; } // <= 7 + 26 bits
-        for (uint32_t i = 0; i < zb.nseq && ok; i++) {
+        bool bad = !ok;
+        const uint32_t nseq = zb.nseq;
+        for (uint32_t i = 0; i < nseq && !bad; i++) {
             b.request(); // one bitstream window per sequence, in flight during the table lookups
             const uint32_t cl = tl[sl], co = to[so], cm = tm[sm];
-            b.settle();
             const uint32_t ofc = cell_sym(co), mlc = cell_sym(cm), llc = cell_sym(cl);
-            if (ofc > 27 || mlc > 52 || llc > 35) { ok = false; break; } // offsets past the format's largest window: left to the frame pass
-            const uint32_t ofv = (1u << ofc) + b.take(ofc);                // phase 1: <= 7 + 27 + 16 bits
-            uint32_t mbase, mbits, lbase, lbits;
-            ml_code_info(mlc, mbase, mbits);
-            ll_code_info(llc, lbase, lbits);
-            const uint32_t ml = mbase + b.take(mbits);
+            const uint32_t mi = info[64 + mlc], li = info[llc];
+            b.settle();
+            bad = ofc > 27 || mlc > 52 || llc > 35;                        // offsets past the format's largest window: left to the frame pass
+            const uint32_t ofv = (1u << (ofc & 31u)) + b.take(ofc & 31u);  // phase 1: <= 7 + 27 + 16 bits
+            const uint32_t ml = (mi & 0xFFFFFu) + b.take(mi >> 20);
             b.second_phase();                                              // phase 2: <= 16 + 9 + 9 + 8 bits
-            const uint32_t ll = lbase + b.take(lbits);
-            uint32_t ov, orf; // this sequence's offset, same symbolic form
-            if (ofv > 3) { ov = ofv - 3; orf = 0; hv2 = hv1; hr2 = hr1; hv1 = hv0; hr1 = hr0; hv0 = ov; hr0 = orf; }
-            else {
-                const uint32_t idx = ofv - 1 + (ll == 0 ? 1u : 0u);
-                if (idx == 0) { ov = hv0; orf = hr0; }
-                else {
-                    if (idx == 1) { ov = hv1; orf = hr1; }
-                    else if (idx == 2) { ov = hv2; orf = hr2; }
-                    else { // first history entry minus one
-                        ov = hv0; orf = hr0;
-                        if (orf) { if ((ov >> 2) >= ZDEC_MAX_DELTA) { ok = false; break; } ov += 4; } // delta + 1 (only absurd chains are left to the frame pass)
-                        else { if (ov <= 1) { ok = false; break; } ov -= 1; }
-                    }
-                    if (idx > 1) { hv2 = hv1; hr2 = hr1; }
-                    hv1 = hv0; hr1 = hr0;
-                    hv0 = ov; hr0 = orf;
-                }
-            }
+            const uint32_t ll = (li & 0xFFFFFu) + b.take(li >> 20);
+            // this sequence's offset, same symbolic form
+            const bool is_new = ofv > 3;
+            const uint32_t idx = ofv - 1 + (ll == 0 ? 1u : 0u); // repeat codes: 0..3
+            uint32_t c = idx == 1 ? h1 : h0;
+            c = idx == 2 ? h2 : c;
+            const bool cref = (c & ZDEC_REP_REF) != 0, is3 = idx == 3 && !is_new; // first history entry minus one: delta + 1, or offset - 1
+            const bool bad3 = cref ? ((c & ~ZDEC_REP_REF) >> 2) >= ZDEC_MAX_DELTA : c <= 1u; // (only absurd chains are left to the frame pass)
+            c = is3 ? (cref ? c + 4u : c - 1u) : c;
+            bad = bad || (is3 && bad3);
+            const uint32_t o = is_new ? ofv - 3u : c;
+            h2 = (is_new || idx >= 2) ? h1 : h2;
+            h1 = (is_new || idx >= 1) ? h0 : h1;
+            h0 = o;
+            const bool orf = (o & ZDEC_REP_REF) != 0;
+            const uint32_t ov = o & ~ZDEC_REP_REF;
             // where this match's source starts, relative to the block: in front of it by `reach` bytes at most (an offset that still
             // refers to the history at the block's start is not known here)
             bpos_ += ll;
-            if (orf) reach_ = ZDEC_REACH_UNKNOWN; else if (ov > bpos_ && ov - bpos_ > reach_) reach_ = ov - bpos_;
+            const uint32_t before = orf ? ZDEC_REACH_UNKNOWN : (ov > bpos_ ? ov - bpos_ : 0u);
+            reach_ = before > reach_ ? before : reach_;
             bpos_ += ml; msum_ += ml;
             // a plain store: eight steps fill a 64-byte line in L2 before it leaves for HBM.  (The non-temporal form of the HBM-table
             // kernel -- which keeps its tables in L2 -- sends every 8-byte store of every lane to memory on its own, and the step's wait
             // for the bitstream also waits for that store: 40.9 -> 26.6 ms at BASELINE configs[1].)
             outp[i] = zge_pack_seq(ll | (orf ? ZDEC_LL_REF : 0u), ml, ov);
-            if (i + 1 < zb.nseq) {
-                sl = cell_base(cl, al_l) + b.take(cell_nbits(cl, al_l));
-                sm = cell_base(cm, al_m) + b.take(cell_nbits(cm, al_m));
-                so = cell_base(co, al_o) + b.take(cell_nbits(co, al_o));
-            }
-            if (b.bitpos < 0) ok = false;
+            const bool more = i + 1 < nseq; // the last sequence reads no state bits
+            sl = cell_base(cl, al_l) + b.take(more ? cell_nbits(cl, al_l) : 0u);
+            sm = cell_base(cm, al_m) + b.take(more ? cell_nbits(cm, al_m) : 0u);
+            so = cell_base(co, al_o) + b.take(more ? cell_nbits(co, al_o) : 0u);
+            bad = bad || b.bitpos < 0;
         }
-        if (ok && b.bitpos != 0) ok = false;
+        ok = !bad && b.bitpos == 0;
     }
     if (ok) {
-        zslot->rep[0] = hr0 ? (ZDEC_REP_REF | hv0) : hv0;
-        zslot->rep[1] = hr1 ? (ZDEC_REP_REF | hv1) : hv1;
-        zslot->rep[2] = hr2 ? (ZDEC_REP_REF | hv2) : hv2;
+        zslot->rep[0] = h0;
+        zslot->rep[1] = h1;
+        zslot->rep[2] = h2;
         zslot->pad[0] = reach_;
         zslot->pad[1] = zb.lit_len + msum_;
         zslot->state = 1;
@@ -1564,6 +1614,13 @@ __global__ void zarc_zdec_predef(uint16_t *__restrict__ out)
 // wave, six waves per CU), and the three lookups per sequence stop being 64-byte lines from 80 000 tables in HBM / MALL (178 GB per
 // launch at BASELINE configs[1], 11 x the whole path's algorithmic bytes).  A wave that needs more tables of some type than fit
 // sets wave_flag[its index] and leaves: the launch of zarc_zdec_seqs behind this one does its 64 slots the old way.
+// literal-length (code) / match-length (64 + code) code -> baseline | extra bits << 20
+__device__ __forceinline__ uint32_t seq_code_info(uint32_t i)
+{
+    uint32_t base, bits;
+    if (i < 64) ll_code_info(i < 36 ? i : 0u, base, bits); else ml_code_info(i - 64 < 53 ? i - 64 : 0u, base, bits);
+    return base | (bits << 20);
+}
 template <int LANES, int SETS>
 __device__ __forceinline__ void zdec_seqs_shared_body(const uint8_t *__restrict__ frames_base, const uint64_t *__restrict__ frame_off, uint64_t n_slots,
                                                       const uint64_t *__restrict__ slot_prefix, ZdecBlock *__restrict__ zblocks,
@@ -1573,7 +1630,10 @@ __device__ __forceinline__ void zdec_seqs_shared_body(const uint8_t *__restrict_
     __shared__ uint16_t T_ll[SETS][512], T_ml[SETS][512], T_of[SETS][256];
     __shared__ int32_t T_al[3][SETS];
     __shared__ uint32_t lead[3][SETS];
+    __shared__ uint32_t T_info[128];
+    __shared__ int16_t T_scratch[3 * SETS][64];
     const int lane = zd::lane_id();
+    for (int i = lane; i < 128; i += LANES) T_info[i] = seq_code_info((uint32_t)i);
     const uint64_t s = slot_base + (uint64_t)blockIdx.x * LANES + (uint64_t)lane;
     ZdecBlock zb;
     zb.type = 0xFFFFFFFFu; zb.nseq = 0; zb.frame = 0; zb.payload = 0; zb.size = 0; zb.seq_hdr = 0; zb.lit_len = 0;
@@ -1630,7 +1690,7 @@ __device__ __forceinline__ void zdec_seqs_shared_body(const uint8_t *__restrict_
         if (from != 0xFFFFFFFFu) {
             uint16_t *tab = bt == 0 ? &T_ll[bn][0] : (bt == 1 ? &T_of[bn][0] : &T_ml[bn][0]);
             const uint8_t *bsrc = frames_base + frame_off[bf];
-            T_al[bt][bn] = build_seq_table(tab, bt, bmode, bsrc + boff, bmode == 2 ? blen : (bmode == 1 ? 1u : 0u));
+            T_al[bt][bn] = build_seq_table(tab, bt, bmode, bsrc + boff, bmode == 2 ? blen : (bmode == 1 ? 1u : 0u), &T_scratch[lane][0]);
         }
     }
     zd::wave_sync();
@@ -1638,8 +1698,8 @@ __device__ __forceinline__ void zdec_seqs_shared_body(const uint8_t *__restrict_
     int al_l = 0, al_o = 0, al_m = 0;
     if (ok) { al_l = T_al[0][idx[0]]; al_o = T_al[1][idx[1]]; al_m = T_al[2][idx[2]]; ok = al_l >= 0 && al_o >= 0 && al_m >= 0; }
     const uint32_t i0 = ok ? idx[0] : 0u, i1 = ok ? idx[1] : 0u, i2 = ok ? idx[2] : 0u;
-    seq_chain128<ZDEC_LDS_TAB>(ok, src, zb, own, end, (ZDEC_LDS_TAB)&T_ll[i0][0], (ZDEC_LDS_TAB)&T_of[i1][0], (ZDEC_LDS_TAB)&T_ml[i2][0],
-                            al_l, al_o, al_m, seqs + seq_index[s], zblocks + s, fast + f);
+    seq_chain128<ZDEC_LDS_TAB, ZDEC_LDS_INFO>(ok, src, zb, own, end, (ZDEC_LDS_TAB)&T_ll[i0][0], (ZDEC_LDS_TAB)&T_of[i1][0], (ZDEC_LDS_TAB)&T_ml[i2][0],
+                                           al_l, al_o, al_m, (ZDEC_LDS_INFO)&T_info[0], seqs + seq_index[s], zblocks + s, fast + f);
 }
 
 
@@ -1761,33 +1821,88 @@ __global__ void __launch_bounds__(ZDEC_LDS_LANES) zarc_zdec_seqs_lds(const uint8
 }
 
 
-// Huffman literals of the fast path.  One wave per ZDEC_LIT_GROUP consecutive block slots: the wave prepares the blocks'
-// decoders in LDS one after the other (wave-cooperative), then every lane decodes one stream (4 streams x 16 blocks).
+// Huffman literals of the fast path.  One wave per ZDEC_LIT_GROUP consecutive block slots.  The wave stages the blocks' tree
+// descriptions in LDS, sixteen lanes turn them into weights side by side (the FSE-coded weights are a serial chain per block: done
+// one block after the other by lane 0, as until round 4, that chain was 85 % of the kernel's time), the wave builds the sixteen
+// decoders, then every lane decodes one stream (4 streams x 16 blocks).
 // A full 2^11-cell decode table per block would cap a CU at 160 decoding lanes (160 KiB / 4 KiB x 4 streams), so the table
-// is kept in its canonical form (0.55 KiB): cells of the format's table are ordered by weight, then by symbol, and the cells
+// is kept in its canonical form (0.3 KiB): cells of the format's table are ordered by weight, then by symbol, and the cells
 // of weight w start at a multiple of 2^(w-1), hence for a cell x of weight w the symbol is sorted[adj[w] + (x >> (w-1))] with
-// adj[w] = (symbols of lower weight) - (start[w] >> (w-1)).  A 128-entry index over the top bits of x gives (w, adj[w]) in one
-// access wherever its bucket lies inside one weight (always, except among the longest codes); the rest compare against start[].
+// adj[w] = (symbols of lower weight) - (start[w] >> (w-1)); w comes from comparing x with start[] (canon_symbol_r).
 struct HufCanon {
-    uint16_t lut[128];   // w | adj[w] << 4 (signed), 0 = bucket spans several weights
     uint8_t sorted[256]; // symbols by (weight, symbol)
     uint16_t start[12];  // first cell of weight w (start[w] for w = 1 .. table log; beyond: 2^log)
     int16_t adj[12];
 };
+constexpr uint32_t HUF_DESC_MAX = 129; // header byte + at most 127 bytes of FSE-coded weights (or 64 of direct ones)
+struct HufBuild {
+    union {
+        struct {
+            alignas(8) uint8_t desc[144]; // the tree description, staged (the bit reader may look 8 bytes past its end)
+            int16_t norm[64];
+            uint16_t next[64];
+            uint16_t wtab[64];        // FSE table for Huffman weights (accuracy <= 6)
+        };
+        HufCanon canon;               // built from weights[] once the description has been read: the scratch above is dead by then
+    };
+    uint8_t weights[256];
+};
 struct LitLds {
-    Lds build;                                   // construction scratch: weights, FSE table of the weights
-    HufCanon canon[ZDEC_LIT_GROUP];
+    HufBuild blk[ZDEC_LIT_GROUP];
     int32_t bits[ZDEC_LIT_GROUP];                // table log per block, 0 = no decoder
     uint32_t used[ZDEC_LIT_GROUP];               // bytes of the tree description in front of the streams
+    int32_t nw[ZDEC_LIT_GROUP];                  // weights read, 0 = none
+    uint32_t frame[ZDEC_LIT_GROUP];
 };
 
-// weights[0..n) in L.b -> canonical decoder.  Uniform; same validity rules as huf_build_table.  Returns the table log or 0.
-__device__ int huf_build_canon(Lds &L, int n, int lane, HufCanon &C)
+// The tree description B.desc[0..len) -> B.weights, all of it on the calling lane (its own HufBuild).  Returns the bytes the
+// description takes or -1; same rules as huf_read_weights.
+__device__ int huf_read_weights_lane(HufBuild &B, uint32_t len, int *nweights)
+{
+    if (len < 1) return -1;
+    const uint32_t hb = B.desc[0];
+    if (hb >= 128) {
+        const int n = (int)hb - 127, consumed = 1 + (n + 1) / 2;
+        if ((uint32_t)consumed > len) return -1;
+        for (int i = 0; i < n; i++) {
+            const uint8_t byte = B.desc[1 + i / 2];
+            B.weights[i] = (i & 1) ? (byte & 15) : (byte >> 4);
+        }
+        *nweights = n;
+        return consumed;
+    }
+    if (hb == 0 || 1 + hb > len) return -1;
+    int nsym = 0, al = 0, cnt = -1;
+    const int used = fse_read_desc(B.desc + 1, hb, 6, 63, B.norm, &nsym, &al); // weights are <= 11; 63 bounds B.norm
+    BackBits b;
+    if (used > 0 && (uint32_t)used < hb && fse_build_dtable(B.wtab, B.norm, nsym, al, B.next) && b.init(B.desc + 1 + used, hb - (uint32_t)used)) {
+        uint32_t s1 = b.read(al), s2 = b.read(al);
+        if (b.bitpos >= 0) {
+            cnt = 0;
+            for (;;) {
+                if (cnt > 253) { cnt = -1; break; }
+                B.weights[cnt++] = (uint8_t)cell_sym(B.wtab[s1]);
+                s1 = cell_base(B.wtab[s1], al) + b.read((int)cell_nbits(B.wtab[s1], al));
+                if (b.bitpos < 0) { B.weights[cnt++] = (uint8_t)cell_sym(B.wtab[s2]); break; }
+                if (cnt > 253) { cnt = -1; break; }
+                B.weights[cnt++] = (uint8_t)cell_sym(B.wtab[s2]);
+                s2 = cell_base(B.wtab[s2], al) + b.read((int)cell_nbits(B.wtab[s2], al));
+                if (b.bitpos < 0) { B.weights[cnt++] = (uint8_t)cell_sym(B.wtab[s1]); break; }
+            }
+        }
+    }
+    if (cnt < 1) return -1;
+    *nweights = cnt;
+    return 1 + (int)hb;
+}
+
+// weights[0..n) (LDS, room for one more) -> canonical decoder.  Uniform; same validity rules as huf_build_table.  Returns the table log or 0.
+__device__ int huf_build_canon(uint8_t *weights, int n, int lane, HufCanon &C)
 {
     uint32_t part = 0;
     bool bad = false;
     for (int i = lane; i < n; i += 64) {
-        const uint32_t w = L.b.weights[i];
+        const uint32_t w = weights[i];
         if (w > 11) bad = true;
         else if (w) part += 1u << (w - 1);
     }
@@ -1798,7 +1913,7 @@ __device__ int huf_build_canon(Lds &L, int n, int lane, HufCanon &C)
     const uint32_t left = (1u << max_bits) - sum;
     if (left & (left - 1)) return 0;
     const uint32_t last_w = (uint32_t)zd::hb32(left) + 1;
-    if (lane == 0) L.b.weights[n] = (uint8_t)last_w;
+    if (lane == 0) weights[n] = (uint8_t)last_w;
     zd::wave_sync();
     const int nsym = n + 1;
     uint32_t cnt[12], my_w[4];
@@ -1807,7 +1922,7 @@ __device__ int huf_build_canon(Lds &L, int n, int lane, HufCanon &C)
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int sidx = r * 64 + lane;
-        const uint32_t w = sidx < nsym ? L.b.weights[sidx] : 0u;
+        const uint32_t w = sidx < nsym ? weights[sidx] : 0u;
         my_w[r] = w;
 #pragma unroll
         for (int ww = 1; ww < 12; ww++) cnt[ww] += (uint32_t)__popcll(zd::ballot(w == (uint32_t)ww));
@@ -1842,39 +1957,10 @@ __device__ int huf_build_canon(Lds &L, int n, int lane, HufCanon &C)
         C.start[lane] = (uint16_t)st;
         C.adj[lane] = (int16_t)ad;
     }
-    // index over the top min(log, 7) bits
-    const int q = max_bits < 7 ? max_bits : 7, sh = max_bits - q;
-    for (int bkt = lane; bkt < (1 << q); bkt += 64) {
-        const uint32_t x0 = (uint32_t)bkt << sh, x1 = x0 + (1u << sh) - 1;
-        uint32_t w0 = 0, w1 = 0;
-#pragma unroll
-        for (int ww = 1; ww < 12; ww++) {
-            if (ww <= max_bits && cnt[ww]) { if (x0 >= start[ww]) w0 = (uint32_t)ww; if (x1 >= start[ww]) w1 = (uint32_t)ww; }
-        }
-        int32_t ad = 0;
-#pragma unroll
-        for (int ww = 1; ww < 12; ww++) if (w0 == (uint32_t)ww) ad = (int32_t)rb[ww] - (int32_t)(start[ww] >> (ww - 1));
-        C.lut[bkt] = (w0 == w1 && w0) ? (uint16_t)(w0 | ((uint32_t)ad << 4)) : (uint16_t)0;
-    }
     zd::wave_sync();
     return max_bits;
 }
 
-// one stream on the calling lane through the canonical decoder; symbols leave in 8-byte stores
-__device__ __forceinline__ uint32_t canon_symbol(const HufCanon &C, int max_bits, int sh, uint32_t x, uint32_t *nbits)
-{
-    const uint32_t e = C.lut[x >> sh];
-    uint32_t w;
-    int32_t ad;
-    if (e) { w = e & 15u; ad = (int32_t)(int16_t)e >> 4; }
-    else {
-        w = 1;
-        for (int ww = 2; ww <= max_bits; ww++) if (x >= C.start[ww]) w = (uint32_t)ww; // start[] of unused weights repeats the next one
-        ad = C.adj[w];
-    }
-    *nbits = (uint32_t)max_bits + 1u - w;
-    return C.sorted[ad + (int32_t)(x >> (w - 1))];
-}
 // The weight of a cell x (x = the next max_bits bits) is 1 + the number of weights ww >= 2 whose first cell start[ww] is <= x (the cells are
 // ordered by weight, start[] rises): ten compares against values the lane keeps in registers for the whole stream.  (Until round 4 a
 // 128-entry index gave the weight in one LDS access where its bucket lay inside one weight and a loop over start[] in LDS otherwise -- with
@@ -1893,9 +1979,11 @@ __device__ __forceinline__ uint32_t canon_symbol_r(const HufCanon &C, const Cano
     *nbits = (uint32_t)max_bits + 1u - w;
     return C.sorted[(int32_t)C.adj[w] + (int32_t)(x >> (w - 1))];
 }
-__device__ bool huf_decode_stream_canon(const HufCanon &C, int max_bits, const uint8_t *src, uint32_t len, uint8_t *out, uint32_t nout)
+// (inlined at its one call site: the compiler then knows the decoder lives in LDS and the streams in global memory -- as a function of
+// its own it went through flat loads, 18 of them per 8 symbols)
+__device__ __forceinline__ bool huf_decode_stream_canon(const HufCanon &C, int max_bits, const uint8_t *src, uint32_t len, uint8_t *out, uint32_t nout)
 {
-    BackBits b;
+    SeqBits b; // the word below the window is requested ahead: the stream's L2 round trip is off the symbol chain
     if (!b.init(src, len)) return false;
     CanonStarts R;
     canon_starts(C, max_bits, R);
@@ -1909,15 +1997,16 @@ __device__ bool huf_decode_stream_canon(const HufCanon &C, int max_bits, const u
             if ((j & 3) == 0) b.refill();
             uint32_t nb;
             const uint32_t sym = canon_symbol_r(C, R, max_bits, (uint32_t)((b.c << b.used) >> (64 - max_bits)), &nb);
-            b.skip((int)nb);
+            b.used += (int32_t)nb; b.bitpos -= (int32_t)nb;
             w |= (uint64_t)sym << (8 * j);
         }
         __builtin_memcpy(out + i, &w, 8);
     }
     for (; i < nout; i++) {
         uint32_t nb;
-        out[i] = (uint8_t)canon_symbol_r(C, R, max_bits, b.peek(max_bits), &nb);
-        b.skip((int)nb);
+        if (b.used + max_bits > 64) b.refill();
+        out[i] = (uint8_t)canon_symbol_r(C, R, max_bits, (uint32_t)((b.c << b.used) >> (64 - max_bits)), &nb);
+        b.used += (int32_t)nb; b.bitpos -= (int32_t)nb;
     }
     return b.bitpos == 0;
 }
@@ -1930,71 +2019,95 @@ __global__ void __launch_bounds__(64) zarc_zdec_literals(const uint8_t *__restri
     __shared__ LitLds S;
     const int lane = zd::lane_id();
     const uint64_t s0 = slot_base + (uint64_t)blockIdx.x * ZDEC_LIT_GROUP;
-    // ---- phase 1: tables ----
-    for (int i = 0; i < ZDEC_LIT_GROUP; i++) {
-        const uint64_t s = s0 + (uint64_t)i;
-        if (lane == 0) { S.bits[i] = 0; S.used[i] = 0; }
-        if (s >= n_slots) continue; // uniform
-        const ZdecBlock zb = zblocks[s];
-        if (zb.type != 2 || zb.lit_type < 2) continue;
-        const uint32_t f = zb.frame;
-        if (!zd::uniform(fast[f])) continue; // one value for the whole wave even while other waves clear the flag
-        if (lane == 0) for (int c = 0; c < 16; c++) S.build.ctrl[c] = 0;
-        zd::wave_sync();
+    static_assert(ZDEC_LIT_GROUP * 4 == 64, "four lanes and four streams per block, one wave");
+    const int i = lane >> 2;
+    const uint32_t k = (uint32_t)lane & 3u;
+    const uint64_t s = s0 + (uint64_t)i;
+    // ---- phase 1a: the four lanes of a block stage its tree description (Treeless: that of the nearest earlier block of the frame that carries one) ----
+    ZdecBlock zb = {};
+    bool want = false;
+    uint32_t f = 0, dlen = 0;
+    const uint8_t *dsrc = frames_base;
+    if (s < n_slots) {
+        zb = zblocks[s];
+        if (zb.type == 2 && zb.lit_type >= 2) { f = zb.frame; want = fast[f] != 0; }
+    }
+    if (want) {
         uint64_t from = s;
-        bool ok = true;
-        if (zb.lit_type == 3) { // Treeless: the tree of the nearest earlier block of the frame that carries one
-            ok = false;
+        if (zb.lit_type == 3) {
+            want = false;
             const uint64_t first = slot_prefix[f];
             for (uint64_t j = s; j > first;) {
                 j--;
                 const ZdecBlock pb = zblocks[j];
-                if (pb.type == 2 && pb.lit_type == 2) { from = j; ok = true; break; }
+                if (pb.type == 2 && pb.lit_type == 2) { from = j; want = true; break; }
             }
+            if (!want) fast[f] = 0;
         }
-        int used = 0;
-        if (ok) {
+        if (want) {
             const ZdecBlock sb = zblocks[from];
-            int nw = 0;
-            used = huf_read_weights(S.build, frames_base + frame_off[f] + sb.lit_off, sb.lit_comp, lane, &nw);
-            int tl = 0;
-            if (used >= 0) tl = huf_build_canon(S.build, nw, lane, S.canon[i]);
-            ok = tl != 0;
-            if (ok && lane == 0) { S.bits[i] = tl; S.used[i] = zb.lit_type == 2 ? (uint32_t)used : 0u; }
+            dsrc = frames_base + frame_off[f] + sb.lit_off;
+            dlen = sb.lit_comp < HUF_DESC_MAX ? sb.lit_comp : HUF_DESC_MAX;
         }
-        if (!ok && lane == 0) fast[f] = 0;
-        zd::wave_sync();
+    }
+    {
+        uint8_t got[33];
+#pragma unroll
+        for (uint32_t j = 0; j < 33; j++) { const uint32_t at = k * 33 + j; got[j] = at < dlen ? dsrc[at] : (uint8_t)0; }
+#pragma unroll
+        for (uint32_t j = 0; j < 33; j++) S.blk[i].desc[k * 33 + j] = got[j];
+    }
+    zd::wave_sync();
+    // ---- phase 1b: one lane per block reads the weights ----
+    if (k == 0) {
+        int nw = 0, used = 0;
+        if (want) {
+            used = huf_read_weights_lane(S.blk[i], dlen, &nw);
+            if (used < 0) { nw = 0; fast[f] = 0; }
+        }
+        S.nw[i] = nw;
+        S.used[i] = (nw && zb.lit_type == 2) ? (uint32_t)used : 0u;
+        S.frame[i] = f;
+    }
+    zd::wave_sync();
+    // ---- phase 1c: the decoders, wave-cooperative, one block after the other ----
+    for (int g = 0; g < ZDEC_LIT_GROUP; g++) {
+        const int nw = S.nw[g]; // uniform
+        int tl = 0;
+        if (nw) tl = huf_build_canon(S.blk[g].weights, nw, lane, S.blk[g].canon);
+        if (lane == 0) {
+            S.bits[g] = tl;
+            if (nw && !tl) fast[S.frame[g]] = 0;
+        }
     }
     zd::wave_sync();
     // ---- phase 2: one stream per lane ----
-    static_assert(ZDEC_LIT_GROUP * 4 == 64, "four streams per block, one wave");
-    const int i = lane >> 2;
-    const uint32_t k = (uint32_t)lane & 3u;
-    const uint64_t s = s0 + (uint64_t)i;
     if (s >= n_slots || S.bits[i] == 0) return;
-    const ZdecBlock zb = zblocks[s];
     if (zb.lit_streams == 1 && k != 0) return;
-    const uint32_t f = zb.frame;
     bool ok = S.used[i] <= zb.lit_comp;
     if (ok) {
         const uint8_t *hp = frames_base + frame_off[f] + zb.lit_off + S.used[i];
         const uint32_t rem = zb.lit_comp - S.used[i];
         uint8_t *dst = lits + lit_index[s];
-        const HufCanon &ht = S.canon[i];
+        const HufCanon &ht = S.blk[i].canon;
         const int tl = S.bits[i];
-        if (zb.lit_streams == 1) ok = huf_decode_stream_canon(ht, tl, hp, rem, dst, zb.lit_len);
-        else if (rem < 6) ok = false;
-        else {
-            const uint32_t s1 = hp[0] | ((uint32_t)hp[1] << 8), s2 = hp[2] | ((uint32_t)hp[3] << 8), s3 = hp[4] | ((uint32_t)hp[5] << 8);
-            const uint32_t per = (zb.lit_len + 3) / 4;
-            if (6 + s1 + s2 + s3 > rem || per * 3 > zb.lit_len) ok = false;
+        uint32_t so = 0, sl = rem, dof = 0, dn = zb.lit_len; // single stream: all of it
+        if (zb.lit_streams != 1) {
+            if (rem < 6) ok = false;
             else {
-                const uint32_t s4 = rem - 6 - s1 - s2 - s3;
-                const uint32_t so = k == 0 ? 0 : (k == 1 ? s1 : (k == 2 ? s1 + s2 : s1 + s2 + s3));
-                const uint32_t sl = k == 0 ? s1 : (k == 1 ? s2 : (k == 2 ? s3 : s4));
-                ok = huf_decode_stream_canon(ht, tl, hp + 6 + so, sl, dst + k * per, k < 3 ? per : zb.lit_len - 3 * per);
+                const uint32_t s1 = hp[0] | ((uint32_t)hp[1] << 8), s2 = hp[2] | ((uint32_t)hp[3] << 8), s3 = hp[4] | ((uint32_t)hp[5] << 8);
+                const uint32_t per = (zb.lit_len + 3) / 4;
+                if (6 + s1 + s2 + s3 > rem || per * 3 > zb.lit_len) ok = false;
+                else {
+                    const uint32_t s4 = rem - 6 - s1 - s2 - s3;
+                    so = 6 + (k == 0 ? 0 : (k == 1 ? s1 : (k == 2 ? s1 + s2 : s1 + s2 + s3)));
+                    sl = k == 0 ? s1 : (k == 1 ? s2 : (k == 2 ? s3 : s4));
+                    dof = k * per;
+                    dn = k < 3 ? per : zb.lit_len - 3 * per;
+                }
             }
         }
+        if (ok) ok = huf_decode_stream_canon(ht, tl, hp + so, sl, dst + dof, dn);
     }
     if (!ok) fast[f] = 0;
 }
