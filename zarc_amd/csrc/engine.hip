@@ -1087,8 +1087,11 @@ int unpack_device_once(zarc_gpu_t *h, size_t n, const void *d_frames_base, const
                     // (a batch of small frames -- fewer than four blocks per frame on average -- has nothing to share: a workgroup's 32 blocks
                     // would belong to a dozen frames with a dozen table sets, and every workgroup would hand its blocks on after looking)
                     const bool shared = diag_env("ZARC_GPU_SEQ_SHARED", 1) != 0 && (s1 - s0) >= 4 * (uint64_t)ng;
-                    int sw = diag_env("ZARC_GPU_SEQ_WIDTH", 32); // block slots per workgroup of the shared-table kernel (measured at configs[1]: 64 -> 27.3 ms, 32 -> 23.7, 16 -> 27.3: tools/r4_ab4.sh)
-                    if (sw != 16 && sw != 32 && sw != 64) sw = 32;
+                    // block slots per workgroup of the shared-table kernel.  Round 4, 128 KiB blocks and a table per 8: 64 -> 27.3 ms, 32 -> 23.7, 16 -> 27.3
+                    // (tools/r4_ab4.sh); with the straight-line step, 64 KiB blocks and a table per 16: 64 lanes with 8 sets 13.1 ms alone, 32 lanes with
+                    // 5 sets 14.9, and side by side with the literals the smaller LDS share is what counts (tools/r4_sets.sh)
+                    int sw = diag_env("ZARC_GPU_SEQ_WIDTH", 64);
+                    if (sw != 16 && sw != 32 && sw != 64) sw = 64;
                     if (!shared) sw = seq_lanes;
                     const size_t waves = (size_t)((split - s0 + (uint64_t)sw - 1) / (uint64_t)sw);
                     uint32_t *flags = nullptr;

@@ -1621,6 +1621,12 @@ __device__ __forceinline__ uint32_t seq_code_info(uint32_t i)
     if (i < 64) ll_code_info(i < 36 ? i : 0u, base, bits); else ml_code_info(i - 64 < 53 ? i - 64 : 0u, base, bits);
     return base | (bits << 20);
 }
+#ifndef ZDEC_SETS64
+#define ZDEC_SETS64 8 // 64 blocks of the engine's own frames = four groups of sixteen: four sets per type, four to spare (A/B: tools/r4_sets.sh)
+#endif
+#ifndef ZDEC_SETS32
+#define ZDEC_SETS32 5
+#endif
 template <int LANES, int SETS>
 __device__ __forceinline__ void zdec_seqs_shared_body(const uint8_t *__restrict__ frames_base, const uint64_t *__restrict__ frame_off, uint64_t n_slots,
                                                       const uint64_t *__restrict__ slot_prefix, ZdecBlock *__restrict__ zblocks,
@@ -1712,14 +1718,14 @@ __global__ void __launch_bounds__(64) zarc_zdec_seqs_shared(const uint8_t *__res
                                                             const uint64_t *__restrict__ seq_index, uint64_t *__restrict__ seqs,
                                                             uint32_t *__restrict__ fast, uint64_t slot_base, uint32_t *__restrict__ wave_flag)
 {
-    zdec_seqs_shared_body<64, 10>(frames_base, frame_off, n_slots, slot_prefix, zblocks, seq_index, seqs, fast, slot_base, wave_flag);
+    zdec_seqs_shared_body<64, ZDEC_SETS64>(frames_base, frame_off, n_slots, slot_prefix, zblocks, seq_index, seqs, fast, slot_base, wave_flag);
 }
 __global__ void __launch_bounds__(32) zarc_zdec_seqs_shared32(const uint8_t *__restrict__ frames_base, const uint64_t *__restrict__ frame_off, uint64_t n_slots,
                                                               const uint64_t *__restrict__ slot_prefix, ZdecBlock *__restrict__ zblocks,
                                                               const uint64_t *__restrict__ seq_index, uint64_t *__restrict__ seqs,
                                                               uint32_t *__restrict__ fast, uint64_t slot_base, uint32_t *__restrict__ wave_flag)
 {
-    zdec_seqs_shared_body<32, 5>(frames_base, frame_off, n_slots, slot_prefix, zblocks, seq_index, seqs, fast, slot_base, wave_flag);
+    zdec_seqs_shared_body<32, ZDEC_SETS32>(frames_base, frame_off, n_slots, slot_prefix, zblocks, seq_index, seqs, fast, slot_base, wave_flag);
 }
 __global__ void __launch_bounds__(16) zarc_zdec_seqs_shared16(const uint8_t *__restrict__ frames_base, const uint64_t *__restrict__ frame_off, uint64_t n_slots,
                                                               const uint64_t *__restrict__ slot_prefix, ZdecBlock *__restrict__ zblocks,
