@@ -1050,8 +1050,8 @@ int unpack_device_once(zarc_gpu_t *h, size_t n, const void *d_frames_base, const
             const uint64_t g_seqs = lean ? g_seq_at[g + 1] - g_seq_at[g] : seqidx[s1] - seqidx[s0], g_lits = lean ? g_lit_at[g + 1] - g_lit_at[g] : litidx[s1] - litidx[s0];
             // the literal and the sequence kernels are independent and neither fills the chip: they run side by side
             hipStream_t sl = side ? sb : sa;
-            // the shared-table sequence kernel needs 25 KiB of LDS per wave: launched first it gets its place on every CU at once and the
-            // literal waves (9 KiB each) fill what is left; behind them it would wait for LDS (diagnostic switch: ZARC_GPU_LIT_FIRST)
+            // the shared-table sequence kernel needs 23 KiB of LDS per wave: launched first it gets its place on every CU at once and the
+            // literal waves (12.5 KiB each) fill what is left; behind them it would wait for LDS (diagnostic switch: ZARC_GPU_LIT_FIRST)
             const bool lit_first = diag_env("ZARC_GPU_LIT_FIRST", 0) != 0;
             auto launch_literals = [&]() -> int {
             if (g_lits) {
@@ -1084,7 +1084,7 @@ int unpack_device_once(zarc_gpu_t *h, size_t n, const void *d_frames_base, const
                     // Waves whose 64 blocks share their tables (the engine's own frames: one table set per group of sixteen 64 KiB blocks; libzstd's
                     // Repeat_Mode blocks) decode with the tables in LDS; the others raise their flag and are done by the second launch with a
                     // table set per block in HBM scratch, as before.
-                    // (a batch of small frames -- fewer than four blocks per frame on average -- has nothing to share: a workgroup's 32 blocks
+                    // (a batch of small frames -- fewer than four blocks per frame on average -- has nothing to share: a workgroup's 64 blocks
                     // would belong to a dozen frames with a dozen table sets, and every workgroup would hand its blocks on after looking)
                     const bool shared = diag_env("ZARC_GPU_SEQ_SHARED", 1) != 0 && (s1 - s0) >= 4 * (uint64_t)ng;
                     // block slots per workgroup of the shared-table kernel.  Round 4, 128 KiB blocks and a table per 8: 64 -> 27.3 ms, 32 -> 23.7, 16 -> 27.3

@@ -1610,7 +1610,7 @@ __global__ void zarc_zdec_predef(uint16_t *__restrict__ out)
 // Stage 2 with the tables of a wave's 64 blocks SHARED in LDS.  The engine's own frames code the sixteen 64 KiB blocks of a 1 MiB entry with
 // one table per type (zge_entropy.hip: zarc_zge_plan; libzstd repeats tables as well): blocks whose tables come from the same
 // description (their own, or the same earlier block's through Repeat_Mode; the predefined distributions; an RLE symbol) use one copy.
-// A wave's 64 consecutive block slots typically need 8 table sets instead of 64: they fit LDS (ZDEC_SH_SETS tables per type, 25 KiB per
+// A wave's 64 consecutive block slots typically need 4 - 8 table sets instead of 64: they fit LDS (ZDEC_SETS64 tables per type, 23 KiB per
 // wave, six waves per CU), and the three lookups per sequence stop being 64-byte lines from 80 000 tables in HBM / MALL (178 GB per
 // launch at BASELINE configs[1], 11 x the whole path's algorithmic bytes).  A wave that needs more tables of some type than fit
 // sets wave_flag[its index] and leaves: the launch of zarc_zdec_seqs behind this one does its 64 slots the old way.
