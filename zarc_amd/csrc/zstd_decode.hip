@@ -1205,16 +1205,30 @@ __global__ void __launch_bounds__(64, 4) zarc_zstd_decode(const uint8_t *__restr
     __shared__ Lds L;
     const int lane = zd::lane_id();
     uint8_t *lit_buf = lit_scratch + (uint64_t)blockIdx.x * (BLOCK_MAX + 64);
+    // Beside the fast path this kernel mostly looks at frames that are not its own: in a batch of many small frames a wave takes 64 queue
+    // slots at a time and every lane looks at one flag (a million frames one by one: a million dependent atomics, 16 ms on the critical
+    // path of `--config small` for nothing to decode); few, large frames stay one per trip so that the largest do not share a wave.
+    const uint32_t take = (fast != nullptr && n_frames >= 16u * gridDim.x) ? 64u : 1u; // uniform over the grid
     for (;;) {
         uint32_t slot = 0;
-        if (lane == 0) slot = atomicAdd(queue, 1u);
+        if (lane == 0) slot = atomicAdd(queue, take);
         slot = zd::uniform(slot); // lane 0 is the first active lane
         if (slot >= n_frames) break;
-        const uint32_t f = order[slot];
-        if (fast != nullptr && zd::uniform(fast[f]) != 0) continue; // zarc_zstd_frames has it
-        decode_frame<false>(L, lane, f, lit_buf, frames_base, frame_off, frame_len, dst_base, dst_off, raw_len, status, stored_checksum, ZDEC_DBG(dbg), nullptr, nullptr,
-                            nullptr, nullptr, nullptr, ZdecPiece{});
-        zd::wave_sync_global(); // LDS tables and the literal buffer are reused by the next frame
+        uint32_t f_l = 0;
+        bool mine = false;
+        if ((uint32_t)lane < take && slot + (uint32_t)lane < n_frames) {
+            f_l = order[slot + (uint32_t)lane];
+            mine = fast == nullptr || fast[f_l] == 0; // the others: zarc_zstd_frames has them
+        }
+        uint64_t todo = zd::ballot(mine);
+        while (todo) { // uniform
+            const uint32_t k = (uint32_t)zd::ctz64(todo);
+            todo &= todo - 1;
+            const uint32_t f = zd::readlane(f_l, k);
+            decode_frame<false>(L, lane, f, lit_buf, frames_base, frame_off, frame_len, dst_base, dst_off, raw_len, status, stored_checksum, ZDEC_DBG(dbg), nullptr, nullptr,
+                                nullptr, nullptr, nullptr, ZdecPiece{});
+            zd::wave_sync_global(); // LDS tables and the literal buffer are reused by the next frame
+        }
     }
 }
 
