@@ -246,7 +246,14 @@ __device__ bool fse_build_dtable(uint16_t *tab, const int16_t *norm, int nsym, i
 // The same table with ONE scratch array: nn[] holds the normalised counts on entry and the symbols' state counters afterwards.  (For
 // the lanes that build tables side by side with the scratch in LDS: two 64-entry arrays of a lane's own end up as registers selected by
 // compare chains, ~130 instructions per access.)
-__device__ bool fse_build_dtable_inplace(uint16_t *tab, int16_t *nn, int nsym, int al)
+// 64 scratch entries of one lane among its workgroup's: entry i of every lane side by side (a row per lane would put the same entry of
+// all lanes on one LDS bank)
+template <int STRIDE> struct Strided16 {
+    int16_t *p;
+    __device__ __forceinline__ int16_t &operator[](int i) const { return p[i * STRIDE]; }
+};
+template <class NN>
+__device__ __forceinline__ bool fse_build_dtable_inplace(uint16_t *tab, NN nn, int nsym, int al)
 {
     const int T = 1 << al;
     int high = T - 1;
@@ -272,7 +279,9 @@ __device__ bool fse_build_dtable_inplace(uint16_t *tab, int16_t *nn, int nsym, i
 }
 
 // Parse an FSE table description (lane-serial).  Returns bytes consumed, or -1.
-__device__ int fse_read_desc(const uint8_t *src, uint32_t len, int max_al, int max_sym, int16_t *norm, int *nsym_out, int *al_out)
+// (NN: int16_t * or a Strided16 view of LDS scratch)
+template <class NN>
+__device__ int fse_read_desc(const uint8_t *src, uint32_t len, int max_al, int max_sym, NN norm, int *nsym_out, int *al_out)
 {
     if (len == 0) return -1;
     FwdBits b = {src, 0};
@@ -680,7 +689,8 @@ __device__ int build_seq_table(uint16_t *tab, int t, uint32_t mode, const uint8_
     return al;
 }
 // (scratch: 64 entries the caller provides, see fse_build_dtable_inplace)
-__device__ __forceinline__ int build_seq_table(uint16_t *tab, int t, uint32_t mode, const uint8_t *desc, uint32_t len, int16_t *scratch)
+template <class NN>
+__device__ __forceinline__ int build_seq_table(uint16_t *tab, int t, uint32_t mode, const uint8_t *desc, uint32_t len, NN scratch)
 {
     const int max_sym = t == 0 ? 35 : (t == 1 ? 31 : 52);
     if (mode == 0) {
@@ -1591,6 +1601,9 @@ __global__ void __launch_bounds__(64) zarc_zdec_seqs(const uint8_t *__restrict__
                                                      uint32_t *__restrict__ fast, uint64_t slot_base, const uint32_t *__restrict__ wave_flag,
                                                      const uint16_t *__restrict__ predef)
 {
+    // every lane builds the tables of its block: the builder's 64 counters live in LDS (two local arrays became registers selected by
+    // compare chains, ~130 instructions per access -- most of this kernel's time on small blocks)
+    __shared__ int16_t T_scratch[64 * 64];
     if (wave_flag && !wave_flag[blockIdx.x]) return; // (launched with 64 lanes per workgroup then: the flags are per 64 slots)
     const uint64_t s = slot_base + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; // slots [slot_base, n_slots); waves may be partly filled (engine.hip)
     if (s >= n_slots) return;
@@ -1616,7 +1629,7 @@ __global__ void __launch_bounds__(64) zarc_zdec_seqs(const uint8_t *__restrict__
             al[t] = t == 1 ? 5 : 6;
             continue;
         }
-        al[t] = build_seq_table(tabs[t], t, mode, src + off, mode == 2 ? len : (mode == 1 ? 1u : 0u));
+        al[t] = build_seq_table(tabs[t], t, mode, src + off, mode == 2 ? len : (mode == 1 ? 1u : 0u), Strided16<64>{&T_scratch[threadIdx.x]});
         if (al[t] < 0) ok = false;
     }
     seq_chain<const uint16_t *>(ok, src, zb, own, end, use[0], use[1], use[2], al[0], al[1], al[2], seqs + seq_index[s], zblocks + s, fast + f);
@@ -1659,7 +1672,7 @@ __device__ __forceinline__ void zdec_seqs_shared_body(const uint8_t *__restrict_
     __shared__ int32_t T_al[3][SETS];
     __shared__ uint32_t lead[3][SETS];
     __shared__ uint32_t T_info[128];
-    __shared__ int16_t T_scratch[3 * SETS][64];
+    __shared__ int16_t T_scratch[64][3 * SETS]; // entry i of builder b at [i][b]
     const int lane = zd::lane_id();
     for (int i = lane; i < 128; i += LANES) T_info[i] = seq_code_info((uint32_t)i);
     const uint64_t s = slot_base + (uint64_t)blockIdx.x * LANES + (uint64_t)lane;
@@ -1718,7 +1731,7 @@ __device__ __forceinline__ void zdec_seqs_shared_body(const uint8_t *__restrict_
         if (from != 0xFFFFFFFFu) {
             uint16_t *tab = bt == 0 ? &T_ll[bn][0] : (bt == 1 ? &T_of[bn][0] : &T_ml[bn][0]);
             const uint8_t *bsrc = frames_base + frame_off[bf];
-            T_al[bt][bn] = build_seq_table(tab, bt, bmode, bsrc + boff, bmode == 2 ? blen : (bmode == 1 ? 1u : 0u), &T_scratch[lane][0]);
+            T_al[bt][bn] = build_seq_table(tab, bt, bmode, bsrc + boff, bmode == 2 ? blen : (bmode == 1 ? 1u : 0u), Strided16<3 * SETS>{&T_scratch[0][lane]});
         }
     }
     zd::wave_sync();
