@@ -17,7 +17,7 @@ for f in glob.glob("$O/p*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"].split("(")[0]
         agg[k][row["Counter_Name"]] += float(row["Counter_Value"]); cnt[k][row["Counter_Name"]] += 1
-for k in ("zarc_zdec_seqs_shared32", "zarc_zdec_seqs", "zarc_zdec_literals", "zarc_zstd_decode"):
+for k in ("zarc_zdec_seqs_shared", "zarc_zdec_seqs", "zarc_zstd_frames", "zarc_zdec_literals", "zarc_zstd_decode"):
     print(k)
     for c in sorted(agg[k]): print("   %-32s %.4g per dispatch (%d)" % (c, agg[k][c] / max(cnt[k][c], 1), cnt[k][c]))
 PY
