@@ -184,6 +184,39 @@ def check_unpack_errors(engine, oracle, corpus, golden_frames):
         assert oracle.zstd_decode(frames[i], len(raw))[0] != 0
 
 
+def check_many_frames_with_turned_down_ones(engine, oracle, corpus, n):
+    """A batch of many small frames in which some are not the fast path's: the general decoder (zarc_zstd_decode) then takes 64 queue slots
+    per trip and decodes exactly the frames whose flag says so (zstd_decode.hip).  Every status and every byte as for the frame alone."""
+    import random
+    rnd = random.Random(11)
+    ents = [corpus.entry(5000 + i, rnd.choice((0, 1, 9, 40, 130, 700, 2500)), i % 4) for i in range(n)]
+    packed = engine.pack(ents)
+    frames = [f for f, _ in packed]
+    digests = [d for _, d in packed]
+    raw_lens = [len(e) for e in ents]
+    bad = {}
+    for i in range(3, n, 37):            # scattered: several per 64-slot trip, and trips without any
+        kind = (i // 37) % 4
+        f = bytearray(frames[i])
+        if kind == 0: f[0] ^= 1; bad[i] = "magic"
+        elif kind == 1 and len(f) > 9: f = f[:-3]; bad[i] = "trunc"
+        elif kind == 2: raw_lens[i] += 1; bad[i] = "size"
+        elif kind == 3: digests[i] = bytes(32); bad[i] = "digest"
+        frames[i] = bytes(f)
+    res = engine.unpack(frames, raw_lens, digests)
+    for i, (out, dig, st) in enumerate(res):
+        why = bad.get(i)
+        if why is None: assert st == _lib.FRAME_OK and out == ents[i], i
+        elif why == "magic": assert st == _lib.FRAME_BAD_MAGIC, i
+        elif why == "trunc": assert st != _lib.FRAME_OK, i
+        elif why == "size": assert st == _lib.FRAME_SRCSIZE, i
+        elif why == "digest": assert (st == _lib.FRAME_DIGEST and out == ents[i]) or len(ents[i]) == 0 and st in (_lib.FRAME_DIGEST, _lib.FRAME_OK), i
+    # the same frames one call each give the same statuses (a sample)
+    for i in sorted(bad)[:12]:
+        one = engine.unpack([frames[i]], [raw_lens[i]], [digests[i]])[0]
+        assert one[2] == res[i][2], (i, bad[i])
+
+
 def check_store(engine, oracle, corpus, libzstds):
     """Encoder::enable_compression(false) (encode.rs:95-97, lowlevel_frames.rs:47-84): raw-block frames.  The layout is pinned
     byte for byte: the reference's descriptor (8-byte content size, no single segment, no checksum) plus the window byte

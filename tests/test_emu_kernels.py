@@ -236,3 +236,7 @@ def test_emu_many_tiny_entries(emu_engine, oracle, corpus):
         assert res[i][0] == oracle.zge_encode(ents[i]) and res[i][1] == oracle.blake3(ents[i]), i
     out = emu_engine.unpack([f for f, _ in res], [len(e) for e in ents], [d for _, d in res])
     assert all(st == 0 and o == e for e, (o, d, st) in zip(ents, out))
+
+
+def test_emu_many_frames_with_turned_down_ones(emu_engine, oracle, corpus):
+    pc.check_many_frames_with_turned_down_ones(emu_engine, oracle, corpus, 1500)   # 2 emulated CUs: 64 slots per trip from 512 frames on

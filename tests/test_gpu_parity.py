@@ -46,6 +46,10 @@ def test_gpu_unpack_error_statuses(engine, oracle, corpus, golden_frames):
     pc.check_unpack_errors(engine, oracle, corpus, golden_frames)
 
 
+def test_gpu_many_frames_with_turned_down_ones(engine, oracle, corpus):
+    pc.check_many_frames_with_turned_down_ones(engine, oracle, corpus, 70000)   # 4096 decoder waves: 64 slots per trip from 65 536 frames on
+
+
 def test_gpu_params(engine):
     pc.check_params(engine)
 
