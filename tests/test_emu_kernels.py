@@ -122,9 +122,16 @@ def test_emu_level9_deep_finder_matches_model(emu_lib_path, oracle, corpus):
         e9.close()
 
 
-def test_emu_sequence_stage_split_between_both_kernels(emu_engine, oracle, corpus, golden_frames, monkeypatch):
-    """ZARC_GPU_SEQ_LDS_FRAC (diagnostic builds only; the emulator library is one) sends part of the blocks to the sequence kernel that keeps its tables in LDS: same results."""
-    monkeypatch.setenv("ZARC_GPU_SEQ_LDS_FRAC", "0.5")
+def test_emu_sequence_stage_with_and_without_the_long_block_kernel(emu_engine, oracle, corpus, golden_frames, monkeypatch):
+    """Blocks with long chains that share no tables go to zarc_zdec_seqs_lds (every lane's own tables in LDS), the rest of what the shared-table
+    kernel turned down to zarc_zdec_seqs: libzstd's golden frames (a table set per block) and the engine's own take all three routes.
+    ZARC_GPU_SEQ_LONG=0 (diagnostic builds only; the emulator library is one) leaves everything to zarc_zdec_seqs: same results."""
+    pc.check_unpack_golden(emu_engine, oracle, corpus, golden_frames)
+    monkeypatch.setenv("ZARC_GPU_SEQ_LONG", "0")
+    pc.check_unpack_golden(emu_engine, oracle, corpus, golden_frames)
+    pc.check_roundtrip(emu_engine, oracle, corpus, big=False)
+    monkeypatch.setenv("ZARC_GPU_SEQ_SHARED", "0")   # nothing shared: long blocks to the LDS kernel, short ones to the HBM-table kernel
+    monkeypatch.setenv("ZARC_GPU_SEQ_LONG", "1")
     pc.check_unpack_golden(emu_engine, oracle, corpus, golden_frames)
     pc.check_roundtrip(emu_engine, oracle, corpus, big=False)
 

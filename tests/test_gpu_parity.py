@@ -217,7 +217,7 @@ def test_gpu_environment_cannot_change_the_frames(engine, oracle, corpus, libzst
     """The product library reads no environment variable: with last round's debug / steering switches set, frames are still
     bit-identical to the model and decode (the switches only exist in the diagnostic build, make DIAG=1)."""
     for k, v in (("ZARC_GPU_DBG", "7"), ("ZARC_GPU_CAP", "16"), ("ZARC_GPU_DBG_DEC", "1"), ("ZARC_GPU_DEC_FAST", "0"),
-                 ("ZARC_GPU_SEQ_LANES", "16"), ("ZARC_GPU_SEQ_LDS_FRAC", "0.5"), ("ZARC_GPU_SCRATCH_MB", "1"), ("ZARC_GPU_STAGE_CHUNK", "4096")):
+                 ("ZARC_GPU_SEQ_LANES", "16"), ("ZARC_GPU_SEQ_LONG", "0"), ("ZARC_GPU_SCRATCH_MB", "1"), ("ZARC_GPU_STAGE_CHUNK", "4096")):
         monkeypatch.setenv(k, v)
     pc.check_pack(engine, oracle, corpus, libzstds, big=False)
     pc.check_roundtrip(engine, oracle, corpus, big=False)

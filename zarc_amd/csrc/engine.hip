@@ -1019,10 +1019,6 @@ int unpack_device_once(zarc_gpu_t *h, size_t n, const void *d_frames_base, const
     const bool side = diag_env("ZARC_GPU_DEC_SIDE", 1) != 0;
     int seq_lanes = diag_env("ZARC_GPU_SEQ_LANES", 64);
     if (seq_lanes != 8 && seq_lanes != 16 && seq_lanes != 32 && seq_lanes != 64) seq_lanes = 64;
-    // (the LDS-table sequence kernel zarc_zdec_seqs_lds stays a measured alternative of the diagnostic build, one group only)
-    double lds_frac = groups == 1 ? diag_env_f("ZARC_GPU_SEQ_LDS_FRAC", 0.0) : 0.0;
-    if (lds_frac < 0) lds_frac = 0;
-    if (lds_frac > 1) lds_frac = 1;
     bool have_seq_t[zarc_gpu::DEC_GROUPS] = {}, have_lit_t[zarc_gpu::DEC_GROUPS] = {};
     std::vector<uint32_t> nblk_of(lean ? n_large : n); // blocks per frame (sorted order; lean: of the large frames only)
     for (size_t i = 0; i < nblk_of.size(); i++) nblk_of[i] = (uint32_t)(slot_prefix[i + 1] - slot_prefix[i]);
@@ -1067,23 +1063,11 @@ int unpack_device_once(zarc_gpu_t *h, size_t n, const void *d_frames_base, const
             if (lit_first && (rc = launch_literals())) return rc;
             if (g_seqs) {
                 ZHIP(hipEventRecord(ev[0], sa));
-                // Each lane is a long serial chain (about one L2/HBM round trip and 340 instructions per sequence).  Partly filled
-                // waves (more waves to interleave) were measured and are slower: 35 ms with 64 lanes per wave, 54 ms with 16
-                // (ZARC_GPU_SEQ_LANES reproduces it) -- the waves' own instruction issue dominates, not exposed waits.
-                const uint64_t split = lds_frac <= 0 ? s1 : s0 + (uint64_t)((double)(s1 - s0) * (1.0 - lds_frac)) / 64 * 64; // [s0, split): tables in HBM scratch; [split, s1): in LDS
-                if (split < s1) {
-                    ZHIP(hipEventRecord(h->ev_fork3, sa));
-                    ZHIP(hipStreamWaitEvent(h->stream3, h->ev_fork3, 0));
-                    hipLaunchKernelGGL(zarc_zdec_seqs_lds, dim3((unsigned)((s1 - split + ZDEC_LDS_LANES - 1) / ZDEC_LDS_LANES)), dim3(ZDEC_LDS_LANES), 0, h->stream3,
-                                       (const uint8_t *)d_frames_base, h->d_frame_off.as<uint64_t>(), s1, h->d_slot_prefix.as<uint64_t>(),
-                                       h->d_zblocks.as<ZdecBlock>(), h->d_seqidx.as<uint64_t>(), h->d_seqs.as<uint64_t>(), h->d_fast.as<uint32_t>(), split);
-                    ZHIP(hipGetLastError());
-                    ZHIP(hipEventRecord(h->ev_join3, h->stream3));
-                }
-                if (split > s0) {
+                {
                     // Waves whose 64 blocks share their tables (the engine's own frames: one table set per group of sixteen 64 KiB blocks; libzstd's
-                    // Repeat_Mode blocks) decode with the tables in LDS; the others raise their flag and are done by the second launch with a
-                    // table set per block in HBM scratch, as before.
+                    // Repeat_Mode blocks) decode with the tables in LDS; the others raise their flag and are done by the launches behind it: 16-slot
+                    // subgroups that hold a block with a long chain by zarc_zdec_seqs_lds (every lane's own tables in LDS, on a side stream), the
+                    // rest by zarc_zdec_seqs with a table set per block in HBM scratch.
                     // (a batch of small frames -- fewer than four blocks per frame on average -- has nothing to share: a workgroup's 64 blocks
                     // would belong to a dozen frames with a dozen table sets, and every workgroup would hand its blocks on after looking)
                     const bool shared = diag_env("ZARC_GPU_SEQ_SHARED", 1) != 0 && (s1 - s0) >= 4 * (uint64_t)ng;
@@ -1093,22 +1077,33 @@ int unpack_device_once(zarc_gpu_t *h, size_t n, const void *d_frames_base, const
                     int sw = diag_env("ZARC_GPU_SEQ_WIDTH", 64);
                     if (sw != 16 && sw != 32 && sw != 64) sw = 64;
                     if (!shared) sw = seq_lanes;
-                    const size_t waves = (size_t)((split - s0 + (uint64_t)sw - 1) / (uint64_t)sw);
+                    const size_t waves = (size_t)((s1 - s0 + (uint64_t)sw - 1) / (uint64_t)sw);
+                    const bool split_long = diag_env("ZARC_GPU_SEQ_LONG", 1) != 0 && (shared ? sw == 64 : sw % ZDEC_LDS_LANES == 0);
                     uint32_t *flags = nullptr;
                     if (shared) {
                         flags = h->d_seqflag.as<uint32_t>() + (size_t)(s0 / 16) + (size_t)g; // (a group's slots need not start at a multiple of the width)
                         ZHIP(hipMemsetAsync(flags, 0, waves * 4, sa));
                         auto kern = sw == 64 ? zarc_zdec_seqs_shared : (sw == 32 ? zarc_zdec_seqs_shared32 : zarc_zdec_seqs_shared16);
                         hipLaunchKernelGGL(kern, dim3((unsigned)waves), dim3(sw), 0, sa, (const uint8_t *)d_frames_base, h->d_frame_off.as<uint64_t>(),
-                                           split, h->d_slot_prefix.as<uint64_t>(), h->d_zblocks.as<ZdecBlock>(), h->d_seqidx.as<uint64_t>(), h->d_seqs.as<uint64_t>(),
+                                           s1, h->d_slot_prefix.as<uint64_t>(), h->d_zblocks.as<ZdecBlock>(), h->d_seqidx.as<uint64_t>(), h->d_seqs.as<uint64_t>(),
                                            h->d_fast.as<uint32_t>(), s0, flags);
                     }
+                    if (split_long) {
+                        ZHIP(hipEventRecord(h->ev_fork3, sa));
+                        ZHIP(hipStreamWaitEvent(h->stream3, h->ev_fork3, 0));
+                        hipLaunchKernelGGL(zarc_zdec_seqs_lds, dim3((unsigned)((s1 - s0 + ZDEC_LDS_LANES - 1) / ZDEC_LDS_LANES)), dim3(ZDEC_LDS_LANES), 0, h->stream3,
+                                           (const uint8_t *)d_frames_base, h->d_frame_off.as<uint64_t>(), s1, h->d_slot_prefix.as<uint64_t>(),
+                                           h->d_zblocks.as<ZdecBlock>(), h->d_seqidx.as<uint64_t>(), h->d_seqs.as<uint64_t>(), h->d_fast.as<uint32_t>(), s0,
+                                           (const uint32_t *)flags);
+                        ZHIP(hipGetLastError());
+                        ZHIP(hipEventRecord(h->ev_join3, h->stream3));
+                    }
                     hipLaunchKernelGGL(zarc_zdec_seqs, dim3((unsigned)waves), dim3(sw), 0, sa, (const uint8_t *)d_frames_base,
-                                       h->d_frame_off.as<uint64_t>(), split, h->d_slot_prefix.as<uint64_t>(), h->d_zblocks.as<ZdecBlock>(), h->d_seqidx.as<uint64_t>(),
+                                       h->d_frame_off.as<uint64_t>(), s1, h->d_slot_prefix.as<uint64_t>(), h->d_zblocks.as<ZdecBlock>(), h->d_seqidx.as<uint64_t>(),
                                        h->d_seqs.as<uint64_t>(), h->d_ztables.as<uint16_t>(), h->d_fast.as<uint32_t>(), s0, (const uint32_t *)flags,
-                                       h->d_predef.as<uint16_t>());
+                                       h->d_predef.as<uint16_t>(), split_long ? 1 : 0);
+                    if (split_long) ZHIP(hipStreamWaitEvent(sa, h->ev_join3, 0));
                 }
-                if (split < s1) ZHIP(hipStreamWaitEvent(sa, h->ev_join3, 0));
                 ZHIP(hipGetLastError());
                 ZHIP(hipEventRecord(ev[1], sa));
                 have_seq_t[g] = true;

@@ -158,6 +158,20 @@ struct Bits128 {
         hi = zd::load_u64(p + base + 8);
         u = 8 * top - bitpos;
     }
+    // The window of a LATER cursor position, asked for now (ahead) and taken over when the cursor is there (adopt): the step of a sequence
+    // knows how many bits it will consume as soon as its five table lookups are back, long before it has consumed them.
+    __device__ __forceinline__ void ahead(int32_t at_bitpos, uint64_t &a_lo, uint64_t &a_hi, int32_t &a_top) const
+    {
+        a_top = (at_bitpos + 7) >> 3;
+        const int32_t base = a_top >= 16 ? a_top - 16 : 0;
+        a_lo = zd::load_u64(p + base);
+        a_hi = zd::load_u64(p + base + 8);
+    }
+    __device__ __forceinline__ void adopt(uint64_t a_lo, uint64_t a_hi, int32_t a_top)
+    {
+        lo = a_lo; hi = a_hi; top = a_top;
+        u = 8 * top - bitpos;
+    }
     __device__ __forceinline__ void settle() // within 16 bytes of the stream's start: move the bytes up, zeros come in below
     {
         if (top < 16) {
@@ -1502,11 +1516,20 @@ __device__ __forceinline__ void seq_chain128(bool ok, const uint8_t *__restrict_
         bool bad = !ok;
         const uint32_t nseq = zb.nseq;
         uint64_t held = 0; // the sequence of an even step, until the odd one's store takes it along
+        uint64_t a_lo = 0, a_hi = 0;
+        int32_t a_top = 0;
+        if (ok) b.ahead(b.bitpos, a_lo, a_hi, a_top);
         for (uint32_t i = 0; i < nseq && !bad; i++) {
-            b.request(); // one bitstream window per sequence, in flight during the table lookups
+            // One bitstream window per sequence, asked for a step ahead: what this step will consume is known once its lookups are back
+            // (the codes' extra bits, the three states' bits), ~100 instructions before the next step needs its window -- in a kernel
+            // that runs one or two waves per SIMD that is the L2 round trip no other wave would cover.
+            b.adopt(a_lo, a_hi, a_top);
             const uint32_t cl = tl[sl], co = to[so], cm = tm[sm];
             const uint32_t ofc = cell_sym(co), mlc = cell_sym(cm), llc = cell_sym(cl);
             const uint32_t mi = info[64 + mlc], li = info[llc];
+            const bool more = i + 1 < nseq; // the last sequence reads no state bits
+            const uint32_t nb_l = more ? cell_nbits(cl, al_l) : 0u, nb_m = more ? cell_nbits(cm, al_m) : 0u, nb_o = more ? cell_nbits(co, al_o) : 0u;
+            b.ahead(b.bitpos - (int32_t)((ofc & 31u) + (mi >> 20) + (li >> 20) + nb_l + nb_m + nb_o), a_lo, a_hi, a_top);
             b.settle();
             bad = ofc > 27 || mlc > 52 || llc > 35;                        // offsets past the format's largest window: left to the frame pass
             const uint32_t ofv = (1u << (ofc & 31u)) + b.take(ofc & 31u);  // phase 1: <= 7 + 27 + 16 bits
@@ -1544,10 +1567,9 @@ __device__ __forceinline__ void seq_chain128(bool ok, const uint8_t *__restrict_
                 struct { uint64_t a, b; } two = {held, packed};
                 __builtin_memcpy(outp + (i - 1), &two, 16);
             } else held = packed;
-            const bool more = i + 1 < nseq; // the last sequence reads no state bits
-            sl = cell_base(cl, al_l) + b.take(more ? cell_nbits(cl, al_l) : 0u);
-            sm = cell_base(cm, al_m) + b.take(more ? cell_nbits(cm, al_m) : 0u);
-            so = cell_base(co, al_o) + b.take(more ? cell_nbits(co, al_o) : 0u);
+            sl = cell_base(cl, al_l) + b.take(nb_l);
+            sm = cell_base(cm, al_m) + b.take(nb_m);
+            so = cell_base(co, al_o) + b.take(nb_o);
             bad = bad || b.bitpos < 0;
         }
         ok = !bad && b.bitpos == 0;
@@ -1593,21 +1615,33 @@ __device__ int make_seq_table(uint16_t *tab, int t, const SeqHeader &own, const 
     return build_seq_table(tab, t, mode, src + off, mode == 2 ? len : (mode == 1 ? 1u : 0u));
 }
 
+// (see zarc_zdec_seqs_lds) does this lane's 16-slot subgroup hold a block with a long chain?  All lanes of the subgroup call it.
+__device__ __forceinline__ bool zdec_long_subgroup(uint32_t my_nseq /* 0 for a lane without a compressed block */, int lane)
+{
+    uint32_t m = my_nseq;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) { const uint32_t o = zd::shfl(m, lane ^ d); m = o > m ? o : m; }
+    return m >= ZDEC_LONG_NSEQ;
+}
+
 // Stage 2: one lane per block slot, every lane with its own table set in HBM scratch.  With `wave_flag` (the launch behind
 // zarc_zdec_seqs_shared) only the waves that kernel turned down do anything.
 __global__ void __launch_bounds__(64) zarc_zdec_seqs(const uint8_t *__restrict__ frames_base, const uint64_t *__restrict__ frame_off, uint64_t n_slots,
                                                      const uint64_t *__restrict__ slot_prefix, ZdecBlock *__restrict__ zblocks,
                                                      const uint64_t *__restrict__ seq_index, uint64_t *__restrict__ seqs, uint16_t *__restrict__ tables,
                                                      uint32_t *__restrict__ fast, uint64_t slot_base, const uint32_t *__restrict__ wave_flag,
-                                                     const uint16_t *__restrict__ predef)
+                                                     const uint16_t *__restrict__ predef, int split_long)
 {
     // every lane builds the tables of its block: the builder's 64 counters live in LDS (two local arrays became registers selected by
     // compare chains, ~130 instructions per access -- most of this kernel's time on small blocks)
     __shared__ int16_t T_scratch[64 * 64];
     if (wave_flag && !wave_flag[blockIdx.x]) return; // (launched with 64 lanes per workgroup then: the flags are per 64 slots)
     const uint64_t s = slot_base + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; // slots [slot_base, n_slots); waves may be partly filled (engine.hip)
+    ZdecBlock zb;
+    zb.type = 0xFFFFFFFFu; zb.nseq = 0;
+    if (s < n_slots) zb = zblocks[s];
+    if (split_long && zdec_long_subgroup(zb.type == 2 ? zb.nseq : 0u, (int)threadIdx.x)) return; // zarc_zdec_seqs_lds has this 16-slot subgroup
     if (s >= n_slots) return;
-    const ZdecBlock zb = zblocks[s];
     if (zb.type != 2 || zb.nseq == 0) return;
     const uint32_t f = zb.frame;
     if (!fast[f]) return;
@@ -1770,95 +1804,50 @@ __global__ void __launch_bounds__(16) zarc_zdec_seqs_shared16(const uint8_t *__r
     zdec_seqs_shared_body<16, 3>(frames_base, frame_off, n_slots, slot_prefix, zblocks, seq_index, seqs, fast, slot_base, wave_flag);
 }
 
-// Stage 2, tables in LDS.  The lookups of zarc_zdec_seqs go to 80 000 different 2.5 KiB tables: every 2-byte lookup costs a
-// cache line from HBM / MALL (about 170 GB per launch on BASELINE configs[1]).  Here a workgroup is ONE wave with 16 active
-// lanes and their tables in LDS (40 KiB, four workgroups per CU, one per SIMD): fewer blocks in flight, but each sequence is
-// a chain of ALU work plus one LDS access instead of an HBM round trip.
+// Blocks with long chains that share no tables (libzstd's frames: a table set per block; the engine's own mid-sized frames, a workgroup's 64
+// slots spread over a dozen of them).  With the tables in HBM scratch every step of zarc_zdec_seqs is a round trip to L2 / HBM per lookup, and
+// the kernel lasts as long as its longest block (3 000 sequences x 2 - 5 us).  Here a lane keeps ITS OWN three tables in LDS (2.5 KiB; 16 lanes
+// per workgroup) and a step is the straight-line code of the shared-table kernel.  Which blocks: a 16-slot subgroup with a block of at least
+// ZDEC_LONG_NSEQ sequences comes here, every other subgroup stays with zarc_zdec_seqs -- both kernels work the rule out from the same slots
+// (zdec_long_subgroup), so every slot is decoded exactly once.
 __global__ void __launch_bounds__(ZDEC_LDS_LANES) zarc_zdec_seqs_lds(const uint8_t *__restrict__ frames_base, const uint64_t *__restrict__ frame_off,
                                                                      uint64_t n_slots, const uint64_t *__restrict__ slot_prefix, ZdecBlock *__restrict__ zblocks,
                                                                      const uint64_t *__restrict__ seq_index, uint64_t *__restrict__ seqs, uint32_t *__restrict__ fast,
-                                                                     uint64_t slot_base)
+                                                                     uint64_t slot_base, const uint32_t *__restrict__ wave_flag)
 {
+    static_assert(ZDEC_LDS_LANES == 16, "the subgroups of zdec_long_subgroup");
     __shared__ uint16_t T[ZDEC_LDS_LANES][ZDEC_TABLE_CELLS];
+    __shared__ uint32_t T_info[128];
+    __shared__ int16_t T_scratch[64][ZDEC_LDS_LANES]; // entry i of lane l at [i][l]
     const int l = (int)threadIdx.x;
+    if (wave_flag && !wave_flag[blockIdx.x / (64 / ZDEC_LDS_LANES)]) return; // uniform: the shared-table kernel has done these 64 slots
+    for (int i = l; i < 128; i += ZDEC_LDS_LANES) T_info[i] = seq_code_info((uint32_t)i);
     const uint64_t s = slot_base + (uint64_t)blockIdx.x * ZDEC_LDS_LANES + (uint64_t)l; // slots [slot_base, n_slots)
-    if (s >= n_slots) return;
-    const ZdecBlock zb = zblocks[s];
-    if (zb.type != 2 || zb.nseq == 0) return;
+    ZdecBlock zb;
+    zb.type = 0xFFFFFFFFu; zb.nseq = 0; zb.frame = 0; zb.payload = 0; zb.size = 0; zb.seq_hdr = 0; zb.lit_len = 0;
+    if (s < n_slots) zb = zblocks[s];
+    const uint32_t nsq = zb.type == 2 ? zb.nseq : 0u;
+    if (!zdec_long_subgroup(nsq, l)) return; // uniform over the workgroup's 16 lanes
+    zd::wave_sync();
+    if (nsq == 0) return;
     const uint32_t f = zb.frame;
     if (!fast[f]) return;
     const uint8_t *src = frames_base + frame_off[f];
     const uint32_t end = zb.payload + zb.size;
     SeqHeader own;
     bool ok = scan_seq_header(src, zb.seq_hdr, end, &own);
-    int al_l = 0, al_o = 0, al_m = 0;
-    if (ok) { al_l = make_seq_table(&T[l][0], 0, own, src, s, f, slot_prefix, zblocks); ok = al_l >= 0; }
-    if (ok) { al_o = make_seq_table(&T[l][1024], 1, own, src, s, f, slot_prefix, zblocks); ok = al_o >= 0; }
-    if (ok) { al_m = make_seq_table(&T[l][512], 2, own, src, s, f, slot_prefix, zblocks); ok = al_m >= 0; }
-    // repeat-offset history, symbolic: hv = offset (hr = 0) or hv = slot | delta << 2 of the history at block start (hr = 1)
-    uint32_t hv0 = 0, hv1 = 1, hv2 = 2, hr0 = 1, hr1 = 1, hr2 = 1;
-    uint32_t bpos_ = 0, reach_ = 0, msum_ = 0; // output position inside the block, farthest reach in front of it, sum of the match lengths
-    if (ok) {
-        Bits128 b;
-        ok = b.init(src + own.bits_off, end - own.bits_off);
-        uint32_t sl = 0, so = 0, sm = 0;
-        if (ok) { b.request(); b.settle(); sl = b.take((uint32_t)al_l); so = b.take((uint32_t)al_o); sm = b.take((uint32_t)al_m); ok = b.bitpos >= 0; } // <= 7 + 26 bits
-        uint64_t *outp = seqs + seq_index[s];
-        for (uint32_t i = 0; i < zb.nseq && ok; i++) {
-            b.request(); // one bitstream window per sequence, in flight during the table lookups
-            const uint32_t cl = T[l][sl], co = T[l][1024 + so], cm = T[l][512 + sm];
-            b.settle();
-            const uint32_t ofc = cell_sym(co), mlc = cell_sym(cm), llc = cell_sym(cl);
-            if (ofc > 27 || mlc > 52 || llc > 35) { ok = false; break; } // offsets past the format's largest window: left to the frame pass
-            const uint32_t ofv = (1u << ofc) + b.take(ofc);                // phase 1: <= 7 + 27 + 16 bits
-            uint32_t mbase, mbits, lbase, lbits;
-            ml_code_info(mlc, mbase, mbits);
-            ll_code_info(llc, lbase, lbits);
-            const uint32_t ml = mbase + b.take(mbits);
-            b.second_phase();                                              // phase 2: <= 16 + 9 + 9 + 8 bits
-            const uint32_t ll = lbase + b.take(lbits);
-            uint32_t ov, orf; // this sequence's offset, same symbolic form
-            if (ofv > 3) { ov = ofv - 3; orf = 0; hv2 = hv1; hr2 = hr1; hv1 = hv0; hr1 = hr0; hv0 = ov; hr0 = orf; }
-            else {
-                const uint32_t idx = ofv - 1 + (ll == 0 ? 1u : 0u);
-                if (idx == 0) { ov = hv0; orf = hr0; }
-                else {
-                    if (idx == 1) { ov = hv1; orf = hr1; }
-                    else if (idx == 2) { ov = hv2; orf = hr2; }
-                    else { // first history entry minus one
-                        ov = hv0; orf = hr0;
-                        if (orf) { if ((ov >> 2) >= ZDEC_MAX_DELTA) { ok = false; break; } ov += 4; } // delta + 1 (only absurd chains are left to the frame pass)
-                        else { if (ov <= 1) { ok = false; break; } ov -= 1; }
-                    }
-                    if (idx > 1) { hv2 = hv1; hr2 = hr1; }
-                    hv1 = hv0; hr1 = hr0;
-                    hv0 = ov; hr0 = orf;
-                }
-            }
-            // where this match's source starts, relative to the block: in front of it by `reach` bytes at most (an offset that still
-            // refers to the history at the block's start is not known here)
-            bpos_ += ll;
-            if (orf) reach_ = ZDEC_REACH_UNKNOWN; else if (ov > bpos_ && ov - bpos_ > reach_) reach_ = ov - bpos_;
-            bpos_ += ml; msum_ += ml;
-            zd::store_streaming(outp + i, zge_pack_seq(ll | (orf ? ZDEC_LL_REF : 0u), ml, ov)); // written once, read by the frame pass: keep it out of the way of the tables
-            if (i + 1 < zb.nseq) {
-                sl = cell_base(cl, al_l) + b.take(cell_nbits(cl, al_l));
-                sm = cell_base(cm, al_m) + b.take(cell_nbits(cm, al_m));
-                so = cell_base(co, al_o) + b.take(cell_nbits(co, al_o));
-            }
-            if (b.bitpos < 0) ok = false;
-        }
-        if (ok && b.bitpos != 0) ok = false;
+    int al[3] = {0, 0, 0};
+    uint16_t *const tabs[3] = {&T[l][0], &T[l][1024], &T[l][512]}; // LL, OF, ML
+    for (int t = 0; t < 3 && ok; t++) {
+        uint32_t mode, off, len;
+        uint64_t owner;
+        ok = seq_table_source(t, own, src, s, f, slot_prefix, zblocks, &mode, &off, &len, &owner);
+        if (!ok) break;
+        al[t] = build_seq_table(tabs[t], t, mode, src + off, mode == 2 ? len : (mode == 1 ? 1u : 0u), Strided16<ZDEC_LDS_LANES>{&T_scratch[0][l]});
+        if (al[t] < 0) ok = false;
     }
-    if (ok) {
-        zblocks[s].rep[0] = hr0 ? (ZDEC_REP_REF | hv0) : hv0;
-        zblocks[s].rep[1] = hr1 ? (ZDEC_REP_REF | hv1) : hv1;
-        zblocks[s].rep[2] = hr2 ? (ZDEC_REP_REF | hv2) : hv2;
-        zblocks[s].pad[0] = reach_;
-        zblocks[s].pad[1] = zb.lit_len + msum_;
-        zblocks[s].state = 1;
-    }
-    else fast[f] = 0; // the frame pass decodes this frame inline and reports whatever is wrong with it
+    seq_chain128<ZDEC_LDS_TAB, ZDEC_LDS_INFO>(ok, src, zb, own, end, (ZDEC_LDS_TAB)tabs[0], (ZDEC_LDS_TAB)tabs[1], (ZDEC_LDS_TAB)tabs[2], al[0], al[1], al[2],
+                                           (ZDEC_LDS_INFO)&T_info[0], seqs + seq_index[s], zblocks + s, fast + f);
 }
 
 
