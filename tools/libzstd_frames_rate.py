@@ -41,6 +41,8 @@ def run(frames, label):
 
 run([f for f, _ in eng.pack(ents)], "engine frames (L3)")
 for lv in levels:
-    with ThreadPoolExecutor(16) as ex:
-        frames = list(ex.map(lambda e: z.compress(e, lv, 1), ents))
+    if os.environ.get("ZARC_TOOL_THREADS") == "1": frames = [z.compress(e, lv, 1) for e in ents]   # (under rocprofv3: its preloaded tool does not survive the pool)
+    else:
+        with ThreadPoolExecutor(16) as ex:
+            frames = list(ex.map(lambda e: z.compress(e, lv, 1), ents))
     run(frames, "libzstd %s -%d" % (z.version, lv))

@@ -1,8 +1,8 @@
 #!/bin/bash
 # kernel times of unpacking libzstd's frames (tools/libzstd_frames_rate.py) under rocprofv3 --kernel-trace --stats
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/kt_long; mkdir -p $O
-cd /tmp && export TMPDIR=/tmp
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O -- python3 $R/tools/libzstd_frames_rate.py 2048 3 > $O/log.txt 2>&1
+cd /tmp && export TMPDIR=/tmp ZARC_TOOL_THREADS=1
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O -- python3 $R/tools/libzstd_frames_rate.py 1024 3 > $O/log.txt 2>&1
 tail -3 $O/log.txt
 python3 - <<PY
 import csv, glob
