@@ -72,7 +72,7 @@ struct zarc_gpu {
     DevBuf d_blocks, d_seq, d_lit, d_out, d_far, d_plan, d_groups;
     // decoder
     DevBuf d_declit, d_status, d_stored_ck;
-    DevBuf d_slot_prefix, d_zblocks, d_nseq, d_fast, d_seqidx, d_seqs, d_ztables, d_litidx, d_lits, d_seqflag, d_totals, d_predef; // decoder fast path (sequences decoded ahead)
+    DevBuf d_slot_prefix, d_zblocks, d_nseq, d_fast, d_seqidx, d_seqs, d_ztables, d_litidx, d_lits, d_seqflag, d_totals, d_predef, d_longlist, d_longcnt; // decoder fast path (sequences decoded ahead)
     DevBuf d_queue; // frame queues of the persistent kernels (one u32 each)
     int num_cus = 1;
     int deep_per_cu = 0; // workgroups of zarc_zge_match_deep a CU holds (0: not asked yet)
@@ -974,6 +974,8 @@ int unpack_device_once(zarc_gpu_t *h, size_t n, const void *d_frames_base, const
             ZHIP(hipGetLastError());
         }
         ZHIP(h->d_seqflag.reserve((nslots / 16 + (size_t)zarc_gpu::DEC_GROUPS + 2) * 4));
+        ZHIP(h->d_longlist.reserve((nslots + 64) * 4));                                   // zarc_zdec_seqs_lds: the blocks with long chains, per group
+        ZHIP(h->d_longcnt.reserve((size_t)zarc_gpu::DEC_GROUPS * 64 * 4));                // ... and their counters (2 x ZDEC_LONG_BUCKETS + 1 words per group)
         ZHIP(hipMemsetAsync(h->d_zblocks.p, 0xFF, nslots * sizeof(ZdecBlock), h->stream));
         ZHIP(hipMemsetAsync(h->d_nseq.p, 0, nslots * 8, h->stream));
         hipLaunchKernelGGL(zarc_zdec_scan, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, h->stream, (const uint8_t *)d_frames_base, h->d_frame_off.as<uint64_t>(),
@@ -1089,12 +1091,20 @@ int unpack_device_once(zarc_gpu_t *h, size_t n, const void *d_frames_base, const
                                            h->d_fast.as<uint32_t>(), s0, flags);
                     }
                     if (split_long) {
+                        static_assert(2 * ZDEC_LONG_BUCKETS + 1 <= 64, "counter words per group");
+                        uint32_t *cnt = h->d_longcnt.as<uint32_t>() + (size_t)g * 64, *list = h->d_longlist.as<uint32_t>() + (size_t)s0;
+                        const unsigned w64 = (unsigned)((s1 - s0 + 63) / 64);
                         ZHIP(hipEventRecord(h->ev_fork3, sa));
                         ZHIP(hipStreamWaitEvent(h->stream3, h->ev_fork3, 0));
+                        ZHIP(hipMemsetAsync(cnt, 0, 64 * 4, h->stream3));
+                        hipLaunchKernelGGL(zarc_zdec_long_count, dim3(w64), dim3(64), 0, h->stream3, (const ZdecBlock *)h->d_zblocks.as<ZdecBlock>(), s0, s1,
+                                           (const uint32_t *)flags, cnt);
+                        hipLaunchKernelGGL(zarc_zdec_long_fill, dim3(w64), dim3(64), 0, h->stream3, (const ZdecBlock *)h->d_zblocks.as<ZdecBlock>(), s0, s1,
+                                           (const uint32_t *)flags, cnt, list);
                         hipLaunchKernelGGL(zarc_zdec_seqs_lds, dim3((unsigned)((s1 - s0 + ZDEC_LDS_LANES - 1) / ZDEC_LDS_LANES)), dim3(ZDEC_LDS_LANES), 0, h->stream3,
                                            (const uint8_t *)d_frames_base, h->d_frame_off.as<uint64_t>(), s1, h->d_slot_prefix.as<uint64_t>(),
                                            h->d_zblocks.as<ZdecBlock>(), h->d_seqidx.as<uint64_t>(), h->d_seqs.as<uint64_t>(), h->d_fast.as<uint32_t>(), s0,
-                                           (const uint32_t *)flags);
+                                           (const uint32_t *)cnt, (const uint32_t *)list);
                         ZHIP(hipGetLastError());
                         ZHIP(hipEventRecord(h->ev_join3, h->stream3));
                     }

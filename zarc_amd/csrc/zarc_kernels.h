@@ -89,7 +89,8 @@ struct ZdecBlock {
 };
 static_assert(sizeof(ZdecBlock) == 72, "block slot layout");
 constexpr int ZDEC_LDS_LANES = 16;  // active lanes (= block slots) per wave of zarc_zdec_seqs_lds: 16 x 2.5 KiB of tables in LDS
-constexpr uint32_t ZDEC_LONG_NSEQ = 768; // a block with at least this many sequences takes its 16-slot subgroup to zarc_zdec_seqs_lds
+constexpr uint32_t ZDEC_LONG_NSEQ = 768; // a block with at least this many sequences is zarc_zdec_seqs_lds's when the shared-table kernel has not done it
+constexpr int ZDEC_LONG_BUCKETS = 16;    // ... listed by sequence count in buckets of 1 024 (the last one: 15 360 and more)
 constexpr int ZDEC_LIT_GROUP = 16;  // block slots per wave of zarc_zdec_literals (4 Huffman streams each)
 // Fast-path sequences are stored with zge_pack_seq(); the offset field is already resolved against the repeat-offset history
 // as far as the block alone allows: bit 17 of the literal-length field set = the offset is (history slot at block start) - delta,
@@ -137,17 +138,21 @@ __global__ void zarc_zdec_scan(const uint8_t *frames_base, const uint64_t *frame
 // Huffman literals of the fast path: one wave per ZDEC_LIT_GROUP block slots (tables in LDS, one stream per lane) -> lits[]
 __global__ void zarc_zdec_literals(const uint8_t *frames_base, const uint64_t *frame_off, uint64_t n_slots, const uint64_t *slot_prefix,
                                    const ZdecBlock *zblocks, const uint64_t *lit_index, uint8_t *lits, uint32_t *fast, uint64_t slot_base);
-// stage 2, every lane's own tables in LDS (one wave of ZDEC_LDS_LANES active lanes per workgroup): the 16-slot subgroups that hold a block of
-// at least ZDEC_LONG_NSEQ sequences; zarc_zdec_seqs (split_long) leaves exactly those alone
+// stage 2, every lane's own tables in LDS (one wave of ZDEC_LDS_LANES active lanes per workgroup): the compressed blocks of at least
+// ZDEC_LONG_NSEQ sequences that zarc_zdec_seqs_shared has not done, from a list ordered by sequence count (zarc_zdec_long_count / _fill);
+// zarc_zdec_seqs (split_long) leaves exactly those alone
+__global__ void zarc_zdec_long_count(const ZdecBlock *zblocks, uint64_t slot_base, uint64_t n_slots, const uint32_t *wave_flag, uint32_t *counters);
+__global__ void zarc_zdec_long_fill(const ZdecBlock *zblocks, uint64_t slot_base, uint64_t n_slots, const uint32_t *wave_flag, uint32_t *counters,
+                                    uint32_t *list);
 __global__ void zarc_zdec_seqs_lds(const uint8_t *frames_base, const uint64_t *frame_off, uint64_t n_slots, const uint64_t *slot_prefix,
                                    ZdecBlock *zblocks, const uint64_t *seq_index, uint64_t *seqs, uint32_t *fast, uint64_t slot_base,
-                                   const uint32_t *wave_flag /* per 64 slots: zarc_zdec_seqs_shared's, or null */);
+                                   const uint32_t *counters, const uint32_t *list);
 // stage 2: one LANE per block slot entropy-decodes the block's sequences (FSE tables in HBM scratch) into seqs[]; with wave_flag only the
 // 64-slot waves zarc_zdec_seqs_shared turned down
 __global__ void zarc_zdec_seqs(const uint8_t *frames_base, const uint64_t *frame_off, uint64_t n_slots, const uint64_t *slot_prefix,
                                ZdecBlock *zblocks, const uint64_t *seq_index, uint64_t *seqs, uint16_t *tables, uint32_t *fast, uint64_t slot_base,
                                const uint32_t *wave_flag /* may be null */, const uint16_t *predef /* zarc_zdec_predef's tables, or null */,
-                               int split_long /* 1: subgroups with a long block are zarc_zdec_seqs_lds's */);
+                               int split_long /* 1: blocks with a long chain are zarc_zdec_seqs_lds's */);
 constexpr int ZDEC_PREDEF_LL = 0, ZDEC_PREDEF_OF = 64, ZDEC_PREDEF_ML = 96, ZDEC_PREDEF_CELLS = 160;
 __global__ void zarc_zdec_predef(uint16_t *out);
 // stage 2 with the tables shared by a wave's 64 blocks in LDS (Repeat_Mode / equal descriptions); sets wave_flag[wave] where they do not fit

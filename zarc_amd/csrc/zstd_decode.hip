@@ -1615,14 +1615,8 @@ __device__ int make_seq_table(uint16_t *tab, int t, const SeqHeader &own, const 
     return build_seq_table(tab, t, mode, src + off, mode == 2 ? len : (mode == 1 ? 1u : 0u));
 }
 
-// (see zarc_zdec_seqs_lds) does this lane's 16-slot subgroup hold a block with a long chain?  All lanes of the subgroup call it.
-__device__ __forceinline__ bool zdec_long_subgroup(uint32_t my_nseq /* 0 for a lane without a compressed block */, int lane)
-{
-    uint32_t m = my_nseq;
-#pragma unroll
-    for (int d = 1; d < 16; d <<= 1) { const uint32_t o = zd::shfl(m, lane ^ d); m = o > m ? o : m; }
-    return m >= ZDEC_LONG_NSEQ;
-}
+// (see zarc_zdec_seqs_lds) a block with a long chain: not this kernel's when the long-block kernel runs beside it
+__device__ __forceinline__ bool zdec_long_block(const ZdecBlock &zb) { return zb.type == 2 && zb.nseq >= ZDEC_LONG_NSEQ; }
 
 // Stage 2: one lane per block slot, every lane with its own table set in HBM scratch.  With `wave_flag` (the launch behind
 // zarc_zdec_seqs_shared) only the waves that kernel turned down do anything.
@@ -1640,7 +1634,7 @@ __global__ void __launch_bounds__(64) zarc_zdec_seqs(const uint8_t *__restrict__
     ZdecBlock zb;
     zb.type = 0xFFFFFFFFu; zb.nseq = 0;
     if (s < n_slots) zb = zblocks[s];
-    if (split_long && zdec_long_subgroup(zb.type == 2 ? zb.nseq : 0u, (int)threadIdx.x)) return; // zarc_zdec_seqs_lds has this 16-slot subgroup
+    if (split_long && zdec_long_block(zb)) return; // zarc_zdec_seqs_lds has it
     if (s >= n_slots) return;
     if (zb.type != 2 || zb.nseq == 0) return;
     const uint32_t f = zb.frame;
@@ -1806,30 +1800,66 @@ __global__ void __launch_bounds__(16) zarc_zdec_seqs_shared16(const uint8_t *__r
 
 // Blocks with long chains that share no tables (libzstd's frames: a table set per block; the engine's own mid-sized frames, a workgroup's 64
 // slots spread over a dozen of them).  With the tables in HBM scratch every step of zarc_zdec_seqs is a round trip to L2 / HBM per lookup, and
-// the kernel lasts as long as its longest block (3 000 sequences x 2 - 5 us).  Here a lane keeps ITS OWN three tables in LDS (2.5 KiB; 16 lanes
-// per workgroup) and a step is the straight-line code of the shared-table kernel.  Which blocks: a 16-slot subgroup with a block of at least
-// ZDEC_LONG_NSEQ sequences comes here, every other subgroup stays with zarc_zdec_seqs -- both kernels work the rule out from the same slots
-// (zdec_long_subgroup), so every slot is decoded exactly once.
+// the kernel lasts as long as its longest block (3 000 - 12 000 sequences x 2 - 5 us).  Here a lane keeps ITS OWN three tables in LDS (2.5 KiB;
+// 16 lanes per workgroup) and a step is the straight-line code of the shared-table kernel.  Which blocks: every compressed block of at least
+// ZDEC_LONG_NSEQ sequences that the shared-table kernel has not done (zdec_long_block; zarc_zdec_seqs leaves exactly those alone).  They are
+// listed first, ordered by sequence count in buckets of 1 024 (zarc_zdec_long_count / _fill: the lanes of a workgroup wait for the longest of
+// their sixteen chains, and neighbouring blocks differ by a factor of two and more), the longest first.
+__device__ __forceinline__ uint32_t zdec_long_bucket(uint32_t nseq) { const uint32_t b = nseq >> 10; return b < ZDEC_LONG_BUCKETS - 1 ? b : (uint32_t)ZDEC_LONG_BUCKETS - 1; }
+// counters[0 .. B) blocks per bucket, [B .. 2B) the fill cursors of zarc_zdec_long_fill, [2B] the total (all zero at launch)
+__global__ void __launch_bounds__(64) zarc_zdec_long_count(const ZdecBlock *__restrict__ zblocks, uint64_t slot_base, uint64_t n_slots,
+                                                           const uint32_t *__restrict__ wave_flag, uint32_t *__restrict__ counters)
+{
+    const uint64_t s = slot_base + (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    bool lng = false;
+    uint32_t bk = 0;
+    if (s < n_slots && (!wave_flag || wave_flag[blockIdx.x])) { const ZdecBlock zb = zblocks[s]; lng = zdec_long_block(zb); bk = zdec_long_bucket(zb.nseq); }
+#pragma unroll
+    for (uint32_t b = 0; b < (uint32_t)ZDEC_LONG_BUCKETS; b++) { // one atomic per wave and bucket
+        const uint64_t m = zd::ballot(lng && bk == b);
+        if (m && threadIdx.x == 0) { atomicAdd(counters + b, (uint32_t)__popcll(m)); atomicAdd(counters + 2 * ZDEC_LONG_BUCKETS, (uint32_t)__popcll(m)); }
+    }
+}
+__global__ void __launch_bounds__(64) zarc_zdec_long_fill(const ZdecBlock *__restrict__ zblocks, uint64_t slot_base, uint64_t n_slots,
+                                                          const uint32_t *__restrict__ wave_flag, uint32_t *__restrict__ counters, uint32_t *__restrict__ list)
+{
+    const uint64_t s = slot_base + (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    const int lane = (int)threadIdx.x;
+    bool lng = false;
+    uint32_t bk = 0;
+    if (s < n_slots && (!wave_flag || wave_flag[blockIdx.x])) { const ZdecBlock zb = zblocks[s]; lng = zdec_long_block(zb); bk = zdec_long_bucket(zb.nseq); }
+#pragma unroll
+    for (uint32_t b = 0; b < (uint32_t)ZDEC_LONG_BUCKETS; b++) {
+        const uint64_t m = zd::ballot(lng && bk == b);
+        if (m == 0) continue; // uniform
+        uint32_t at = 0;
+        if (lane == 0) {
+            uint32_t base = 0; // the longer buckets come first
+            for (uint32_t h = b + 1; h < (uint32_t)ZDEC_LONG_BUCKETS; h++) base += counters[h];
+            at = base + atomicAdd(counters + ZDEC_LONG_BUCKETS + b, (uint32_t)__popcll(m));
+        }
+        at = zd::uniform(at);
+        if (lng && bk == b) list[at + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = (uint32_t)(s - slot_base);
+    }
+}
 __global__ void __launch_bounds__(ZDEC_LDS_LANES) zarc_zdec_seqs_lds(const uint8_t *__restrict__ frames_base, const uint64_t *__restrict__ frame_off,
                                                                      uint64_t n_slots, const uint64_t *__restrict__ slot_prefix, ZdecBlock *__restrict__ zblocks,
                                                                      const uint64_t *__restrict__ seq_index, uint64_t *__restrict__ seqs, uint32_t *__restrict__ fast,
-                                                                     uint64_t slot_base, const uint32_t *__restrict__ wave_flag)
+                                                                     uint64_t slot_base, const uint32_t *__restrict__ counters, const uint32_t *__restrict__ list)
 {
-    static_assert(ZDEC_LDS_LANES == 16, "the subgroups of zdec_long_subgroup");
     __shared__ uint16_t T[ZDEC_LDS_LANES][ZDEC_TABLE_CELLS];
     __shared__ uint32_t T_info[128];
     __shared__ int16_t T_scratch[64][ZDEC_LDS_LANES]; // entry i of lane l at [i][l]
     const int l = (int)threadIdx.x;
-    if (wave_flag && !wave_flag[blockIdx.x / (64 / ZDEC_LDS_LANES)]) return; // uniform: the shared-table kernel has done these 64 slots
+    const uint32_t total = counters[2 * ZDEC_LONG_BUCKETS];
+    if ((uint64_t)blockIdx.x * ZDEC_LDS_LANES >= total) return; // uniform: the grid covers every slot, the list only the long ones
     for (int i = l; i < 128; i += ZDEC_LDS_LANES) T_info[i] = seq_code_info((uint32_t)i);
-    const uint64_t s = slot_base + (uint64_t)blockIdx.x * ZDEC_LDS_LANES + (uint64_t)l; // slots [slot_base, n_slots)
-    ZdecBlock zb;
-    zb.type = 0xFFFFFFFFu; zb.nseq = 0; zb.frame = 0; zb.payload = 0; zb.size = 0; zb.seq_hdr = 0; zb.lit_len = 0;
-    if (s < n_slots) zb = zblocks[s];
-    const uint32_t nsq = zb.type == 2 ? zb.nseq : 0u;
-    if (!zdec_long_subgroup(nsq, l)) return; // uniform over the workgroup's 16 lanes
     zd::wave_sync();
-    if (nsq == 0) return;
+    const uint32_t at = blockIdx.x * ZDEC_LDS_LANES + (uint32_t)l;
+    if (at >= total) return;
+    const uint64_t s = slot_base + list[at];
+    if (s >= n_slots) return; // (not reachable)
+    const ZdecBlock zb = zblocks[s];
     const uint32_t f = zb.frame;
     if (!fast[f]) return;
     const uint8_t *src = frames_base + frame_off[f];
