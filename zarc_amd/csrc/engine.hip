@@ -195,6 +195,34 @@ inline std::vector<uint32_t> order_by_size_desc(const uint64_t *len, size_t n)
     return order;
 }
 
+// The decoder's order: descending content size in steps of 4 KiB (what the groups, the piece lists of large frames and the XXH64 lanes
+// want), and among frames of one size step the better compressed first.  The lane-per-block and lane-per-stream kernels of stage 2 work
+// on consecutive frames, and a wave lasts as long as its longest lane: neighbours with the same share of matches and literals have
+// chains of a length (a batch that alternates text, records and incompressible entries kept half of every wave's lanes waiting).
+inline std::vector<uint32_t> order_for_decode(const uint64_t *raw_len, const uint64_t *frame_len, size_t n)
+{
+    auto key = [&](size_t i) -> uint32_t {
+        const uint64_t r = raw_len[i], c = frame_len[i];
+        const uint32_t dens = r ? (uint32_t)std::min<uint64_t>(4095, c * 4096 / r) : 4095u; // compressed share, 12 bits
+        return (~(uint32_t)(r >> 12) & 0xFFFFFu) << 12 | dens;                               // ascending: larger first, denser matches first
+    };
+    std::vector<uint32_t> order(n);
+    std::iota(order.begin(), order.end(), 0u);
+    if (n < 4096) { std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return key(a) < key(b); }); return order; }
+    std::vector<uint64_t> a(n), b(n);
+    for (size_t i = 0; i < n; i++) a[i] = (uint64_t)key(i) << 32 | (uint32_t)i;
+    for (int pass = 0; pass < 3; pass++) {
+        const int shift = 32 + 11 * pass;
+        size_t count[2049] = {0};
+        for (size_t i = 0; i < n; i++) count[(a[i] >> shift & 2047u) + 1]++;
+        for (int d = 0; d < 2048; d++) count[d + 1] += count[d];
+        for (size_t i = 0; i < n; i++) b[count[a[i] >> shift & 2047u]++] = a[i];
+        a.swap(b);
+    }
+    for (size_t i = 0; i < n; i++) order[i] = (uint32_t)a[i];
+    return order;
+}
+
 inline uint64_t chunks_of(uint64_t len) { return len == 0 ? 1 : (len + 1023) / 1024; }
 inline uint64_t blocks_of(uint64_t len) { return len == 0 ? 1 : (len + ZARC_BLOCK - 1) / ZARC_BLOCK; }
 
@@ -857,7 +885,7 @@ int unpack_device_once(zarc_gpu_t *h, size_t n, const void *d_frames_base, const
         if (frame_len_in[i] >= 0xFFFFFFF0ull || raw_len_in[i] >= 0xFFFFFFF0ull) { set_error(h, "frames of 4 GiB or more are not supported"); return ZARC_GPU_E_UNSUPPORTED; }
         total_raw += raw_len_in[i];
     }
-    const std::vector<uint32_t> order = order_by_size_desc(raw_len_in, n);
+    const std::vector<uint32_t> order = diag_env("ZARC_GPU_DEC_DENSITY", 1) ? order_for_decode(raw_len_in, frame_len_in, n) : order_by_size_desc(raw_len_in, n);
     std::vector<uint64_t> frame_off(n), frame_len(n), dst_off(n), raw_len(n);
     for (size_t i = 0; i < n; i++) { const uint32_t f = order[i]; frame_off[i] = frame_off_in[f]; frame_len[i] = frame_len_in[f]; dst_off[i] = dst_off_in[f]; raw_len[i] = raw_len_in[f]; }
     if ((rc = upload_u64(h, h->d_frame_off, frame_off.data(), n))) return rc;
