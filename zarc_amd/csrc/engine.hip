@@ -1095,9 +1095,9 @@ int unpack_device_once(zarc_gpu_t *h, size_t n, const void *d_frames_base, const
                 ZHIP(hipEventRecord(ev[0], sa));
                 {
                     // Waves whose 64 blocks share their tables (the engine's own frames: one table set per group of sixteen 64 KiB blocks; libzstd's
-                    // Repeat_Mode blocks) decode with the tables in LDS; the others raise their flag and are done by the launches behind it: 16-slot
-                    // subgroups that hold a block with a long chain by zarc_zdec_seqs_lds (every lane's own tables in LDS, on a side stream), the
-                    // rest by zarc_zdec_seqs with a table set per block in HBM scratch.
+                    // Repeat_Mode blocks) decode with the tables in LDS; the others raise their flag and are done by the launches behind it: blocks
+                    // with a long chain by zarc_zdec_seqs_lds (every lane's own tables in LDS, on a side stream, from a list ordered by sequence count),
+                    // the rest by zarc_zdec_seqs with a table set per block in HBM scratch.
                     // (a batch of small frames -- fewer than four blocks per frame on average -- has nothing to share: a workgroup's 64 blocks
                     // would belong to a dozen frames with a dozen table sets, and every workgroup would hand its blocks on after looking)
                     const bool shared = diag_env("ZARC_GPU_SEQ_SHARED", 1) != 0 && (s1 - s0) >= 4 * (uint64_t)ng;
